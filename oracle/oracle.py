@@ -1,0 +1,256 @@
+"""ctypes front-end of the CPU parity oracle (oracle/mvf_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; the product package never imports this module.
+
+Parity status: pinned against golden vectors captured from the reference
+(tests/golden/*.npz, checked by tests/test_oracle_golden.py).
+
+All functions take and return numpy fp32 arrays laid out like the reference's tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libmvf_oracle.so")
+
+NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "mvf_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+_fp = C.POINTER(C.c_float)
+_ip = C.POINTER(C.c_int32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.mvfo_smooth.restype = C.c_double
+        _lib.mvfo_losses_base_fwd.restype = C.c_double
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_fp)
+
+
+def _pi(a):
+    return None if a is None else a.ctypes.data_as(_ip)
+
+
+def depth_consts(min_depth, max_depth):
+    """(min_disp, range) rounded to fp32 the way the Python scalars of reference
+    layers.py:21-23 are when they meet the fp32 tensor."""
+    min_disp = 1 / max_depth
+    max_disp = 1 / min_depth
+    return np.float32(min_disp), np.float32(max_disp - min_disp)
+
+
+def disp_to_depth(disp, min_depth=0.1, max_depth=100.0):
+    disp = _f(disp)
+    md, rg = depth_consts(min_depth, max_depth)
+    scaled, depth = np.empty_like(disp), np.empty_like(disp)
+    lib().mvfo_disp_to_depth(_p(disp), _p(scaled), _p(depth), C.c_long(disp.size),
+                             C.c_float(md), C.c_float(rg))
+    return scaled, depth
+
+
+def backproject(depth, inv_K):
+    depth, inv_K = _f(depth), _f(inv_K)
+    B, _, H, W = depth.shape
+    cam = np.empty((B, 4, H * W), np.float32)
+    lib().mvfo_backproject(_p(depth), _p(inv_K), _p(cam), B, H, W)
+    return cam
+
+
+def proj_matrix(K, T):
+    K, T = _f(K), _f(T)
+    P = np.empty((K.shape[0], 3, 4), np.float32)
+    lib().mvfo_proj_matrix(_p(K), _p(T), _p(P), K.shape[0])
+    return P
+
+
+def project(cam, K, T, H, W, eps=1e-7):
+    cam, K, T = _f(cam), _f(K), _f(T)
+    B = cam.shape[0]
+    pix = np.empty((B, H, W, 2), np.float32)
+    lib().mvfo_project(_p(cam), _p(K), _p(T), _p(pix), B, H, W, C.c_float(eps))
+    return pix
+
+
+def grid_sample(img, grid, want_idx=False):
+    img, grid = _f(img), _f(grid)
+    B, Cc, H, W = img.shape
+    out = np.empty_like(img)
+    x0 = np.empty((B, H, W), np.int32)
+    y0 = np.empty((B, H, W), np.int32)
+    lib().mvfo_grid_sample(_p(img), _p(grid), _p(out), _pi(x0), _pi(y0), B, Cc, H, W)
+    return (out, x0, y0) if want_idx else out
+
+
+def grid_sample_bwd(img, grid, gout):
+    img, grid, gout = _f(img), _f(grid), _f(gout)
+    B, Cc, H, W = img.shape
+    gg = np.empty((B, H, W, 2), np.float32)
+    lib().mvfo_grid_sample_bwd(_p(img), _p(grid), _p(gout), _p(gg), B, Cc, H, W)
+    return gg
+
+
+def warp_fwd(disp, inv_K, K, T, src, min_depth=0.1, max_depth=100.0, eps=1e-7):
+    """-> dict(warped, pix, x0, y0) for one source (reference train.py:956-971)."""
+    disp, inv_K, K, T, src = _f(disp), _f(inv_K), _f(K), _f(T), _f(src)
+    B, _, H, W = disp.shape
+    md, rg = depth_consts(min_depth, max_depth)
+    warped = np.empty((B, 3, H, W), np.float32)
+    pix = np.empty((B, H, W, 2), np.float32)
+    x0 = np.empty((B, H, W), np.int32)
+    y0 = np.empty((B, H, W), np.int32)
+    lib().mvfo_warp_fwd(_p(disp), _p(inv_K), _p(K), _p(T), _p(src), _p(warped), _p(pix),
+                        _pi(x0), _pi(y0), B, H, W, C.c_float(md), C.c_float(rg), C.c_float(eps))
+    return dict(warped=warped, pix=pix, x0=x0, y0=y0)
+
+
+def warp_bwd(disp, inv_K, K, T, src, gwarped, gdisp=None, min_depth=0.1, max_depth=100.0,
+             eps=1e-7):
+    """-> (grad_disp accumulated, grad_T [B,4,4])."""
+    disp, inv_K, K, T, src, gwarped = map(_f, (disp, inv_K, K, T, src, gwarped))
+    B, _, H, W = disp.shape
+    md, rg = depth_consts(min_depth, max_depth)
+    if gdisp is None:
+        gdisp = np.zeros_like(disp)
+    gT = np.empty((B, 4, 4), np.float32)
+    lib().mvfo_warp_bwd(_p(disp), _p(inv_K), _p(K), _p(T), _p(src), _p(gwarped), _p(gdisp),
+                        _p(gT), B, H, W, C.c_float(md), C.c_float(rg), C.c_float(eps))
+    return gdisp, gT
+
+
+def ssim(x, y):
+    x, y = _f(x), _f(y)
+    B, Cc, H, W = x.shape
+    out = np.empty_like(x)
+    lib().mvfo_ssim(_p(x), _p(y), _p(out), B, Cc, H, W)
+    return out
+
+
+def ssim_bwd(x, y, gout):
+    x, y, gout = _f(x), _f(y), _f(gout)
+    B, Cc, H, W = x.shape
+    gx, gy = np.empty_like(x), np.empty_like(x)
+    lib().mvfo_ssim_bwd(_p(x), _p(y), _p(gout), _p(gx), _p(gy), B, Cc, H, W)
+    return gx, gy
+
+
+def reprojection(pred, tgt, no_ssim=False):
+    pred, tgt = _f(pred), _f(tgt)
+    B, _, H, W = pred.shape
+    out = np.empty((B, 1, H, W), np.float32)
+    lib().mvfo_reprojection(_p(pred), _p(tgt), _p(out), B, H, W, int(bool(no_ssim)))
+    return out
+
+
+def smooth(disp, img, normalise=True):
+    disp, img = _f(disp), _f(img)
+    B, _, H, W = disp.shape
+    mean = np.empty((B,), np.float32)
+    v = lib().mvfo_smooth(_p(disp), _p(img), B, H, W, int(normalise), _p(mean))
+    return float(v), mean
+
+
+def smooth_bwd(disp, img, scale, normalise=True, gdisp=None):
+    disp, img = _f(disp), _f(img)
+    B, _, H, W = disp.shape
+    if gdisp is None:
+        gdisp = np.zeros_like(disp)
+    lib().mvfo_smooth_bwd(_p(disp), _p(img), _p(gdisp), B, H, W, int(normalise), C.c_float(scale))
+    return gdisp
+
+
+def _ptr_array(arrs):
+    return (_fp * len(arrs))(*[a.ctypes.data_as(_fp) for a in arrs])
+
+
+def losses_base_fwd(tgt, warped, src, noise=None, mask_rec=None, flags=0):
+    """-> dict(photo, rp, idl, to_opt, idx).  warped/src: sequences of [B,3,H,W]."""
+    tgt = _f(tgt)
+    warped = [_f(w) for w in warped]
+    src = [_f(s) for s in src] if src is not None else warped
+    S = len(warped)
+    B, _, H, W = tgt.shape
+    noise = _f(noise) if noise is not None else np.zeros((B, S, H, W), np.float32)
+    mask = _f(mask_rec) if mask_rec is not None else None
+    rp = np.empty((B, S, H, W), np.float32)
+    idl = np.empty((B, S, H, W), np.float32)
+    to_opt = np.empty((B, H, W), np.float32)
+    idx = np.empty((B, H, W), np.int32)
+    photo = lib().mvfo_losses_base_fwd(_p(tgt), _ptr_array(warped), _ptr_array(src), _p(noise),
+                                       _p(mask), S, int(flags), _p(rp), _p(idl), _p(to_opt),
+                                       _pi(idx), B, H, W)
+    return dict(photo=float(photo), rp=rp, idl=idl, to_opt=to_opt, idx=idx)
+
+
+def losses_base_bwd(tgt, warped, idx, mask_rec=None, flags=0, gloss=1.0):
+    tgt = _f(tgt)
+    warped = [_f(w) for w in warped]
+    S = len(warped)
+    B, _, H, W = tgt.shape
+    mask = _f(mask_rec) if mask_rec is not None else None
+    idx = np.ascontiguousarray(idx, np.int32)
+    gw = [np.empty((B, 3, H, W), np.float32) for _ in range(S)]
+    lib().mvfo_losses_base_bwd(_p(tgt), _ptr_array(warped), _pi(idx), _p(mask), S, int(flags),
+                               C.c_float(gloss), _ptr_array(gw), B, H, W)
+    return gw
+
+
+def pose(axisangle, translation, invert=False):
+    aa = _f(axisangle).reshape(-1, 3)
+    tr = _f(translation).reshape(-1, 3)
+    M = np.empty((aa.shape[0], 4, 4), np.float32)
+    lib().mvfo_pose(_p(aa), _p(tr), int(bool(invert)), _p(M), aa.shape[0])
+    return M
+
+
+def unit(disp, tgt, src, T, K, inv_K, noise=None, mask_rec=None, flags=0,
+         smoothness=1e-3, min_depth=0.1, max_depth=100.0, want_grads=False, gloss=1.0):
+    """One hot-path unit end to end: S x generate_images_pred + compute_losses_base
+    (reference train.py:956-1051).  src [S,B,3,H,W], T [S,B,4,4]."""
+    S = len(src)
+    w = [warp_fwd(disp, inv_K, K, T[k], src[k], min_depth, max_depth) for k in range(S)]
+    warped = [x["warped"] for x in w]
+    automask = not (flags & NO_AUTOMASK)
+    fw = losses_base_fwd(tgt, warped, list(src) if automask else None, noise, mask_rec, flags)
+    sm, _ = smooth(disp, tgt, normalise=True)
+    loss = fw["photo"] + smoothness * sm
+    out = dict(loss=loss, photo=fw["photo"], smooth=sm, warped=warped, to_opt=fw["to_opt"],
+               idx=fw["idx"], rp=fw["rp"], idl=fw["idl"], x0=[x["x0"] for x in w],
+               y0=[x["y0"] for x in w], pix=[x["pix"] for x in w])
+    n_id = 0 if not automask else (1 if flags & AVG_REPROJ else S)
+    if automask:
+        out["auto_mask"] = (fw["idx"] > n_id - 1).astype(np.float32)[:, None]
+    if want_grads:
+        gw = losses_base_bwd(tgt, warped, fw["idx"], mask_rec, flags, gloss)
+        gdisp = np.zeros_like(_f(disp))
+        gT = []
+        for k in range(S):
+            gdisp, g = warp_bwd(disp, inv_K, K, T[k], src[k], gw[k], gdisp, min_depth, max_depth)
+            gT.append(g)
+        gdisp = smooth_bwd(disp, tgt, gloss * smoothness, True, gdisp)
+        out.update(grad_disp=gdisp, grad_T=np.stack(gT, 0), grad_warped=gw)
+    return out

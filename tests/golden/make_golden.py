@@ -1,0 +1,404 @@
+#!/usr/bin/env python3
+"""Capture golden vectors for the view-synthesis hot path from the reference.
+
+Runs ONLY in the build container (needs /root/reference, which never travels to
+the GPU box).  It imports the reference's ``layers.py`` unmodified and
+``train.py`` behind six stub modules (the absent third-party deps), calls the
+reference functions on inputs drawn from ``mono-vifi_amd/synthetic.py`` and
+stores inputs + outputs as small ``.npz`` fixtures next to this file.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+What is captured is DATA (inputs and the reference's numeric outputs); no
+reference source text enters the repository.
+"""
+import hashlib
+import importlib.util
+import os
+import sys
+import types
+from types import SimpleNamespace
+
+import numpy as np
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+import torch  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def _load_synth():
+    spec = importlib.util.spec_from_file_location(
+        "mvf_synthetic", os.path.join(ROOT, "mono-vifi_amd", "synthetic.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+synth = _load_synth()
+
+
+def _import_reference():
+    sys.path.insert(0, REF)
+    import layers  # noqa
+    tv = types.ModuleType("torchvision")
+    tv.transforms = types.ModuleType("torchvision.transforms")
+    tv.transforms.functional = types.ModuleType("torchvision.transforms.functional")
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.transforms"] = tv.transforms
+    sys.modules["torchvision.transforms.functional"] = tv.transforms.functional
+    tb = types.ModuleType("torch.utils.tensorboard")
+    tb.SummaryWriter = object
+    sys.modules["torch.utils.tensorboard"] = tb
+    thop = types.ModuleType("thop")
+    thop.profile = thop.clever_format = None
+    sys.modules["thop"] = thop
+    opt_mod = types.ModuleType("options")
+    opt_mod.opts = SimpleNamespace()
+    sys.modules["options"] = opt_mod
+    ds = types.ModuleType("datasets")
+    ds.__all__ = []
+    sys.modules["datasets"] = ds
+    nw = types.ModuleType("networks")
+    nw.__all__ = []
+    sys.modules["networks"] = nw
+    import train  # noqa
+    return layers, train
+
+
+layers, train = _import_reference()
+Trainer = train.Trainer
+
+
+def fake_self(B, H, W, **flags):
+    opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False,
+                          avg_reprojection=False, disable_automasking=False,
+                          disparity_smoothness=1e-3, batch_size=B, height=H, width=W)
+    for k, v in flags.items():
+        setattr(opt, k, v)
+    fs = SimpleNamespace(opt=opt, device=torch.device("cpu"), ssim=layers.SSIM(),
+                         backproject_depth=layers.BackprojectDepth(B, H, W),
+                         project_3d=layers.Project3D(B, H, W))
+    fs.compute_reprojection_loss = lambda pred, target: Trainer.compute_reprojection_loss(
+        fs, pred, target)
+    return fs
+
+
+class FixedRandn:
+    """Replace torch.randn inside compute_losses_base by a known draw."""
+
+    def __init__(self, noise):
+        self.noise = noise
+        self.orig = torch.randn
+
+    def __enter__(self):
+        noise = self.noise
+
+        def _randn(shape, *a, **k):
+            shape = tuple(shape)
+            assert tuple(noise.shape) == shape, (noise.shape, shape)
+            return noise.clone()
+        torch.randn = _randn
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn = self.orig
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def index_maps(pix, H, W):
+    """Integer top-left tap (x0,y0) of F.grid_sample(border, align_corners=True)
+    for a reference-produced grid (unnormalise -> clip -> floor, fp32)."""
+    gx, gy = pix[..., 0], pix[..., 1]
+    ix = ((gx + 1) / 2) * (W - 1)
+    iy = ((gy + 1) / 2) * (H - 1)
+    ix = torch.clamp(ix, 0, W - 1)
+    iy = torch.clamp(iy, 0, H - 1)
+    return torch.floor(ix).to(torch.int32), torch.floor(iy).to(torch.int32)
+
+
+def poses_from(inp, invert_second=True):
+    S = inp["axisangle"].shape[0]
+    Ts = []
+    for k in range(S):
+        Ts.append(layers.transformation_from_parameters(
+            t(inp["axisangle"][k]), t(inp["translation"][k]),
+            invert=(invert_second and k == 1)))
+    return Ts
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if v is None:
+            continue
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+# ----------------------------------------------------------------------------- G1
+def g1_geometry():
+    B, H, W = 2, 24, 40
+    cases = {}
+    for seed in (0, 1, 2):
+        cases[f"seed{seed}"] = synth.unit_inputs(100 + seed, B, H, W, pose_scale=0.02)
+    ident = synth.unit_inputs(110, B, H, W)
+    ident["axisangle"][:] = 0
+    ident["translation"][:] = 0
+    cases["identity"] = ident
+    big = synth.unit_inputs(111, B, H, W)
+    big["axisangle"][0, :, 0, :] = np.array([0.1, 2.6, -0.2], np.float32)   # z <= 0 for many pixels
+    big["axisangle"][1, :, 0, :] = np.array([-1.2, 0.4, 0.9], np.float32)
+    big["translation"][:] *= 30
+    cases["bigrot"] = big
+    for name, inp in cases.items():
+        fs = fake_self(B, H, W)
+        Ts = poses_from(inp)
+        disp = t(inp["disp"])
+        _, depth = layers.disp_to_depth(disp, 0.1, 100.0)
+        cam = fs.backproject_depth(depth, t(inp["inv_K"]))
+        out = dict(disp=inp["disp"], src=inp["src"], axisangle=inp["axisangle"],
+                   translation=inp["translation"], K=inp["K"], inv_K=inp["inv_K"],
+                   depth=depth, cam_points=cam)
+        for k, T in enumerate(Ts):
+            pix = fs.project_3d(cam, t(inp["K"]), T)
+            x0, y0 = index_maps(pix, H, W)
+            warped = Trainer.generate_images_pred(
+                fs, {("disp", 0): disp}, T, t(inp["src"][k]), t(inp["K"]), t(inp["inv_K"]))
+            out[f"T{k}"] = T
+            out[f"P{k}"] = torch.matmul(t(inp["K"]), T)[:, :3, :]
+            out[f"pix{k}"] = pix
+            out[f"x0_{k}"] = x0
+            out[f"y0_{k}"] = y0
+            out[f"warped{k}"] = warped
+        save("g1_geom_" + name, **out)
+
+
+# ----------------------------------------------------------------------------- G2
+def restated_min(fs, rp, idl, noise, mask):
+    """to_optimise / idxs exactly as reference train.py:1010-1039 composes them
+    from the reference-computed per-source maps (checked against the reference's
+    own loss and auto_mask by the caller)."""
+    opt = fs.opt
+    rp = torch.cat(rp, 1)
+    if not opt.disable_automasking:
+        idl = torch.cat(idl, 1)
+        if opt.avg_reprojection:
+            idl = idl.mean(1, keepdim=True)
+    if opt.avg_reprojection:
+        rp = rp.mean(1, keepdim=True)
+    if not opt.disable_automasking:
+        idl = idl + noise * 0.00001
+        combined = torch.cat((idl, rp), 1)
+    else:
+        combined = rp
+    if combined.shape[1] == 1:
+        to_opt, idxs = combined, None
+    else:
+        to_opt, idxs = torch.min(combined, dim=1)
+    if mask is not None:
+        to_opt = to_opt * mask[:, 0]
+    return combined, to_opt, idxs
+
+
+def g2_photometric():
+    B, H, W = 2, 24, 40
+    variants = {
+        "default": dict(),
+        "mask": dict(_mask=True),
+        "no_ssim": dict(no_ssim=True),
+        "avg": dict(avg_reprojection=True),
+        "noauto": dict(disable_automasking=True),
+        "noauto_mask": dict(disable_automasking=True, _mask=True),
+    }
+    for vi, (name, flags) in enumerate(variants.items()):
+        use_mask = flags.pop("_mask", False)
+        inp = synth.unit_inputs(200 + vi, B, H, W, pose_scale=0.02, with_mask=use_mask)
+        fs = fake_self(B, H, W, **flags)
+        Ts = poses_from(inp)
+        disp = t(inp["disp"])
+        tgt = t(inp["tgt"])
+        srcs = [t(inp["src"][k]) for k in range(2)]
+        warped = [Trainer.generate_images_pred(fs, {("disp", 0): disp}, Ts[k], srcs[k],
+                                               t(inp["K"]), t(inp["inv_K"])) for k in range(2)]
+        mask = t(inp["mask_rec"]) if use_mask else None
+        noise_full = t(inp["noise"])
+        noise = noise_full[:, :1] if fs.opt.avg_reprojection else noise_full
+        with FixedRandn(noise):
+            loss, auto_mask = Trainer.compute_losses_base(
+                fs, {("disp", 0): disp}, tgt, warped, srcs, mask)
+        rp = [Trainer.compute_reprojection_loss(fs, w, tgt) for w in warped]
+        idl = [Trainer.compute_reprojection_loss(fs, s, tgt) for s in srcs]
+        combined, to_opt, idxs = restated_min(fs, rp, idl, noise, mask)
+        mean_disp = disp.mean(2, True).mean(3, True)
+        smooth = layers.get_smooth_loss(disp / (mean_disp + 1e-7), tgt)
+        loss2 = to_opt.mean() + fs.opt.disparity_smoothness * smooth
+        assert torch.equal(loss, loss2), (name, float(loss), float(loss2))
+        if auto_mask is not None:
+            n_id = 1 if fs.opt.avg_reprojection else 2
+            assert torch.equal(auto_mask, (idxs > n_id - 1).float().unsqueeze(1))
+        ssim0 = fs.ssim(warped[0], tgt)
+        save("g2_photo_" + name,
+             disp=inp["disp"], tgt=inp["tgt"], src=inp["src"], warped=torch.stack(warped, 0),
+             noise=noise, mask_rec=inp["mask_rec"],
+             flags=np.array([int(fs.opt.no_ssim), int(fs.opt.avg_reprojection),
+                             int(fs.opt.disable_automasking)], np.int32),
+             ssim0=ssim0, rp=torch.cat(rp, 1), idl=torch.cat(idl, 1),
+             combined=combined, to_opt=to_opt,
+             idxs=(idxs.to(torch.int32) if idxs is not None else None),
+             auto_mask=auto_mask, loss=loss, smooth=smooth)
+
+
+# ----------------------------------------------------------------------------- G3
+def run_unit_with_grads(fs, inp, use_mask, upstream=1.0):
+    aa = t(inp["axisangle"]).clone().requires_grad_(True)
+    tr = t(inp["translation"]).clone().requires_grad_(True)
+    disp = t(inp["disp"]).clone().requires_grad_(True)
+    tgt = t(inp["tgt"])
+    srcs = [t(inp["src"][k]) for k in range(2)]
+    Ts, warped = [], []
+    for k in range(2):
+        T = layers.transformation_from_parameters(aa[k], tr[k], invert=(k == 1))
+        T.retain_grad()
+        Ts.append(T)
+        w = Trainer.generate_images_pred(fs, {("disp", 0): disp}, T, srcs[k],
+                                         t(inp["K"]), t(inp["inv_K"]))
+        w.retain_grad()
+        warped.append(w)
+    mask = t(inp["mask_rec"]) if use_mask else None
+    noise_full = t(inp["noise"])
+    noise = noise_full[:, :1] if fs.opt.avg_reprojection else noise_full
+    with FixedRandn(noise):
+        loss, auto_mask = Trainer.compute_losses_base(
+            fs, {("disp", 0): disp}, tgt, warped, srcs, mask)
+    (loss * upstream).backward()
+    return dict(loss=loss, auto_mask=auto_mask, grad_disp=disp.grad, grad_axisangle=aa.grad,
+                grad_translation=tr.grad, grad_T=torch.stack([T.grad for T in Ts], 0),
+                grad_warped=torch.stack([w.grad for w in warped], 0),
+                T=torch.stack([T.detach() for T in Ts], 0),
+                warped=torch.stack([w.detach() for w in warped], 0)), noise
+
+
+def g3_gradients():
+    B, H, W = 2, 24, 40
+    variants = {
+        "default": dict(),
+        "mask": dict(_mask=True),
+        "no_ssim": dict(no_ssim=True),
+        "avg": dict(avg_reprojection=True),
+        "noauto": dict(disable_automasking=True),
+    }
+    for vi, (name, flags) in enumerate(variants.items()):
+        use_mask = flags.pop("_mask", False)
+        inp = synth.unit_inputs(300 + vi, B, H, W, pose_scale=0.02, with_mask=use_mask)
+        fs = fake_self(B, H, W, **flags)
+        out, noise = run_unit_with_grads(fs, inp, use_mask, upstream=1.0)
+        save("g3_grad_" + name,
+             disp=inp["disp"], tgt=inp["tgt"], src=inp["src"], axisangle=inp["axisangle"],
+             translation=inp["translation"], K=inp["K"], inv_K=inp["inv_K"], noise=noise,
+             mask_rec=inp["mask_rec"],
+             flags=np.array([int(fs.opt.no_ssim), int(fs.opt.avg_reprojection),
+                             int(fs.opt.disable_automasking)], np.int32), **out)
+
+
+# ----------------------------------------------------------------------------- G4
+FULL_SHAPES = {"C1": (4, 192, 640), "C2": (12, 192, 640), "C4": (8, 320, 1024), "C5": (12, 192, 512)}
+
+
+def sample_idx(n, k=4096, seed=7):
+    rng = np.random.default_rng(seed)
+    return np.sort(rng.choice(n, size=min(k, n), replace=False))
+
+
+def g4_fullsize():
+    for name, (B, H, W) in FULL_SHAPES.items():
+        seed = 400 + list(FULL_SHAPES).index(name)
+        inp = synth.unit_inputs(seed, B, H, W, with_mask=True)
+        fs = fake_self(B, H, W)
+        out, noise = run_unit_with_grads(fs, inp, use_mask=True)
+        disp = t(inp["disp"])
+        _, depth = layers.disp_to_depth(disp, 0.1, 100.0)
+        cam = fs.backproject_depth(depth, t(inp["inv_K"]))
+        sha = {}
+        for k in range(2):
+            pix = fs.project_3d(cam, t(inp["K"]), out["T"][k])
+            x0, y0 = index_maps(pix, H, W)
+            sha[f"sha_x0_{k}"] = hashlib.sha256(x0.numpy().tobytes()).hexdigest()
+            sha[f"sha_y0_{k}"] = hashlib.sha256(y0.numpy().tobytes()).hexdigest()
+        n = B * H * W
+        sidx = sample_idx(n)
+        save("g4_full_" + name,
+             shape=np.array([B, H, W], np.int32), seed=np.array(seed, np.int32),
+             loss=out["loss"], auto_mask_mean=out["auto_mask"].mean(),
+             sample_idx=sidx,
+             warped0_s=out["warped"][0].permute(1, 0, 2, 3).reshape(3, n)[:, sidx],
+             warped1_s=out["warped"][1].permute(1, 0, 2, 3).reshape(3, n)[:, sidx],
+             grad_disp_s=out["grad_disp"].reshape(n)[sidx],
+             auto_mask_s=out["auto_mask"].reshape(n)[sidx],
+             grad_disp_norm=out["grad_disp"].double().norm(),
+             grad_disp_abs_sum=out["grad_disp"].double().abs().sum(),
+             T=out["T"], grad_T=out["grad_T"], grad_axisangle=out["grad_axisangle"],
+             grad_translation=out["grad_translation"],
+             **{k: np.array(v) for k, v in sha.items()})
+
+
+# ----------------------------------------------------------------------------- G5
+def g5_pose():
+    rng = np.random.default_rng(500)
+    aa = (0.5 * rng.standard_normal((8, 1, 3))).astype(np.float32)
+    tr = rng.standard_normal((8, 1, 3)).astype(np.float32)
+    aa[0] = 0            # zero rotation: angle + 1e-7 guard
+    aa[1] = [[3.0, 0.0, 0.0]]
+    aa[2] *= 0.01
+    tr[2] *= 0.01
+    wgt = rng.standard_normal((8, 4, 4)).astype(np.float32)
+    out = dict(axisangle=aa, translation=tr, weight=wgt)
+    for inv in (False, True):
+        a = t(aa).clone().requires_grad_(True)
+        b = t(tr).clone().requires_grad_(True)
+        M = layers.transformation_from_parameters(a, b, invert=inv)
+        (M * t(wgt)).sum().backward()
+        tag = "inv" if inv else "fwd"
+        out["M_" + tag] = M
+        out["grad_axisangle_" + tag] = a.grad
+        out["grad_translation_" + tag] = b.grad
+    save("g5_pose", **out)
+
+
+# ----------------------------------------------------------------------------- G6 (SSIM, smoothness standalone)
+def g6_ssim_smooth():
+    B, H, W = 2, 24, 40
+    inp = synth.unit_inputs(600, B, H, W)
+    x = t(inp["src"][0]).clone().requires_grad_(True)
+    y = t(inp["tgt"]).clone().requires_grad_(True)
+    wgt = t(np.random.default_rng(601).standard_normal((B, 3, H, W)).astype(np.float32))
+    s = layers.SSIM()(x, y)
+    (s * wgt).sum().backward()
+    # near-identical pair: the catastrophic-cancellation regime
+    x2 = (t(inp["tgt"]) + 1e-3 * wgt).clamp(0, 1)
+    s2 = layers.SSIM()(x2, t(inp["tgt"]))
+    disp = t(inp["disp"]).clone().requires_grad_(True)
+    sm = layers.get_smooth_loss(disp, t(inp["tgt"]))
+    sm.backward()
+    save("g6_ssim_smooth", x=inp["src"][0], y=inp["tgt"], weight=wgt, ssim=s,
+         grad_x=x.grad, grad_y=y.grad, x_near=x2, ssim_near=s2,
+         disp=inp["disp"], smooth=sm, grad_disp=disp.grad)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    fns = dict(g1=g1_geometry, g2=g2_photometric, g3=g3_gradients, g4=g4_fullsize,
+               g5=g5_pose, g6=g6_ssim_smooth)
+    for w in which:
+        fns[w]()
