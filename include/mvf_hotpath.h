@@ -1,0 +1,178 @@
+/*
+ * mvf_hotpath.h -- C ABI of the MI355X (gfx950) view-synthesis + photometric-loss hot path.
+ *
+ * The reference (LiuJF1226/Mono-ViFI) has no FFI: its boundary for this path is the Python
+ * API of layers.py plus three Trainer methods.  Each entry point below is the native body
+ * of one of those functions (cited as file:line relative to the reference root); the Python
+ * mirror in mono-vifi_amd/layers.py and mono-vifi_amd/trainer.py binds them with ctypes.
+ *
+ * Conventions
+ *  - all pointers are DEVICE pointers (HIP), fp32 unless stated, tensors contiguous in the
+ *    reference's layout: images [B,C,H,W], disp/depth [B,1,H,W], cam points [B,4,H*W],
+ *    sampling grid [B,H,W,2], K / inv_K / T [B,4,4] row-major;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); every call only
+ *    enqueues work -- no host synchronisation, no allocation, no global state;
+ *  - return value: hipError_t as int (0 = success); mvf_error_string() describes it;
+ *  - "exact mode" arithmetic: IEEE fp32, no FMA contraction except the
+ *    k-sequential fmaf chains of the two [3xk]@[kxN] matrix products, true divides -- the
+ *    integer sampling indices are bit-identical to the reference's CPU run.
+ *  - reductions are deterministic: per-workgroup partials in caller-provided workspace,
+ *    folded by a finishing kernel in a fixed order.
+ */
+#ifndef MVF_HOTPATH_H
+#define MVF_HOTPATH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVF_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define MVF_API __attribute__((visibility("default")))
+#else
+#define MVF_API
+#endif
+
+/* flags of compute_losses_base (reference: options.py --no_ssim / --avg_reprojection /
+ * --disable_automasking, used at train.py:979,1001,1010,1016) */
+#define MVF_NO_SSIM 1
+#define MVF_AVG_REPROJ 2
+#define MVF_NO_AUTOMASK 4
+
+#define MVF_MAX_SRC 4
+
+MVF_API int mvf_abi_version(void);
+MVF_API const char *mvf_error_string(int err);
+
+/* ---- a1: layers.disp_to_depth (layers.py:16-25) -------------------------------------
+ * scaled = min_disp + range*disp ; depth = 1/scaled.  min_disp = (float)(1/max_depth),
+ * range = (float)(1/min_depth - 1/max_depth) are rounded by the caller.  Either output may
+ * be NULL. */
+MVF_API int mvf_disp_to_depth_fwd(const float *disp, float *scaled, float *depth, int64_t n,
+                          float min_disp, float range, void *stream);
+/* g_disp = g_scaled*range - g_depth*range*depth^2 (either upstream may be NULL) */
+MVF_API int mvf_disp_to_depth_bwd(const float *disp, const float *g_scaled, const float *g_depth,
+                          float *g_disp, int64_t n, float min_disp, float range, void *stream);
+
+/* ---- a2: BackprojectDepth.forward (layers.py:192-197) --------------------------------
+ * cam[b,0:3,i] = depth[b,i] * (inv_K[b,:3,:3] @ [x,y,1]) ; cam[b,3,i] = 1 ; i = y*W+x */
+MVF_API int mvf_backproject_fwd(const float *depth, const float *inv_K, float *cam, int B, int H, int W,
+                        void *stream);
+/* g_depth[b,i] = sum_c g_cam[b,c,i] * ray_c(i) */
+MVF_API int mvf_backproject_bwd(const float *g_cam, const float *inv_K, float *g_depth, int B, int H,
+                        int W, void *stream);
+
+/* ---- a3: Project3D.forward (layers.py:211-222) ---------------------------------------
+ * P = (K@T)[:3] ; c = P@cam ; pix = ((c.xy/(c.z+eps)) / (W-1,H-1) - 0.5)*2, [B,H,W,2] */
+MVF_API int mvf_project_fwd(const float *cam, const float *K, const float *T, float *pix, int B, int H,
+                    int W, float eps, void *stream);
+/* g_cam [B,4,N] (may be NULL) and g_T [B,4,4] (may be NULL).  workspace: floats, size
+ * mvf_workspace_floats(B,H,W). */
+MVF_API int mvf_project_bwd(const float *cam, const float *K, const float *T, const float *g_pix,
+                    float *g_cam, float *g_T, float *workspace, int B, int H, int W, float eps,
+                    void *stream);
+
+/* ---- a4: F.grid_sample(img, grid, "bilinear", "border", align_corners=True) ----------
+ * call site train.py:966-969.  idx_xy (nullable) int32 [B,H,W,2] = top-left tap (x0,y0):
+ * the bit-exact integers of the parity contract. */
+MVF_API int mvf_grid_sample_fwd(const float *img, const float *grid, float *out, int32_t *idx_xy, int B,
+                        int C, int H, int W, void *stream);
+/* g_grid [B,H,W,2] (zero where the coordinate was clipped); g_img nullable, must be
+ * zero-initialised by the caller (scatter-add). */
+MVF_API int mvf_grid_sample_bwd(const float *img, const float *grid, const float *g_out, float *g_grid,
+                        float *g_img, int B, int C, int H, int W, void *stream);
+
+/* ---- a5: Trainer.generate_images_pred (train.py:956-971), fused per pixel -------------
+ * disp->depth->backproject->project->grid_sample for ONE source.  pix / idx_xy nullable. */
+MVF_API int mvf_warp_fwd(const float *disp, const float *inv_K, const float *K, const float *T,
+                 const float *src, float *warped, float *pix, int32_t *idx_xy, int B, int H,
+                 int W, float min_disp, float range, float eps, void *stream);
+/* g_warped [B,3,H,W] -> g_disp [B,1,H,W] (overwritten, or added to when accumulate != 0)
+ * and g_T [B,4,4].  g_src nullable, zero-initialised by the caller (scatter-add).
+ * workspace: mvf_workspace_floats(B,H,W) floats. */
+MVF_API int mvf_warp_bwd(const float *disp, const float *inv_K, const float *K, const float *T,
+                 const float *src, const float *g_warped, float *g_disp, float *g_T, float *g_src,
+                 float *workspace, int accumulate, int B, int H, int W, float min_disp,
+                 float range, float eps, void *stream);
+
+/* ---- a6: SSIM.forward (layers.py:277-290) ---------------------------------------------*/
+MVF_API int mvf_ssim_fwd(const float *x, const float *y, float *out, int B, int C, int H, int W,
+                 void *stream);
+/* g_x, g_y: either may be NULL */
+MVF_API int mvf_ssim_bwd(const float *x, const float *y, const float *g_out, float *g_x, float *g_y,
+                 int B, int C, int H, int W, void *stream);
+
+/* ---- a7: Trainer.compute_reprojection_loss (train.py:973-985) -------------------------
+ * pred, target [B,3,H,W] -> out [B,1,H,W] = 0.85*mean_c SSIM + 0.15*mean_c |t-p| */
+MVF_API int mvf_reprojection_fwd(const float *pred, const float *target, float *out, int B, int H, int W,
+                         int no_ssim, void *stream);
+MVF_API int mvf_reprojection_bwd(const float *pred, const float *target, const float *g_out, float *g_pred,
+                         int B, int H, int W, int no_ssim, void *stream);
+
+/* ---- a9: get_smooth_loss (layers.py:231-242) ------------------------------------------
+ * out[0] = mean|dx disp|*exp(-mean_c|dx img|) + same for y.  normalise != 0 first divides
+ * disp by (per-image mean + 1e-7) as train.py:1044-1045 does.
+ * stats (nullable, [B,4] floats): per image {mean, den = mean+1e-7, sx_b, sy_b} saved for
+ * the backward.  workspace: mvf_workspace_floats(B,H,W). */
+MVF_API int mvf_smooth_fwd(const float *disp, const float *img, float *out, float *stats, float *workspace,
+                   int normalise, int B, int H, int W, void *stream);
+/* g_disp = (*g_loss) * scale * d smooth / d disp ; overwritten or accumulated */
+MVF_API int mvf_smooth_bwd(const float *disp, const float *img, const float *stats, const float *g_loss,
+                   float scale, float *g_disp, int accumulate, int normalise, int B, int H, int W,
+                   void *stream);
+
+/* ---- a8: Trainer.compute_losses_base (train.py:987-1051) ------------------------------
+ * warped[k], src[k]: S device pointers each (host arrays of device pointers), [B,3,H,W].
+ * noise: the standard-normal tie-break draw of train.py:1023-1024 BEFORE the 1e-5 scale,
+ * [B,n_id,H,W] with n_id = 1 if AVG_REPROJ else S (ignored when NO_AUTOMASK);
+ * mask_rec nullable [B,1,H,W].
+ * outputs: loss[0] = mean(to_optimise) + smoothness*smooth ; loss[1] = photometric mean ;
+ * loss[2] = smooth ; argmin uint8 [B,H,W] (candidate index, identity candidates first; 255
+ * when there is a single candidate) ; auto_mask nullable float [B,1,H,W] ; to_opt nullable
+ * float [B,H,W] ; stats [B,4] (see mvf_smooth_fwd).
+ * workspace: mvf_workspace_floats(B,H,W). */
+MVF_API int mvf_photo_fwd(const float *disp, const float *tgt, const float *const *warped,
+                  const float *const *src, const float *noise, const float *mask_rec, int S,
+                  int flags, float smoothness, float *loss, uint8_t *argmin, float *auto_mask,
+                  float *to_opt, float *stats, float *workspace, int B, int H, int W, void *stream);
+/* g_loss: device scalar.  g_warped[k] [B,3,H,W] overwritten; g_disp [B,1,H,W] overwritten
+ * with the smoothness gradient (nullable). */
+MVF_API int mvf_photo_bwd(const float *disp, const float *tgt, const float *const *warped,
+                  const uint8_t *argmin, const float *mask_rec, const float *stats,
+                  const float *g_loss, int S, int flags, float smoothness, float *const *g_warped,
+                  float *g_disp, int B, int H, int W, void *stream);
+
+/* ---- a5+a8 fused: one hot-path UNIT (S x generate_images_pred + compute_losses_base) ---
+ * The warped images never touch HBM: algorithmic traffic is disp 4 + tgt 12 + S*12 B/px
+ * read, 1 B/px (argmin) [+4 auto_mask] written.  T: [S,B,4,4].  src: S device pointers.
+ * idx_xy nullable int32 [S,B,H,W,2] (parity tests). */
+MVF_API int mvf_unit_fwd(const float *disp, const float *tgt, const float *const *src, const float *T,
+                 const float *K, const float *inv_K, const float *noise, const float *mask_rec,
+                 int S, int flags, float smoothness, float min_disp, float range, float eps,
+                 float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
+                 int32_t *idx_xy, float *workspace, int B, int H, int W, void *stream);
+/* g_disp [B,1,H,W] overwritten ; g_T [S,B,4,4] overwritten */
+MVF_API int mvf_unit_bwd(const float *disp, const float *tgt, const float *const *src, const float *T,
+                 const float *K, const float *inv_K, const uint8_t *argmin, const float *mask_rec,
+                 const float *stats, const float *g_loss, int S, int flags, float smoothness,
+                 float min_disp, float range, float eps, float *g_disp, float *g_T,
+                 float *workspace, int B, int H, int W, void *stream);
+
+/* ---- a10: layers.transformation_from_parameters (layers.py:28-103) --------------------
+ * axisangle, translation [B,3] -> M [B,4,4]; M = T*R, or R^T*T(-t) when invert != 0 */
+MVF_API int mvf_pose_fwd(const float *axisangle, const float *translation, float *M, int invert, int B,
+                 void *stream);
+MVF_API int mvf_pose_bwd(const float *axisangle, const float *translation, const float *g_M,
+                 float *g_axisangle, float *g_translation, int invert, int B, void *stream);
+
+/* floats of scratch the reducing entry points need for a [B,*,H,W] problem */
+MVF_API size_t mvf_workspace_floats(int B, int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVF_HOTPATH_H */

@@ -1,0 +1,110 @@
+"""ctypes binding of the gfx950 hot-path library (C ABI: include/mvf_hotpath.h).
+
+There is NO CPU fallback: if the library is missing or a tensor is not on a HIP device
+the call fails loudly.  Build the library with ``python __graft_entry__.py`` (or
+``make -C mono-vifi_amd/csrc``); it is kept in-tree at ``mono-vifi_amd/lib/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmvf_hotpath.so")
+ABI_VERSION = 1
+
+NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
+MAX_SRC = 4
+
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+# name -> argument ctypes (return type is always int = hipError_t unless listed in _RESTYPE)
+_SIGNATURES = {
+    "mvf_abi_version": [],
+    "mvf_error_string": [_i],
+    "mvf_workspace_floats": [_i, _i, _i],
+    "mvf_disp_to_depth_fwd": [_vp, _vp, _vp, _i64, _f, _f, _vp],
+    "mvf_disp_to_depth_bwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _vp],
+    "mvf_backproject_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvf_backproject_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvf_project_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "mvf_project_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _vp],
+    "mvf_grid_sample_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_grid_sample_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_warp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _vp],
+    "mvf_warp_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f,
+                     _vp],
+    "mvf_ssim_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_ssim_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_reprojection_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_reprojection_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_smooth_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_smooth_bwd": [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvf_photo_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _i,
+                      _i, _i, _vp],
+    "mvf_photo_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp],
+    "mvf_unit_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
+                     _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvf_unit_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp,
+                     _vp, _vp, _i, _i, _i, _vp],
+    "mvf_pose_fwd": [_vp, _vp, _vp, _i, _i, _vp],
+    "mvf_pose_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+}
+_RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t}
+
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} not found: the MI355X hot-path library is not built. Run "
+            "`python __graft_entry__.py` (or `make -C mono-vifi_amd/csrc`). "
+            "There is no CPU fallback.")
+    handle = C.CDLL(LIB_PATH)
+    for name, args in _SIGNATURES.items():
+        fn = getattr(handle, name)   # AttributeError if the ABI lost a symbol
+        fn.argtypes = args
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    got = handle.mvf_abi_version()
+    if got != ABI_VERSION:
+        raise NativeLibraryError(f"ABI mismatch: library {got}, binding {ABI_VERSION}")
+    _lib = handle
+    return _lib
+
+
+def check(err, what):
+    if err != 0:
+        msg = lib().mvf_error_string(err)
+        raise RuntimeError(f"{what} failed: HIP error {err} ({msg.decode() if msg else '?'})")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def ptr_array(tensors):
+    """Host array of device pointers (const float* const*)."""
+    arr = (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+    return C.cast(arr, C.c_void_p), arr   # keep `arr` alive until the call returns
+
+
+def require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "mono_vifi_amd hot-path ops run on a HIP device (MI355X) only; got a "
+                f"{t.device} tensor. There is no CPU fallback.")

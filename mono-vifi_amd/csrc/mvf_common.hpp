@@ -1,0 +1,284 @@
+// mvf_common.hpp -- device-side building blocks shared by the gfx950 kernels.
+//
+// "Exact mode" arithmetic contract: this
+// translation unit is compiled with -ffp-contract=off, so `a*b + c` is two roundings;
+// fmaf() appears ONLY where the reference's BLAS-backed [3xk]@[kxN] products accumulate
+// (k-sequential chain seeded by a multiply); every `/` is the correctly rounded IEEE
+// divide hipcc emits by default.  The integer sampling indices this produces are
+// bit-identical to the reference's CPU run (pinned by tests/golden).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mvf_hotpath.h"
+
+#define MVF_DEV __device__ __forceinline__
+
+namespace mvf {
+
+constexpr int kWave = 64;
+
+struct SrcPtrs {
+    const float *p[MVF_MAX_SRC];
+};
+struct DstPtrs {
+    float *p[MVF_MAX_SRC];
+};
+
+// ------------------------------------------------------------------------------- geometry
+// depth = 1 / (min_disp + range*disp)          reference: layers.py:21-24
+MVF_DEV float depth_of(float disp, float min_disp, float range)
+{
+    float scaled = min_disp + range * disp;
+    return 1.0f / scaled;
+}
+
+// inv_K[:3,:3] @ [x,y,1]                        reference: layers.py:193
+MVF_DEV void ray_of(const float *__restrict__ iK, float x, float y, float r[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float a = iK[i * 4 + 0] * x;
+        a = fmaf(iK[i * 4 + 1], y, a);
+        a = fmaf(iK[i * 4 + 2], 1.0f, a);
+        r[i] = a;
+    }
+}
+
+// P = (K @ T)[:3]                               reference: layers.py:212
+// 4x4 @ 4x4 runs ATen's small-matrix loop on the reference's CPU path: products and sums
+// rounded separately (pinned by golden key "P*").
+MVF_DEV float proj_entry(const float *__restrict__ K, const float *__restrict__ T, int i, int j)
+{
+    float a = K[i * 4 + 0] * T[0 * 4 + j];
+    a = a + K[i * 4 + 1] * T[1 * 4 + j];
+    a = a + K[i * 4 + 2] * T[2 * 4 + j];
+    a = a + K[i * 4 + 3] * T[3 * 4 + j];
+    return a;
+}
+
+// c = P @ [X;1]                                 reference: layers.py:214
+MVF_DEV void apply_P(const float P[12], const float X[3], float c[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float a = P[i * 4 + 0] * X[0];
+        a = fmaf(P[i * 4 + 1], X[1], a);
+        a = fmaf(P[i * 4 + 2], X[2], a);
+        a = fmaf(P[i * 4 + 3], 1.0f, a);
+        c[i] = a;
+    }
+}
+
+// perspective divide + [-1,1] normalisation    reference: layers.py:216-221
+MVF_DEV void normalise_uv(const float c[3], float eps, float wm1, float hm1, float &gx, float &gy,
+                          float &u, float &v, float &z)
+{
+    z = c[2] + eps;
+    u = c[0] / z;
+    v = c[1] / z;
+    float un = u / wm1;
+    float vn = v / hm1;
+    gx = (un - 0.5f) * 2.0f;
+    gy = (vn - 0.5f) * 2.0f;
+}
+
+// bilinear tap of grid_sample(border, align_corners=True)   call site train.py:966-969
+struct Tap {
+    int x0, y0, x1, y1;
+    float wx, wy;
+    bool inx, iny;   // coordinate strictly inside (0, size-1): gradient passes
+};
+
+MVF_DEV float clip_coord(float v, float hi)
+{
+    float a = (v > 0.0f) ? v : 0.0f;   // NaN -> 0: never indexes out of bounds
+    return (a < hi) ? a : hi;
+}
+
+MVF_DEV Tap tap_of(float gx, float gy, int H, int W)
+{
+    Tap t;
+    float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    float ix = ((gx + 1.0f) / 2.0f) * wm1;
+    float iy = ((gy + 1.0f) / 2.0f) * hm1;
+    t.inx = (ix > 0.0f) && (ix < wm1);
+    t.iny = (iy > 0.0f) && (iy < hm1);
+    ix = clip_coord(ix, wm1);
+    iy = clip_coord(iy, hm1);
+    float fx = floorf(ix), fy = floorf(iy);
+    t.x0 = (int)fx;
+    t.y0 = (int)fy;
+    t.x1 = min(t.x0 + 1, W - 1);
+    t.y1 = min(t.y0 + 1, H - 1);
+    t.wx = ix - fx;
+    t.wy = iy - fy;
+    return t;
+}
+
+MVF_DEV float bilerp(const float *__restrict__ im, int W, const Tap &t)
+{
+    float w = t.wx, e = 1.0f - w, n = t.wy, s = 1.0f - n;
+    float nw = im[t.y0 * W + t.x0], ne = im[t.y0 * W + t.x1];
+    float sw = im[t.y1 * W + t.x0], se = im[t.y1 * W + t.x1];
+    return nw * (s * e) + ne * (s * w) + sw * (n * e) + se * (n * w);
+}
+
+MVF_DEV void bilerp_grad(const float *__restrict__ im, int W, const Tap &t, float &dx, float &dy)
+{
+    float w = t.wx, e = 1.0f - w, n = t.wy, s = 1.0f - n;
+    float nw = im[t.y0 * W + t.x0], ne = im[t.y0 * W + t.x1];
+    float sw = im[t.y1 * W + t.x0], se = im[t.y1 * W + t.x1];
+    dx = (ne - nw) * s + (se - sw) * n;
+    dy = (sw - nw) * e + (se - ne) * w;
+}
+
+// full per-pixel chain of generate_images_pred up to the tap (reference train.py:956-969)
+struct WarpPoint {
+    Tap t;
+    float gx, gy;       // normalised grid
+    float u, v, z;      // perspective quotient and (z + eps)
+    float X[3];         // camera point
+    float r[3];         // ray
+    float depth;
+};
+
+MVF_DEV WarpPoint warp_point(float disp, const float *__restrict__ iK, const float P[12], int x,
+                             int y, int H, int W, float min_disp, float range, float eps)
+{
+    WarpPoint w;
+    ray_of(iK, (float)x, (float)y, w.r);
+    w.depth = depth_of(disp, min_disp, range);
+    w.X[0] = w.depth * w.r[0];
+    w.X[1] = w.depth * w.r[1];
+    w.X[2] = w.depth * w.r[2];
+    float c[3];
+    apply_P(P, w.X, c);
+    normalise_uv(c, eps, (float)(W - 1), (float)(H - 1), w.gx, w.gy, w.u, w.v, w.z);
+    w.t = tap_of(w.gx, w.gy, H, W);
+    return w;
+}
+
+// adjoint of the chain: (g_ix, g_iy) w.r.t. the un-normalised sample coordinate ->
+// gc (grad of c = P@[X;1]) ; returns grad of depth.
+MVF_DEV float warp_point_bwd(const WarpPoint &w, const float P[12], float gix, float giy, int H,
+                             int W, float gc[3])
+{
+    float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    float ggx = w.t.inx ? gix * (wm1 / 2.0f) : 0.0f;
+    float ggy = w.t.iny ? giy * (hm1 / 2.0f) : 0.0f;
+    float gu = ggx * 2.0f / wm1;
+    float gv = ggy * 2.0f / hm1;
+    gc[0] = gu / w.z;
+    gc[1] = gv / w.z;
+    gc[2] = -(gu * w.u + gv * w.v) / w.z;
+    float gd = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        float gX = gc[0] * P[0 * 4 + j] + gc[1] * P[1 * 4 + j] + gc[2] * P[2 * 4 + j];
+        gd += gX * w.r[j];
+    }
+    return gd;
+}
+
+// ------------------------------------------------------------------------------- SSIM
+MVF_DEV int refl(int j, int n)
+{
+    j = (j < 0) ? -j : j;
+    j = (j >= n) ? 2 * (n - 1) - j : j;
+    return j;
+}
+
+// (float)(0.01**2), (float)(0.03**2)            reference: layers.py:274-275
+constexpr float kC1 = (float)(0.01 * 0.01);
+constexpr float kC2 = (float)(0.03 * 0.03);
+
+struct Win {
+    float mu_x, mu_y, exx, eyy, exy;
+};
+
+// reference: layers.py:281-290 -- literal expression order, no contraction
+MVF_DEV float ssim_raw(const Win &w)
+{
+    float sigma_x = w.exx - w.mu_x * w.mu_x;
+    float sigma_y = w.eyy - w.mu_y * w.mu_y;
+    float sigma_xy = w.exy - w.mu_x * w.mu_y;
+    float n = (2.0f * w.mu_x * w.mu_y + kC1) * (2.0f * sigma_xy + kC2);
+    float d = (w.mu_x * w.mu_x + w.mu_y * w.mu_y + kC1) * (sigma_x + sigma_y + kC2);
+    return (1.0f - n / d) / 2.0f;
+}
+
+MVF_DEV float clamp01(float v)
+{
+    float c = v < 0.0f ? 0.0f : v;
+    return c > 1.0f ? 1.0f : c;
+}
+
+struct DWin {
+    float dmux, dexx, dexy, dmuy, deyy;
+};
+
+// partial derivatives of the clamped SSIM map w.r.t. the window statistics
+MVF_DEV DWin ssim_partials(const Win &w)
+{
+    float mx = w.mu_x, my = w.mu_y;
+    float sigma_x = w.exx - mx * mx, sigma_y = w.eyy - my * my, sigma_xy = w.exy - mx * my;
+    float A1 = 2.0f * mx * my + kC1, A2 = 2.0f * sigma_xy + kC2;
+    float B1 = mx * mx + my * my + kC1, B2 = sigma_x + sigma_y + kC2;
+    float n = A1 * A2, d = B1 * B2;
+    float raw = (1.0f - n / d) / 2.0f;
+    DWin g = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (!(raw >= 0.0f && raw <= 1.0f)) return g;
+    float inv_d = 1.0f / d;
+    float kn = -0.5f * inv_d;
+    float kd = 0.5f * n * inv_d * inv_d;
+    float dn_dmx = 2.0f * my * A2 - 2.0f * my * A1;
+    float dn_dmy = 2.0f * mx * A2 - 2.0f * mx * A1;
+    float dd_dmx = 2.0f * mx * B2 - 2.0f * mx * B1;
+    float dd_dmy = 2.0f * my * B2 - 2.0f * my * B1;
+    g.dmux = kn * dn_dmx + kd * dd_dmx;
+    g.dmuy = kn * dn_dmy + kd * dd_dmy;
+    g.dexy = kn * 2.0f * A1;
+    g.dexx = kd * B1;
+    g.deyy = kd * B1;
+    return g;
+}
+
+// multiplicity of image column q in the reflect-padded 3-window centred on column p
+MVF_DEV float refl_mult(int p, int q, int n)
+{
+    return ((p == 0 && q == 1) || (p == n - 1 && q == n - 2)) ? 2.0f : 1.0f;
+}
+
+// ------------------------------------------------------------------------------- reductions
+MVF_DEV float wave_sum(float v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// sum over the workgroup; result valid in thread 0.  `scratch` holds >= nwaves floats.
+template <int NT>
+MVF_DEV float block_sum(float v, float *scratch)
+{
+    constexpr int NW = NT / kWave;
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wid] = v;
+    __syncthreads();
+    float r = 0.0f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += scratch[i];
+    }
+    return r;
+}
+
+inline int hip_check_launch()
+{
+    return (int)hipGetLastError();
+}
+
+}  // namespace mvf

@@ -1,0 +1,617 @@
+// mvf_geom.hip -- geometry stages of the hot path for gfx950 (MI355X):
+// disp_to_depth, BackprojectDepth, Project3D, grid_sample(border, align_corners=True), the
+// per-pixel fusion of the four (Trainer.generate_images_pred) and the pose glue.
+//
+// All kernels are one-pixel-per-lane streaming kernels: lanes of a wavefront walk
+// consecutive x, so every planar [B,C,H,W] access is a fully coalesced 256-B wave
+// transaction; the 2x2 bilinear taps of neighbouring lanes fall in the same or adjacent
+// cache lines for realistic ego-motion and are served by L2.  Bound: HBM bandwidth.
+// Compiled with -ffp-contract=off (see mvf_common.hpp for the arithmetic contract).
+#include "mvf_common.hpp"
+
+using namespace mvf;
+
+namespace {
+
+constexpr int NT = 256;
+
+inline dim3 pix_grid(int H, int W, int B) { return dim3((unsigned)((H * W + NT - 1) / NT), (unsigned)B); }
+
+// ---------------------------------------------------------------- a1 disp_to_depth
+__global__ void __launch_bounds__(NT) k_disp_to_depth(const float *__restrict__ disp,
+                                                      float *__restrict__ scaled,
+                                                      float *__restrict__ depth, int64_t n,
+                                                      float min_disp, float range)
+{
+    int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * NT;
+    for (; i < n; i += stride) {
+        float s = min_disp + range * disp[i];
+        if (scaled) scaled[i] = s;
+        if (depth) depth[i] = 1.0f / s;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_disp_to_depth_bwd(const float *__restrict__ disp,
+                                                          const float *__restrict__ g_scaled,
+                                                          const float *__restrict__ g_depth,
+                                                          float *__restrict__ g_disp, int64_t n,
+                                                          float min_disp, float range)
+{
+    int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * NT;
+    for (; i < n; i += stride) {
+        float s = min_disp + range * disp[i];
+        float d = 1.0f / s;
+        float g = 0.0f;
+        if (g_scaled) g += g_scaled[i] * range;
+        if (g_depth) g += -g_depth[i] * d * d * range;
+        g_disp[i] = g;
+    }
+}
+
+// ---------------------------------------------------------------- a2 BackprojectDepth
+__global__ void __launch_bounds__(NT) k_backproject(const float *__restrict__ depth,
+                                                    const float *__restrict__ invK,
+                                                    float *__restrict__ cam, int H, int W)
+{
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    int y = i / W, x = i - y * W;
+    float r[3];
+    ray_of(invK + b * 16, (float)x, (float)y, r);
+    float d = depth[(size_t)b * N + i];
+    float *o = cam + (size_t)b * 4 * N + i;
+    o[0] = d * r[0];
+    o[(size_t)N] = d * r[1];
+    o[(size_t)2 * N] = d * r[2];
+    o[(size_t)3 * N] = 1.0f;
+}
+
+__global__ void __launch_bounds__(NT) k_backproject_bwd(const float *__restrict__ g_cam,
+                                                        const float *__restrict__ invK,
+                                                        float *__restrict__ g_depth, int H, int W)
+{
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    int y = i / W, x = i - y * W;
+    float r[3];
+    ray_of(invK + b * 16, (float)x, (float)y, r);
+    const float *g = g_cam + (size_t)b * 4 * N + i;
+    g_depth[(size_t)b * N + i] = g[0] * r[0] + g[(size_t)N] * r[1] + g[(size_t)2 * N] * r[2];
+}
+
+// ---------------------------------------------------------------- a3 Project3D
+MVF_DEV void load_P(const float *__restrict__ K, const float *__restrict__ T, float P[12])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) P[i * 4 + j] = proj_entry(K, T, i, j);
+}
+
+__global__ void __launch_bounds__(NT) k_project(const float *__restrict__ cam,
+                                                const float *__restrict__ K,
+                                                const float *__restrict__ T,
+                                                float *__restrict__ pix, int H, int W, float eps)
+{
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    float P[12];
+    load_P(K + b * 16, T + b * 16, P);
+    const float *cp = cam + (size_t)b * 4 * N + i;
+    float X0 = cp[0], X1 = cp[(size_t)N], X2 = cp[(size_t)2 * N], X3 = cp[(size_t)3 * N];
+    float c[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        float a = P[q * 4 + 0] * X0;
+        a = fmaf(P[q * 4 + 1], X1, a);
+        a = fmaf(P[q * 4 + 2], X2, a);
+        a = fmaf(P[q * 4 + 3], X3, a);
+        c[q] = a;
+    }
+    float gx, gy, u, v, z;
+    normalise_uv(c, eps, (float)(W - 1), (float)(H - 1), gx, gy, u, v, z);
+    float2 o = make_float2(gx, gy);
+    reinterpret_cast<float2 *>(pix)[(size_t)b * N + i] = o;
+}
+
+// per-block partial of sum_i gc[q]*Xh[j] (12 values) -> ws[(b*nblk + blk)*12 + k]
+template <int NTT>
+MVF_DEV void reduce12_to_ws(float acc[12], float *__restrict__ ws, float *scratch)
+{
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        float s = block_sum<NTT>(acc[k], scratch);
+        if (threadIdx.x == 0) ws[k] = s;
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_project_bwd(const float *__restrict__ cam,
+                                                    const float *__restrict__ K,
+                                                    const float *__restrict__ T,
+                                                    const float *__restrict__ g_pix,
+                                                    float *__restrict__ g_cam,
+                                                    float *__restrict__ ws, int H, int W, float eps)
+{
+    __shared__ float scratch[NT / kWave];
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    float P[12];
+    load_P(K + b * 16, T + b * 16, P);
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    if (i < N) {
+        const float *cp = cam + (size_t)b * 4 * N + i;
+        float Xh[4] = {cp[0], cp[(size_t)N], cp[(size_t)2 * N], cp[(size_t)3 * N]};
+        float c[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float a = P[q * 4 + 0] * Xh[0];
+            a = fmaf(P[q * 4 + 1], Xh[1], a);
+            a = fmaf(P[q * 4 + 2], Xh[2], a);
+            a = fmaf(P[q * 4 + 3], Xh[3], a);
+            c[q] = a;
+        }
+        float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+        float z = c[2] + eps, u = c[0] / z, v = c[1] / z;
+        float2 g = reinterpret_cast<const float2 *>(g_pix)[(size_t)b * N + i];
+        float gu = g.x * 2.0f / wm1, gv = g.y * 2.0f / hm1;
+        float gc[3] = {gu / z, gv / z, -(gu * u + gv * v) / z};
+        if (g_cam) {
+            float *o = g_cam + (size_t)b * 4 * N + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                o[(size_t)j * N] = gc[0] * P[j] + gc[1] * P[4 + j] + gc[2] * P[8 + j];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[q * 4 + j] = gc[q] * Xh[j];
+    }
+    if (ws) reduce12_to_ws<NT>(acc, ws + ((size_t)b * gridDim.x + blockIdx.x) * 12, scratch);
+}
+
+// fold per-block grad_P partials in fixed order (fp64) and form grad_T = K^T [grad_P ; 0]
+// grid (B, S): ws [S][B][nblk][12], K [B,4,4], gT [S][B][4][4]
+__global__ void __launch_bounds__(NT) k_finish_gT(const float *__restrict__ ws,
+                                                  const float *__restrict__ K,
+                                                  float *__restrict__ gT, int nblk)
+{
+    __shared__ double sh[NT / kWave][12];
+    __shared__ double gP[12];
+    int b = blockIdx.x, s = blockIdx.y, B = gridDim.x;
+    const float *w = ws + ((size_t)s * B + b) * nblk * 12;
+    double acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+    for (int blk = threadIdx.x; blk < nblk; blk += NT)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] += (double)w[(size_t)blk * 12 + k];
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+        double v = acc[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if (lane == 0) sh[wid][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        double v = 0.0;
+        for (int i = 0; i < NT / kWave; ++i) v += sh[i][threadIdx.x];
+        gP[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        int k = threadIdx.x >> 2, j = threadIdx.x & 3;
+        const float *Kb = K + b * 16;
+        double a = 0.0;
+        for (int q = 0; q < 3; ++q) a += (double)Kb[q * 4 + k] * gP[q * 4 + j];
+        gT[((size_t)s * B + b) * 16 + threadIdx.x] = (float)a;
+    }
+}
+
+// ---------------------------------------------------------------- a4 grid_sample
+__global__ void __launch_bounds__(NT) k_grid_sample(const float *__restrict__ img,
+                                                    const float *__restrict__ grid,
+                                                    float *__restrict__ out,
+                                                    int32_t *__restrict__ idx_xy, int C, int H, int W)
+{
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    float2 g = reinterpret_cast<const float2 *>(grid)[(size_t)b * N + i];
+    Tap t = tap_of(g.x, g.y, H, W);
+    if (idx_xy) reinterpret_cast<int2 *>(idx_xy)[(size_t)b * N + i] = make_int2(t.x0, t.y0);
+    if (out)
+        for (int c = 0; c < C; ++c)
+            out[((size_t)b * C + c) * N + i] = bilerp(img + ((size_t)b * C + c) * N, W, t);
+}
+
+MVF_DEV void scatter_taps(float *__restrict__ gi, int W, const Tap &t, float g)
+{
+    float w = t.wx, e = 1.0f - w, n = t.wy, s = 1.0f - n;
+    atomicAdd(gi + t.y0 * W + t.x0, g * (s * e));
+    atomicAdd(gi + t.y0 * W + t.x1, g * (s * w));
+    atomicAdd(gi + t.y1 * W + t.x0, g * (n * e));
+    atomicAdd(gi + t.y1 * W + t.x1, g * (n * w));
+}
+
+__global__ void __launch_bounds__(NT) k_grid_sample_bwd(const float *__restrict__ img,
+                                                        const float *__restrict__ grid,
+                                                        const float *__restrict__ g_out,
+                                                        float *__restrict__ g_grid,
+                                                        float *__restrict__ g_img, int C, int H, int W)
+{
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    float2 g = reinterpret_cast<const float2 *>(grid)[(size_t)b * N + i];
+    Tap t = tap_of(g.x, g.y, H, W);
+    float gx = 0.0f, gy = 0.0f;
+    for (int c = 0; c < C; ++c) {
+        float go = g_out[((size_t)b * C + c) * N + i];
+        float dx, dy;
+        bilerp_grad(img + ((size_t)b * C + c) * N, W, t, dx, dy);
+        gx += go * dx;
+        gy += go * dy;
+        if (g_img) scatter_taps(g_img + ((size_t)b * C + c) * N, W, t, go);
+    }
+    float sx = (float)(W - 1) / 2.0f, sy = (float)(H - 1) / 2.0f;
+    if (g_grid)
+        reinterpret_cast<float2 *>(g_grid)[(size_t)b * N + i] =
+            make_float2(t.inx ? gx * sx : 0.0f, t.iny ? gy * sy : 0.0f);
+}
+
+// ---------------------------------------------------------------- a5 fused warp
+__global__ void __launch_bounds__(NT) k_warp_fwd(const float *__restrict__ disp,
+                                                 const float *__restrict__ invK,
+                                                 const float *__restrict__ K,
+                                                 const float *__restrict__ T,
+                                                 const float *__restrict__ src,
+                                                 float *__restrict__ warped, float *__restrict__ pix,
+                                                 int32_t *__restrict__ idx_xy, int H, int W,
+                                                 float min_disp, float range, float eps)
+{
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    int y = i / W, x = i - y * W;
+    float P[12];
+    load_P(K + b * 16, T + b * 16, P);
+    WarpPoint w = warp_point(disp[(size_t)b * N + i], invK + b * 16, P, x, y, H, W, min_disp,
+                             range, eps);
+    if (pix) reinterpret_cast<float2 *>(pix)[(size_t)b * N + i] = make_float2(w.gx, w.gy);
+    if (idx_xy) reinterpret_cast<int2 *>(idx_xy)[(size_t)b * N + i] = make_int2(w.t.x0, w.t.y0);
+    if (warped) {
+        const float *sp = src + (size_t)b * 3 * N;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+            warped[((size_t)b * 3 + c) * N + i] = bilerp(sp + (size_t)c * N, W, w.t);
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_warp_bwd(const float *__restrict__ disp,
+                                                 const float *__restrict__ invK,
+                                                 const float *__restrict__ K,
+                                                 const float *__restrict__ T,
+                                                 const float *__restrict__ src,
+                                                 const float *__restrict__ g_warped,
+                                                 float *__restrict__ g_disp,
+                                                 float *__restrict__ g_src, float *__restrict__ ws,
+                                                 int accumulate, int H, int W, float min_disp,
+                                                 float range, float eps)
+{
+    __shared__ float scratch[NT / kWave];
+    int N = H * W, b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    float P[12];
+    load_P(K + b * 16, T + b * 16, P);
+    float acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) acc[k] = 0.0f;
+    if (i < N) {
+        int y = i / W, x = i - y * W;
+        WarpPoint w = warp_point(disp[(size_t)b * N + i], invK + b * 16, P, x, y, H, W, min_disp,
+                                 range, eps);
+        const float *sp = src + (size_t)b * 3 * N;
+        float gix = 0.0f, giy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float go = g_warped[((size_t)b * 3 + c) * N + i];
+            float dx, dy;
+            bilerp_grad(sp + (size_t)c * N, W, w.t, dx, dy);
+            gix += go * dx;
+            giy += go * dy;
+            if (g_src) scatter_taps(g_src + ((size_t)b * 3 + c) * N, W, w.t, go);
+        }
+        float gc[3];
+        float gd = warp_point_bwd(w, P, gix, giy, H, W, gc);
+        float g = -gd * w.depth * w.depth * range;
+        size_t o = (size_t)b * N + i;
+        g_disp[o] = accumulate ? g_disp[o] + g : g;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            acc[q * 4 + 0] = gc[q] * w.X[0];
+            acc[q * 4 + 1] = gc[q] * w.X[1];
+            acc[q * 4 + 2] = gc[q] * w.X[2];
+            acc[q * 4 + 3] = gc[q];
+        }
+    }
+    reduce12_to_ws<NT>(acc, ws + ((size_t)b * gridDim.x + blockIdx.x) * 12, scratch);
+}
+
+// ---------------------------------------------------------------- a10 pose glue
+// reference: layers.py:28-103.  One lane per batch element.
+struct Rot {
+    float R[9];
+};
+
+MVF_DEV void rodrigues(const float v[3], float R[9], float &angle, float axis[3], float &sa,
+                       float &ca)
+{
+    angle = sqrtf(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    float den = angle + 1e-7f;
+    float x = v[0] / den, y = v[1] / den, z = v[2] / den;
+    axis[0] = x; axis[1] = y; axis[2] = z;
+    ca = cosf(angle);
+    sa = sinf(angle);
+    float C = 1.0f - ca;
+    float xs = x * sa, ys = y * sa, zs = z * sa;
+    float xC = x * C, yC = y * C, zC = z * C;
+    float xyC = x * yC, yzC = y * zC, zxC = z * xC;
+    R[0] = x * xC + ca; R[1] = xyC - zs;     R[2] = zxC + ys;
+    R[3] = xyC + zs;    R[4] = y * yC + ca;  R[5] = yzC - xs;
+    R[6] = zxC - ys;    R[7] = yzC + xs;     R[8] = z * zC + ca;
+}
+
+__global__ void k_pose_fwd(const float *__restrict__ aa, const float *__restrict__ tr,
+                           float *__restrict__ M, int invert, int B)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float v[3] = {aa[b * 3], aa[b * 3 + 1], aa[b * 3 + 2]};
+    float t[3] = {tr[b * 3], tr[b * 3 + 1], tr[b * 3 + 2]};
+    float R[9], angle, axis[3], sa, ca;
+    rodrigues(v, R, angle, axis, sa, ca);
+    float *m = M + b * 16;
+    if (!invert) {
+        // M = T * R : rotation block R, translation column t
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            m[i * 4 + 0] = R[i * 3 + 0];
+            m[i * 4 + 1] = R[i * 3 + 1];
+            m[i * 4 + 2] = R[i * 3 + 2];
+            m[i * 4 + 3] = t[i];
+        }
+    } else {
+        // M = R^T * T(-t) : rotation block R^T, translation column R^T * (-t)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float r0 = R[0 * 3 + i], r1 = R[1 * 3 + i], r2 = R[2 * 3 + i];
+            m[i * 4 + 0] = r0;
+            m[i * 4 + 1] = r1;
+            m[i * 4 + 2] = r2;
+            // 4x4 @ 4x4: the reference's small-matrix loop, no fma (see proj_entry)
+            float a = r0 * (-t[0]);
+            a = a + r1 * (-t[1]);
+            a = a + r2 * (-t[2]);
+            m[i * 4 + 3] = a;
+        }
+    }
+    m[12] = 0.0f; m[13] = 0.0f; m[14] = 0.0f; m[15] = 1.0f;
+}
+
+__global__ void k_pose_bwd(const float *__restrict__ aa, const float *__restrict__ tr,
+                           const float *__restrict__ gM, float *__restrict__ g_aa,
+                           float *__restrict__ g_tr, int invert, int B)
+{
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float v[3] = {aa[b * 3], aa[b * 3 + 1], aa[b * 3 + 2]};
+    float t[3] = {tr[b * 3], tr[b * 3 + 1], tr[b * 3 + 2]};
+    float R[9], angle, ax[3], sa, ca;
+    rodrigues(v, R, angle, ax, sa, ca);
+    const float *g = gM + b * 16;
+    // gradient w.r.t. R (3x3) and t
+    float gR[9], gt[3];
+    if (!invert) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) gR[i * 3 + j] = g[i * 4 + j];
+            gt[i] = g[i * 4 + 3];
+        }
+    } else {
+        // M[i][j] = R[j][i] ; M[i][3] = -sum_j R[j][i] t[j]
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                gR[j * 3 + i] = g[i * 4 + j] - g[i * 4 + 3] * t[j];
+                acc += -g[i * 4 + 3] * R[j * 3 + i];
+            }
+            gt[j] = acc;
+        }
+    }
+    // R entries in terms of (x,y,z, sa, ca, C=1-ca)
+    float x = ax[0], y = ax[1], z = ax[2], C = 1.0f - ca;
+    // d/dx, d/dy, d/dz, d/dsa, d/dca (C depends on ca: dC/dca = -1)
+    float gx = gR[0] * 2.0f * x * C + (gR[1] + gR[3]) * y * C + (gR[2] + gR[6]) * z * C +
+               (gR[7] - gR[5]) * sa;
+    float gy = gR[4] * 2.0f * y * C + (gR[1] + gR[3]) * x * C + (gR[5] + gR[7]) * z * C +
+               (gR[2] - gR[6]) * sa;
+    float gz = gR[8] * 2.0f * z * C + (gR[2] + gR[6]) * x * C + (gR[5] + gR[7]) * y * C +
+               (gR[3] - gR[1]) * sa;
+    float gsa = (gR[3] - gR[1]) * z + (gR[2] - gR[6]) * y + (gR[7] - gR[5]) * x;
+    float gC = gR[0] * x * x + gR[4] * y * y + gR[8] * z * z + (gR[1] + gR[3]) * x * y +
+               (gR[2] + gR[6]) * z * x + (gR[5] + gR[7]) * y * z;
+    float gca = gR[0] + gR[4] + gR[8] - gC;
+    // angle = |v| ; axis = v / (angle + 1e-7) ; sa = sin(angle) ; ca = cos(angle)
+    float g_angle = gsa * ca - gca * sa;
+    float den = angle + 1e-7f;
+    float gax[3] = {gx, gy, gz};
+    float dot = gax[0] * v[0] + gax[1] * v[1] + gax[2] * v[2];
+    g_angle += -dot / (den * den);
+    // d angle / d v = v / angle  (torch.norm backward gives 0 at angle == 0)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float dn = (angle > 0.0f) ? v[i] / angle : 0.0f;
+        g_aa[b * 3 + i] = gax[i] / den + g_angle * dn;
+        g_tr[b * 3 + i] = gt[i];
+    }
+}
+
+}  // namespace
+
+// shared with mvf_photo.hip: fold the fused backward's per-tile grad_P partials
+namespace mvf_geom {
+int finish_gT(const float *ws, const float *K, float *gT, int B, int S, int nblk, void *stream)
+{
+    hipLaunchKernelGGL(k_finish_gT, dim3(B, S), dim3(NT), 0, (hipStream_t)stream, ws, K, gT, nblk);
+    return hip_check_launch();
+}
+}  // namespace mvf_geom
+
+// ============================================================================ C ABI
+extern "C" {
+
+int mvf_abi_version(void) { return MVF_ABI_VERSION; }
+
+const char *mvf_error_string(int err) { return hipGetErrorString((hipError_t)err); }
+
+size_t mvf_workspace_floats(int B, int H, int W)
+{
+    size_t nblk = ((size_t)H * W + NT - 1) / NT;
+    return (size_t)B * nblk * 16 * MVF_MAX_SRC + 1024;
+}
+
+int mvf_disp_to_depth_fwd(const float *disp, float *scaled, float *depth, int64_t n,
+                          float min_disp, float range, void *stream)
+{
+    if (n <= 0) return 0;
+    int64_t blocks = (n + NT - 1) / NT;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_disp_to_depth, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream,
+                       disp, scaled, depth, n, min_disp, range);
+    return hip_check_launch();
+}
+
+int mvf_disp_to_depth_bwd(const float *disp, const float *g_scaled, const float *g_depth,
+                          float *g_disp, int64_t n, float min_disp, float range, void *stream)
+{
+    if (n <= 0) return 0;
+    int64_t blocks = (n + NT - 1) / NT;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_disp_to_depth_bwd, dim3((unsigned)blocks), dim3(NT), 0,
+                       (hipStream_t)stream, disp, g_scaled, g_depth, g_disp, n, min_disp, range);
+    return hip_check_launch();
+}
+
+int mvf_backproject_fwd(const float *depth, const float *inv_K, float *cam, int B, int H, int W,
+                        void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    hipLaunchKernelGGL(k_backproject, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream, depth,
+                       inv_K, cam, H, W);
+    return hip_check_launch();
+}
+
+int mvf_backproject_bwd(const float *g_cam, const float *inv_K, float *g_depth, int B, int H,
+                        int W, void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    hipLaunchKernelGGL(k_backproject_bwd, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream,
+                       g_cam, inv_K, g_depth, H, W);
+    return hip_check_launch();
+}
+
+int mvf_project_fwd(const float *cam, const float *K, const float *T, float *pix, int B, int H,
+                    int W, float eps, void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    hipLaunchKernelGGL(k_project, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream, cam, K, T,
+                       pix, H, W, eps);
+    return hip_check_launch();
+}
+
+int mvf_project_bwd(const float *cam, const float *K, const float *T, const float *g_pix,
+                    float *g_cam, float *g_T, float *workspace, int B, int H, int W, float eps,
+                    void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    dim3 grid = pix_grid(H, W, B);
+    hipLaunchKernelGGL(k_project_bwd, grid, dim3(NT), 0, (hipStream_t)stream, cam, K, T, g_pix,
+                       g_cam, g_T ? workspace : nullptr, H, W, eps);
+    if (g_T)
+        hipLaunchKernelGGL(k_finish_gT, dim3(B, 1), dim3(NT), 0, (hipStream_t)stream, workspace, K,
+                           g_T, (int)grid.x);
+    return hip_check_launch();
+}
+
+int mvf_grid_sample_fwd(const float *img, const float *grid, float *out, int32_t *idx_xy, int B,
+                        int C, int H, int W, void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    hipLaunchKernelGGL(k_grid_sample, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream, img,
+                       grid, out, idx_xy, C, H, W);
+    return hip_check_launch();
+}
+
+int mvf_grid_sample_bwd(const float *img, const float *grid, const float *g_out, float *g_grid,
+                        float *g_img, int B, int C, int H, int W, void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    hipLaunchKernelGGL(k_grid_sample_bwd, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream, img,
+                       grid, g_out, g_grid, g_img, C, H, W);
+    return hip_check_launch();
+}
+
+int mvf_warp_fwd(const float *disp, const float *inv_K, const float *K, const float *T,
+                 const float *src, float *warped, float *pix, int32_t *idx_xy, int B, int H,
+                 int W, float min_disp, float range, float eps, void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    hipLaunchKernelGGL(k_warp_fwd, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream, disp,
+                       inv_K, K, T, src, warped, pix, idx_xy, H, W, min_disp, range, eps);
+    return hip_check_launch();
+}
+
+int mvf_warp_bwd(const float *disp, const float *inv_K, const float *K, const float *T,
+                 const float *src, const float *g_warped, float *g_disp, float *g_T, float *g_src,
+                 float *workspace, int accumulate, int B, int H, int W, float min_disp,
+                 float range, float eps, void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    dim3 grid = pix_grid(H, W, B);
+    hipLaunchKernelGGL(k_warp_bwd, grid, dim3(NT), 0, (hipStream_t)stream, disp, inv_K, K, T, src,
+                       g_warped, g_disp, g_src, workspace, accumulate, H, W, min_disp, range, eps);
+    hipLaunchKernelGGL(k_finish_gT, dim3(B, 1), dim3(NT), 0, (hipStream_t)stream, workspace, K,
+                       g_T, (int)grid.x);
+    return hip_check_launch();
+}
+
+int mvf_pose_fwd(const float *axisangle, const float *translation, float *M, int invert, int B,
+                 void *stream)
+{
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_pose_fwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, axisangle,
+                       translation, M, invert, B);
+    return hip_check_launch();
+}
+
+int mvf_pose_bwd(const float *axisangle, const float *translation, const float *g_M,
+                 float *g_axisangle, float *g_translation, int invert, int B, void *stream)
+{
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_pose_bwd, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, axisangle,
+                       translation, g_M, g_axisangle, g_translation, invert, B);
+    return hip_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,91 @@
+"""The three ``Trainer`` loss methods on the hot path, with the reference's signatures.
+
+reference: train.py:956-1051 (``generate_images_pred``, ``compute_reprojection_loss``,
+``compute_losses_base``).  They are written as a mixin so that ``Trainer`` (trainer.py)
+inherits them and tests can call them unbound on a light-weight object carrying ``opt``
+exactly as the golden-vector capture does with the reference's own methods.
+
+Two ways through the path:
+
+* **staged** (drop-in): ``generate_images_pred`` materialises the warped image
+  (``mvf_warp_fwd``), ``compute_losses_base`` consumes it (``mvf_photo_fwd``) -- same
+  call sequence and intermediate tensors as the reference.
+* **fused** (``compute_unit``): one forward and one backward kernel per unit with the
+  warped images held in LDS only (``mvf_unit_fwd`` / ``mvf_unit_bwd``); this is what
+  ``Trainer.process_batch`` uses.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class HotPathLosses:
+    """Mixin; expects ``self.opt`` with min_depth, max_depth, no_ssim, avg_reprojection,
+    disable_automasking, disparity_smoothness (reference: options.py:84-105,190-200)."""
+
+    # ------------------------------------------------------------------ helpers
+    def _loss_flags(self):
+        o = self.opt
+        return ops._flags(o.no_ssim, o.avg_reprojection, o.disable_automasking)
+
+    def _tie_break_noise(self, disp, num_src):
+        """The draw of reference train.py:1023-1024 (before its 1e-5 scale).  Tests
+        inject a fixed tensor through ``self.tie_break_noise``."""
+        if self.opt.disable_automasking:
+            return None
+        B, _, H, W = disp.shape
+        n_id = 1 if self.opt.avg_reprojection else num_src
+        fixed = getattr(self, "tie_break_noise", None)
+        if fixed is not None:
+            if tuple(fixed.shape) != (B, n_id, H, W):
+                raise RuntimeError(f"tie_break_noise must be {(B, n_id, H, W)}, got {tuple(fixed.shape)}")
+            return fixed
+        return torch.randn((B, n_id, H, W), device=disp.device)
+
+    # ------------------------------------------------------------------ reference API
+    def generate_images_pred(self, disp_tgt, pose_tgt_src, img_src, K, inv_K):
+        """Warp ``img_src`` into the target view; reference: train.py:956-971."""
+        disp = disp_tgt[("disp", 0)]
+        return ops.Warp.apply(disp, pose_tgt_src, img_src, K, inv_K,
+                              self.opt.min_depth, self.opt.max_depth, 1e-7)
+
+    def compute_reprojection_loss(self, pred, target):
+        """0.85*SSIM + 0.15*L1 map [B,1,H,W]; reference: train.py:973-985."""
+        return ops.Reprojection.apply(pred, target, bool(self.opt.no_ssim))
+
+    def compute_losses_base(self, disp_tgt, img_tgt, imgs_src_tgt, imgs_src, mask_rec=None):
+        """Min-reprojection + auto-mask + smoothness; reference: train.py:987-1051.
+        Returns (loss, auto_mask | None)."""
+        disp = disp_tgt[("disp", 0)]
+        S = len(imgs_src_tgt)
+        o = self.opt
+        if mask_rec is not None and o.disable_automasking and (o.avg_reprojection or S == 1) \
+                and disp.shape[0] > 1:
+            # the reference's in-place `to_optimise *= mask_rec[:,0]` cannot broadcast a
+            # [B,1,H,W] map against [B,H,W] (train.py:1030-1036)
+            raise RuntimeError("output with shape [B, 1, H, W] doesn't match the broadcast shape")
+        noise = self._tie_break_noise(disp, S)
+        srcs = list(imgs_src) if not o.disable_automasking else []
+        loss, auto_mask, _, _ = ops.LossesBase.apply(
+            disp, img_tgt, mask_rec, noise, S, self._loss_flags(), float(o.disparity_smoothness),
+            *imgs_src_tgt, *srcs)
+        return loss, (None if o.disable_automasking else auto_mask)
+
+    # ------------------------------------------------------------------ fused unit
+    def compute_unit(self, disp_tgt, img_tgt, poses, imgs_src, K, inv_K, mask_rec=None,
+                     want_auto_mask=False):
+        """``len(poses)`` x generate_images_pred + compute_losses_base in one fused
+        forward kernel (and one fused backward).  ``poses``: list of [B,4,4] or a stacked
+        [S,B,4,4] tensor.  Returns (loss, auto_mask | None)."""
+        disp = disp_tgt[("disp", 0)]
+        o = self.opt
+        T = poses if torch.is_tensor(poses) else torch.stack(list(poses), 0)
+        S = T.shape[0]
+        noise = self._tie_break_noise(disp, S)
+        cfg = (S, self._loss_flags(), float(o.disparity_smoothness), o.min_depth, o.max_depth,
+               1e-7, bool(want_auto_mask), False)
+        loss, auto_mask, _, _, _ = ops.Unit.apply(disp, img_tgt, T, K, inv_K, mask_rec, noise, cfg,
+                                                  *imgs_src)
+        return loss, (auto_mask if want_auto_mask and not o.disable_automasking else None)

@@ -1,0 +1,446 @@
+"""torch.autograd glue over the C ABI (include/mvf_hotpath.h).
+
+PyTorch is plumbing here: it owns device memory (caching allocator), the current HIP
+stream and the autograd tape; all arithmetic of the hot path happens in the gfx950
+kernels.  Every Function below is the native body of one reference function (cited).
+Kernels are enqueued on ``torch.cuda.current_stream()`` so they order with the
+surrounding MIOpen kernels and with DDP's reducer through normal stream semantics.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+NO_SSIM, AVG_REPROJ, NO_AUTOMASK = nat.NO_SSIM, nat.AVG_REPROJ, nat.NO_AUTOMASK
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _c(t):
+    """contiguous fp32 view (the reference passes slices such as cam_points[:, :2])."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ws(ref, B, H, W):
+    n = nat.lib().mvf_workspace_floats(B, H, W)
+    return torch.empty(n, dtype=torch.float32, device=ref.device)
+
+
+def depth_consts(min_depth, max_depth):
+    """(min_disp, range) as the fp32 scalars of reference layers.py:21-23."""
+    min_disp = 1 / max_depth
+    max_disp = 1 / min_depth
+    return float(np.float32(min_disp)), float(np.float32(max_disp - min_disp))
+
+
+# ------------------------------------------------------------------ a1 disp_to_depth
+class DispToDepth(torch.autograd.Function):
+    """reference: layers.py:16-25"""
+
+    @staticmethod
+    def forward(ctx, disp, min_depth, max_depth):
+        nat.require_device(disp)
+        disp = _c(disp)
+        md, rg = depth_consts(min_depth, max_depth)
+        scaled, depth = torch.empty_like(disp), torch.empty_like(disp)
+        nat.check(nat.lib().mvf_disp_to_depth_fwd(nat.ptr(disp), nat.ptr(scaled), nat.ptr(depth),
+                                                  disp.numel(), md, rg, _stream()), "disp_to_depth")
+        ctx.save_for_backward(disp)
+        ctx.consts = (md, rg)
+        return scaled, depth
+
+    @staticmethod
+    def backward(ctx, g_scaled, g_depth):
+        (disp,) = ctx.saved_tensors
+        md, rg = ctx.consts
+        g_scaled, g_depth = _c(g_scaled), _c(g_depth)
+        g = torch.empty_like(disp)
+        nat.check(nat.lib().mvf_disp_to_depth_bwd(nat.ptr(disp), nat.ptr(g_scaled), nat.ptr(g_depth),
+                                                  nat.ptr(g), disp.numel(), md, rg, _stream()),
+                  "disp_to_depth_bwd")
+        return g, None, None
+
+
+# ------------------------------------------------------------------ a2 BackprojectDepth
+class Backproject(torch.autograd.Function):
+    """reference: layers.py:192-197"""
+
+    @staticmethod
+    def forward(ctx, depth, inv_K, B, H, W):
+        nat.require_device(depth, inv_K)
+        depth, inv_K = _c(depth), _c(inv_K)
+        cam = torch.empty((B, 4, H * W), dtype=torch.float32, device=depth.device)
+        nat.check(nat.lib().mvf_backproject_fwd(nat.ptr(depth), nat.ptr(inv_K), nat.ptr(cam), B, H,
+                                                W, _stream()), "backproject")
+        ctx.save_for_backward(inv_K)
+        ctx.dims = (B, H, W)
+        return cam
+
+    @staticmethod
+    def backward(ctx, g_cam):
+        (inv_K,) = ctx.saved_tensors
+        B, H, W = ctx.dims
+        g_cam = _c(g_cam)
+        g_depth = torch.empty((B, 1, H, W), dtype=torch.float32, device=g_cam.device)
+        nat.check(nat.lib().mvf_backproject_bwd(nat.ptr(g_cam), nat.ptr(inv_K), nat.ptr(g_depth), B,
+                                                H, W, _stream()), "backproject_bwd")
+        return g_depth, None, None, None, None
+
+
+# ------------------------------------------------------------------ a3 Project3D
+class Project(torch.autograd.Function):
+    """reference: layers.py:211-222"""
+
+    @staticmethod
+    def forward(ctx, points, K, T, B, H, W, eps):
+        nat.require_device(points, K, T)
+        points, K, T = _c(points), _c(K), _c(T)
+        pix = torch.empty((B, H, W, 2), dtype=torch.float32, device=points.device)
+        nat.check(nat.lib().mvf_project_fwd(nat.ptr(points), nat.ptr(K), nat.ptr(T), nat.ptr(pix), B,
+                                            H, W, eps, _stream()), "project")
+        ctx.save_for_backward(points, K, T)
+        ctx.dims = (B, H, W, eps)
+        return pix
+
+    @staticmethod
+    def backward(ctx, g_pix):
+        points, K, T = ctx.saved_tensors
+        B, H, W, eps = ctx.dims
+        g_pix = _c(g_pix)
+        need_cam, need_T = ctx.needs_input_grad[0], ctx.needs_input_grad[2]
+        g_cam = torch.empty_like(points) if need_cam else None
+        g_T = torch.empty((B, 4, 4), dtype=torch.float32, device=points.device) if need_T else None
+        ws = _ws(points, B, H, W)
+        nat.check(nat.lib().mvf_project_bwd(nat.ptr(points), nat.ptr(K), nat.ptr(T), nat.ptr(g_pix),
+                                            nat.ptr(g_cam), nat.ptr(g_T), nat.ptr(ws), B, H, W, eps,
+                                            _stream()), "project_bwd")
+        return g_cam, None, g_T, None, None, None, None
+
+
+# ------------------------------------------------------------------ a4 grid_sample
+class GridSampleBorderAC(torch.autograd.Function):
+    """F.grid_sample(img, grid, padding_mode="border", align_corners=True);
+    reference call site: train.py:966-969"""
+
+    @staticmethod
+    def forward(ctx, img, grid):
+        nat.require_device(img, grid)
+        img, grid = _c(img), _c(grid)
+        B, Cc, H, W = img.shape
+        if tuple(grid.shape) != (B, H, W, 2):
+            raise RuntimeError(f"grid must be [B,H,W,2] matching img, got {tuple(grid.shape)}")
+        out = torch.empty_like(img)
+        nat.check(nat.lib().mvf_grid_sample_fwd(nat.ptr(img), nat.ptr(grid), nat.ptr(out), None, B,
+                                                Cc, H, W, _stream()), "grid_sample")
+        ctx.save_for_backward(img, grid)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        img, grid = ctx.saved_tensors
+        B, Cc, H, W = img.shape
+        g_out = _c(g_out)
+        g_grid = torch.empty_like(grid) if ctx.needs_input_grad[1] else None
+        g_img = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        nat.check(nat.lib().mvf_grid_sample_bwd(nat.ptr(img), nat.ptr(grid), nat.ptr(g_out),
+                                                nat.ptr(g_grid), nat.ptr(g_img), B, Cc, H, W,
+                                                _stream()), "grid_sample_bwd")
+        return g_img, g_grid
+
+
+def grid_sample_indices(img_shape, grid):
+    """int32 [B,H,W,2] top-left taps (x0,y0): the bit-exact integers of the parity contract."""
+    nat.require_device(grid)
+    B, Cc, H, W = img_shape
+    grid = _c(grid)
+    idx = torch.empty((B, H, W, 2), dtype=torch.int32, device=grid.device)
+    nat.check(nat.lib().mvf_grid_sample_fwd(None, nat.ptr(grid), None, nat.ptr(idx), B, Cc, H, W,
+                                            _stream()), "grid_sample(idx)")
+    return idx
+
+
+# ------------------------------------------------------------------ a5 fused warp
+class Warp(torch.autograd.Function):
+    """Trainer.generate_images_pred for one source; reference: train.py:956-971"""
+
+    @staticmethod
+    def forward(ctx, disp, T, src, K, inv_K, min_depth, max_depth, eps):
+        nat.require_device(disp, T, src, K, inv_K)
+        disp, T, src, K, inv_K = _c(disp), _c(T), _c(src), _c(K), _c(inv_K)
+        B, _, H, W = disp.shape
+        md, rg = depth_consts(min_depth, max_depth)
+        warped = torch.empty((B, 3, H, W), dtype=torch.float32, device=disp.device)
+        nat.check(nat.lib().mvf_warp_fwd(nat.ptr(disp), nat.ptr(inv_K), nat.ptr(K), nat.ptr(T),
+                                         nat.ptr(src), nat.ptr(warped), None, None, B, H, W, md, rg,
+                                         eps, _stream()), "warp_fwd")
+        ctx.save_for_backward(disp, T, src, K, inv_K)
+        ctx.consts = (md, rg, eps)
+        return warped
+
+    @staticmethod
+    def backward(ctx, g_warped):
+        disp, T, src, K, inv_K = ctx.saved_tensors
+        md, rg, eps = ctx.consts
+        B, _, H, W = disp.shape
+        g_warped = _c(g_warped)
+        g_disp = torch.empty_like(disp)
+        g_T = torch.empty_like(T)
+        g_src = torch.zeros_like(src) if ctx.needs_input_grad[2] else None
+        ws = _ws(disp, B, H, W)
+        nat.check(nat.lib().mvf_warp_bwd(nat.ptr(disp), nat.ptr(inv_K), nat.ptr(K), nat.ptr(T),
+                                         nat.ptr(src), nat.ptr(g_warped), nat.ptr(g_disp),
+                                         nat.ptr(g_T), nat.ptr(g_src), nat.ptr(ws), 0, B, H, W, md,
+                                         rg, eps, _stream()), "warp_bwd")
+        return g_disp, g_T, g_src, None, None, None, None, None
+
+
+def warp_debug(disp, T, src, K, inv_K, min_depth=0.1, max_depth=100.0, eps=1e-7):
+    """(warped, pix [B,H,W,2], idx_xy int32 [B,H,W,2]) -- for stage-level parity tests."""
+    nat.require_device(disp, T, src, K, inv_K)
+    disp, T, src, K, inv_K = _c(disp), _c(T), _c(src), _c(K), _c(inv_K)
+    B, _, H, W = disp.shape
+    md, rg = depth_consts(min_depth, max_depth)
+    warped = torch.empty((B, 3, H, W), dtype=torch.float32, device=disp.device)
+    pix = torch.empty((B, H, W, 2), dtype=torch.float32, device=disp.device)
+    idx = torch.empty((B, H, W, 2), dtype=torch.int32, device=disp.device)
+    nat.check(nat.lib().mvf_warp_fwd(nat.ptr(disp), nat.ptr(inv_K), nat.ptr(K), nat.ptr(T),
+                                     nat.ptr(src), nat.ptr(warped), nat.ptr(pix), nat.ptr(idx), B, H,
+                                     W, md, rg, eps, _stream()), "warp_fwd")
+    return warped, pix, idx
+
+
+# ------------------------------------------------------------------ a6 SSIM
+class SSIMFn(torch.autograd.Function):
+    """reference: layers.py:277-290"""
+
+    @staticmethod
+    def forward(ctx, x, y):
+        nat.require_device(x, y)
+        x, y = _c(x), _c(y)
+        B, Cc, H, W = x.shape
+        if H < 2 or W < 2:
+            raise RuntimeError("ReflectionPad2d(1) needs H, W >= 2")
+        out = torch.empty_like(x)
+        nat.check(nat.lib().mvf_ssim_fwd(nat.ptr(x), nat.ptr(y), nat.ptr(out), B, Cc, H, W,
+                                         _stream()), "ssim")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        g = _c(g)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        nat.check(nat.lib().mvf_ssim_bwd(nat.ptr(x), nat.ptr(y), nat.ptr(g), nat.ptr(gx), nat.ptr(gy),
+                                         B, Cc, H, W, _stream()), "ssim_bwd")
+        return gx, gy
+
+
+# ------------------------------------------------------------------ a7 reprojection
+class Reprojection(torch.autograd.Function):
+    """Trainer.compute_reprojection_loss; reference: train.py:973-985 (grad w.r.t. pred)"""
+
+    @staticmethod
+    def forward(ctx, pred, target, no_ssim):
+        nat.require_device(pred, target)
+        pred, target = _c(pred), _c(target)
+        B, Cc, H, W = pred.shape
+        if Cc != 3:
+            raise RuntimeError("compute_reprojection_loss expects 3-channel images")
+        out = torch.empty((B, 1, H, W), dtype=torch.float32, device=pred.device)
+        nat.check(nat.lib().mvf_reprojection_fwd(nat.ptr(pred), nat.ptr(target), nat.ptr(out), B, H,
+                                                 W, int(no_ssim), _stream()), "reprojection")
+        ctx.save_for_backward(pred, target)
+        ctx.no_ssim = int(no_ssim)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise NotImplementedError("grad w.r.t. the target image is never needed by the trainer")
+        B, _, H, W = pred.shape
+        g = _c(g)
+        gp = torch.empty_like(pred)
+        nat.check(nat.lib().mvf_reprojection_bwd(nat.ptr(pred), nat.ptr(target), nat.ptr(g),
+                                                 nat.ptr(gp), B, H, W, ctx.no_ssim, _stream()),
+                  "reprojection_bwd")
+        return gp, None, None
+
+
+# ------------------------------------------------------------------ a9 smoothness
+class Smooth(torch.autograd.Function):
+    """get_smooth_loss; reference: layers.py:231-242 (normalise=True adds train.py:1044-1045)"""
+
+    @staticmethod
+    def forward(ctx, disp, img, normalise):
+        nat.require_device(disp, img)
+        disp, img = _c(disp), _c(img)
+        B, _, H, W = disp.shape
+        out = torch.empty(3, dtype=torch.float32, device=disp.device)
+        stats = torch.empty((B, 4), dtype=torch.float32, device=disp.device)
+        ws = _ws(disp, B, H, W)
+        nat.check(nat.lib().mvf_smooth_fwd(nat.ptr(disp), nat.ptr(img), nat.ptr(out), nat.ptr(stats),
+                                           nat.ptr(ws), int(normalise), B, H, W, _stream()), "smooth")
+        ctx.save_for_backward(disp, img, stats)
+        ctx.normalise = int(normalise)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, img, stats = ctx.saved_tensors
+        B, _, H, W = disp.shape
+        g = _c(g).reshape(1)
+        gd = torch.empty_like(disp)
+        nat.check(nat.lib().mvf_smooth_bwd(nat.ptr(disp), nat.ptr(img), nat.ptr(stats), nat.ptr(g),
+                                           1.0, nat.ptr(gd), 0, ctx.normalise, B, H, W, _stream()),
+                  "smooth_bwd")
+        return gd, None, None
+
+
+# ------------------------------------------------------------------ a8 compute_losses_base
+def _flags(no_ssim, avg_reprojection, disable_automasking):
+    return (NO_SSIM if no_ssim else 0) | (AVG_REPROJ if avg_reprojection else 0) | \
+        (NO_AUTOMASK if disable_automasking else 0)
+
+
+class LossesBase(torch.autograd.Function):
+    """Trainer.compute_losses_base on materialised warped images; reference: train.py:987-1051.
+    inputs: disp, tgt, mask_rec|None, noise|None, S, flags, smoothness, *warped(S), *src(S)
+    outputs: loss (0-dim), auto_mask [B,1,H,W], to_opt [B,H,W], argmin uint8 [B,H,W]"""
+
+    @staticmethod
+    def forward(ctx, disp, tgt, mask_rec, noise, S, flags, smoothness, *imgs):
+        warped = [_c(t) for t in imgs[:S]]
+        src = [_c(t) for t in imgs[S:2 * S]]
+        nat.require_device(disp, tgt, mask_rec, noise, *warped, *src)
+        disp, tgt, mask_rec, noise = _c(disp), _c(tgt), _c(mask_rec), _c(noise)
+        B, _, H, W = disp.shape
+        dev = disp.device
+        loss = torch.empty(3, dtype=torch.float32, device=dev)
+        argmin = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        auto_mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev)
+        to_opt = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+        stats = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        ws = _ws(disp, B, H, W)
+        wp, wkeep = nat.ptr_array(warped)
+        sp, skeep = nat.ptr_array(src) if src else (None, None)
+        nat.check(nat.lib().mvf_photo_fwd(nat.ptr(disp), nat.ptr(tgt), wp, sp, nat.ptr(noise),
+                                          nat.ptr(mask_rec), S, flags, smoothness, nat.ptr(loss),
+                                          nat.ptr(argmin), nat.ptr(auto_mask), nat.ptr(to_opt),
+                                          nat.ptr(stats), nat.ptr(ws), B, H, W, _stream()),
+                  "photo_fwd")
+        ctx.save_for_backward(disp, tgt, mask_rec, argmin, stats, *warped)
+        ctx.cfg = (S, flags, smoothness)
+        ctx.mark_non_differentiable(auto_mask, to_opt, argmin)
+        return loss[0], auto_mask, to_opt, argmin
+
+    @staticmethod
+    def backward(ctx, g_loss, *_unused):
+        disp, tgt, mask_rec, argmin, stats, *warped = ctx.saved_tensors
+        S, flags, smoothness = ctx.cfg
+        B, _, H, W = disp.shape
+        g_loss = _c(g_loss).reshape(1)
+        g_warped = [torch.empty_like(w) for w in warped]
+        g_disp = torch.empty_like(disp)
+        wp, wkeep = nat.ptr_array(warped)
+        gp, gkeep = nat.ptr_array(g_warped)
+        nat.check(nat.lib().mvf_photo_bwd(nat.ptr(disp), nat.ptr(tgt), wp, nat.ptr(argmin),
+                                          nat.ptr(mask_rec), nat.ptr(stats), nat.ptr(g_loss), S,
+                                          flags, smoothness, gp, nat.ptr(g_disp), B, H, W,
+                                          _stream()), "photo_bwd")
+        return (g_disp, None, None, None, None, None, None, *g_warped, *([None] * S))
+
+
+# ------------------------------------------------------------------ fused unit
+class Unit(torch.autograd.Function):
+    """One hot-path unit: S x generate_images_pred + compute_losses_base with the warped
+    images kept in LDS (reference: train.py:956-1051).
+    inputs: disp, tgt, T [S,B,4,4], K, inv_K, mask_rec|None, noise|None, cfg, *src(S)
+    outputs: loss (0-dim), auto_mask [B,1,H,W] (or None), argmin uint8"""
+
+    @staticmethod
+    def forward(ctx, disp, tgt, T, K, inv_K, mask_rec, noise, cfg, *src):
+        S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx = cfg
+        src = [_c(t) for t in src]
+        nat.require_device(disp, tgt, T, K, inv_K, mask_rec, noise, *src)
+        disp, tgt, T, K, inv_K = _c(disp), _c(tgt), _c(T), _c(K), _c(inv_K)
+        mask_rec, noise = _c(mask_rec), _c(noise)
+        B, _, H, W = disp.shape
+        dev = disp.device
+        md, rg = depth_consts(min_depth, max_depth)
+        loss = torch.empty(3, dtype=torch.float32, device=dev)
+        argmin = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+        auto_mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_mask else None
+        idx = torch.empty((S, B, H, W, 2), dtype=torch.int32, device=dev) if want_idx else None
+        stats = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        ws = _ws(disp, B, H, W)
+        sp, skeep = nat.ptr_array(src)
+        nat.check(nat.lib().mvf_unit_fwd(nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K),
+                                         nat.ptr(inv_K), nat.ptr(noise), nat.ptr(mask_rec), S, flags,
+                                         smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
+                                         nat.ptr(auto_mask), None, nat.ptr(stats), nat.ptr(idx),
+                                         nat.ptr(ws), B, H, W, _stream()), "unit_fwd")
+        ctx.save_for_backward(disp, tgt, T, K, inv_K, mask_rec, argmin, stats, *src)
+        ctx.cfg = (S, flags, smoothness, md, rg, eps)
+        outs = [loss[0], auto_mask if want_mask else torch.empty(0, device=dev), argmin,
+                idx if want_idx else torch.empty(0, device=dev), loss[1:]]
+        ctx.mark_non_differentiable(*outs[1:])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_loss, *_unused):
+        disp, tgt, T, K, inv_K, mask_rec, argmin, stats, *src = ctx.saved_tensors
+        S, flags, smoothness, md, rg, eps = ctx.cfg
+        B, _, H, W = disp.shape
+        g_loss = _c(g_loss).reshape(1)
+        g_disp = torch.empty_like(disp)
+        g_T = torch.empty_like(T)
+        ws = _ws(disp, B, H, W)
+        sp, skeep = nat.ptr_array(src)
+        nat.check(nat.lib().mvf_unit_bwd(nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K),
+                                         nat.ptr(inv_K), nat.ptr(argmin), nat.ptr(mask_rec),
+                                         nat.ptr(stats), nat.ptr(g_loss), S, flags, smoothness, md,
+                                         rg, eps, nat.ptr(g_disp), nat.ptr(g_T), nat.ptr(ws), B, H, W,
+                                         _stream()), "unit_bwd")
+        return (g_disp, None, g_T, None, None, None, None, None, *([None] * S))
+
+
+# ------------------------------------------------------------------ a10 pose glue
+class Pose(torch.autograd.Function):
+    """layers.transformation_from_parameters; reference: layers.py:28-103"""
+
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        nat.require_device(axisangle, translation)
+        aa = _c(axisangle).reshape(-1, 3)
+        tr = _c(translation).reshape(-1, 3)
+        B = aa.shape[0]
+        M = torch.empty((B, 4, 4), dtype=torch.float32, device=aa.device)
+        nat.check(nat.lib().mvf_pose_fwd(nat.ptr(aa), nat.ptr(tr), nat.ptr(M), int(invert), B,
+                                         _stream()), "pose_fwd")
+        ctx.save_for_backward(aa, tr)
+        ctx.meta = (int(invert), axisangle.shape, translation.shape)
+        return M
+
+    @staticmethod
+    def backward(ctx, gM):
+        aa, tr = ctx.saved_tensors
+        invert, sa, st = ctx.meta
+        gM = _c(gM)
+        g_aa, g_tr = torch.empty_like(aa), torch.empty_like(tr)
+        nat.check(nat.lib().mvf_pose_bwd(nat.ptr(aa), nat.ptr(tr), nat.ptr(gM), nat.ptr(g_aa),
+                                         nat.ptr(g_tr), invert, aa.shape[0], _stream()), "pose_bwd")
+        return g_aa.reshape(sa), g_tr.reshape(st), None

@@ -783,8 +783,9 @@ static void mat4_mul(const float *A, const float *Bm, float *C)
 {
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j < 4; ++j) {
+            /* 4x4 @ 4x4: ATen small-matrix loop, no fma (see proj_matrix) */
             float a = A[i * 4] * Bm[j];
-            for (int k = 1; k < 4; ++k) a = fmaf(A[i * 4 + k], Bm[k * 4 + j], a);
+            for (int k = 1; k < 4; ++k) a = a + A[i * 4 + k] * Bm[k * 4 + j];
             C[i * 4 + j] = a;
         }
 }

@@ -1,0 +1,342 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU
+oracle and the committed golden vectors.
+
+Bar: bit-exact for the integer sampling indices and argmin (and, in exact mode, for every
+per-pixel fp32 map whose arithmetic the reference's CPU run reproduces: depth, cam points,
+grid, SSIM, reprojection, to_optimise); <= 1e-4 relative (tensor level: max|a-b|/max|b|)
+for bilinear values, reductions and gradients -- the tolerance north_star states.
+"""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from mono_vifi_amd import _native
+    _native.lib()   # fail loudly if the HIP library is missing: no fallback
+    return torch.device("cuda:0")
+
+
+def T(a, dev, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_(True) if grad else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+class FakeSelf:
+    """Carries `opt` like the object the golden capture calls the reference's methods on."""
+
+    def __init__(self, **flags):
+        from types import SimpleNamespace
+        self.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False,
+                                   avg_reprojection=False, disable_automasking=False,
+                                   disparity_smoothness=1e-3)
+        for k, v in flags.items():
+            setattr(self.opt, k, v)
+
+
+def make_self(flags_arr, noise=None):
+    from mono_vifi_amd.losses import HotPathLosses
+
+    class S(FakeSelf, HotPathLosses):
+        pass
+    s = S(no_ssim=bool(flags_arr[0]), avg_reprojection=bool(flags_arr[1]),
+          disable_automasking=bool(flags_arr[2]))
+    s.tie_break_noise = noise
+    return s
+
+
+# ------------------------------------------------------------------ geometry (G1)
+@pytest.mark.parametrize("case", ["seed0", "seed1", "seed2", "identity", "bigrot"])
+def test_geometry_stages_bit_exact(dev, case):
+    from mono_vifi_amd import layers, ops
+    g = load_golden("g1_geom_" + case)
+    B, _, H, W = g["disp"].shape
+    _, depth = layers.disp_to_depth(T(g["disp"], dev), 0.1, 100.0)
+    assert np.array_equal(N(depth), g["depth"])
+    cam = layers.BackprojectDepth(B, H, W).to(dev)(depth, T(g["inv_K"], dev))
+    assert np.array_equal(N(cam), g["cam_points"])
+    proj = layers.Project3D(B, H, W).to(dev)
+    for k in range(2):
+        pix = proj(cam, T(g["K"], dev), T(g[f"T{k}"], dev))
+        assert np.array_equal(N(pix), g[f"pix{k}"], equal_nan=True)
+        idx = N(ops.grid_sample_indices((B, 3, H, W), pix))
+        assert np.array_equal(idx[..., 0], g[f"x0_{k}"])
+        assert np.array_equal(idx[..., 1], g[f"y0_{k}"])
+        out = layers.grid_sample_border_ac(T(g["src"][k], dev), pix)
+        assert np.max(np.abs(N(out) - g[f"warped{k}"])) <= 1e-6
+        warped, pix2, idx2 = ops.warp_debug(T(g["disp"], dev), T(g[f"T{k}"], dev),
+                                            T(g["src"][k], dev), T(g["K"], dev), T(g["inv_K"], dev))
+        assert np.array_equal(N(pix2), g[f"pix{k}"], equal_nan=True)
+        assert np.array_equal(N(idx2)[..., 0], g[f"x0_{k}"])
+        assert np.array_equal(N(idx2)[..., 1], g[f"y0_{k}"])
+        assert np.max(np.abs(N(warped) - g[f"warped{k}"])) <= 1e-6
+
+
+def test_pose_glue(dev):
+    from mono_vifi_amd import layers
+    g = load_golden("g5_pose")
+    for tag, inv in (("fwd", False), ("inv", True)):
+        aa, tr = T(g["axisangle"], dev, True), T(g["translation"], dev, True)
+        M = layers.transformation_from_parameters(aa, tr, invert=inv)
+        assert np.max(np.abs(N(M) - g["M_" + tag])) <= 2e-6
+        (M * T(g["weight"], dev)).sum().backward()
+        assert rel_err(N(aa.grad), g["grad_axisangle_" + tag]) <= TOL
+        assert rel_err(N(tr.grad), g["grad_translation_" + tag]) <= TOL
+    R = layers.rot_from_axisangle(T(g["axisangle"], dev))
+    assert np.max(np.abs(N(R)[:, :3, :3] - g["M_fwd"][:, :3, :3])) <= 2e-6
+
+
+# ------------------------------------------------------------------ photometric (G2, G6)
+def test_ssim_and_smooth_standalone(dev):
+    from mono_vifi_amd import layers
+    g = load_golden("g6_ssim_smooth")
+    x, y = T(g["x"], dev, True), T(g["y"], dev, True)
+    s = layers.SSIM().to(dev)(x, y)
+    assert np.array_equal(N(s), g["ssim"])
+    (s * T(g["weight"], dev)).sum().backward()
+    assert rel_err(N(x.grad), g["grad_x"]) <= TOL
+    assert rel_err(N(y.grad), g["grad_y"]) <= TOL
+    s2 = layers.SSIM()(T(g["x_near"], dev), T(g["y"], dev))
+    assert np.array_equal(N(s2), g["ssim_near"])   # catastrophic-cancellation regime
+    disp = T(g["disp"], dev, True)
+    sm = layers.get_smooth_loss(disp, T(g["y"], dev))
+    assert abs(float(sm) - float(g["smooth"])) <= 2e-6 * abs(float(g["smooth"]))
+    sm.backward()
+    assert rel_err(N(disp.grad), g["grad_disp"]) <= 1e-5
+
+
+@pytest.mark.parametrize("case", ["default", "mask", "no_ssim", "avg", "noauto", "noauto_mask"])
+def test_losses_base_forward(dev, case):
+    g = load_golden("g2_photo_" + case)
+    noise = T(g["noise"], dev) if "noise" in g and not g["flags"][2] else None
+    s = make_self(g["flags"], noise)
+    tgt = T(g["tgt"], dev)
+    warped = [T(g["warped"][k], dev) for k in range(2)]
+    srcs = [T(g["src"][k], dev) for k in range(2)]
+    for k in range(2):
+        rp = s.compute_reprojection_loss(warped[k], tgt)
+        assert np.array_equal(N(rp)[:, 0], g["rp"][:, k])
+        idl = s.compute_reprojection_loss(srcs[k], tgt)
+        assert np.array_equal(N(idl)[:, 0], g["idl"][:, k])
+    mask = T(g["mask_rec"], dev) if case in ("mask", "noauto_mask") else None
+    from mono_vifi_amd import ops
+    disp = T(g["disp"], dev)
+    S = 2
+    src_args = srcs if not g["flags"][2] else []
+    loss, auto_mask, to_opt, argmin = ops.LossesBase.apply(
+        disp, tgt, mask, noise, S, s._loss_flags(), 1e-3, *warped, *src_args)
+    assert np.array_equal(N(to_opt).reshape(g["to_opt"].shape), g["to_opt"])
+    if "idxs" in g:
+        assert np.array_equal(N(argmin).astype(np.int32), g["idxs"])
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    loss2, am2 = s.compute_losses_base({("disp", 0): disp}, tgt, warped, srcs, mask)
+    assert float(loss2) == float(loss)
+    if "auto_mask" in g:
+        assert np.array_equal(N(am2), g["auto_mask"])
+    else:
+        assert am2 is None
+
+
+# ------------------------------------------------------------------ gradients (G3)
+@pytest.mark.parametrize("case", ["default", "mask", "no_ssim", "avg", "noauto"])
+@pytest.mark.parametrize("path", ["staged", "fused"])
+def test_unit_gradients(dev, case, path):
+    from mono_vifi_amd import layers
+    g = load_golden("g3_grad_" + case)
+    noise = T(g["noise"], dev) if "noise" in g and not g["flags"][2] else None
+    s = make_self(g["flags"], noise)
+    aa, tr = T(g["axisangle"], dev, True), T(g["translation"], dev, True)
+    disp = T(g["disp"], dev, True)
+    tgt = T(g["tgt"], dev)
+    srcs = [T(g["src"][k], dev) for k in range(2)]
+    K, inv_K = T(g["K"], dev), T(g["inv_K"], dev)
+    mask = T(g["mask_rec"], dev) if case == "mask" else None
+    poses = []
+    for k in range(2):
+        M = layers.transformation_from_parameters(aa[k], tr[k], invert=(k == 1))
+        M.retain_grad()
+        poses.append(M)
+    warped = []
+    if path == "staged":
+        for k in range(2):
+            w = s.generate_images_pred({("disp", 0): disp}, poses[k], srcs[k], K, inv_K)
+            w.retain_grad()
+            warped.append(w)
+        loss, auto_mask = s.compute_losses_base({("disp", 0): disp}, tgt, warped, srcs, mask)
+    else:
+        loss, auto_mask = s.compute_unit({("disp", 0): disp}, tgt, poses, srcs, K, inv_K, mask,
+                                         want_auto_mask=True)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    if "auto_mask" in g:
+        assert np.array_equal(N(auto_mask), g["auto_mask"])
+    if path == "staged":
+        for k in range(2):
+            assert np.max(np.abs(N(warped[k]) - g["warped"][k])) <= 1e-6
+            assert rel_err(N(warped[k].grad), g["grad_warped"][k]) <= TOL
+    assert rel_err(N(disp.grad), g["grad_disp"]) <= TOL
+    gT = np.stack([N(p.grad) for p in poses], 0)
+    assert rel_err(gT, g["grad_T"]) <= TOL
+    assert rel_err(N(aa.grad), g["grad_axisangle"]) <= TOL
+    assert rel_err(N(tr.grad), g["grad_translation"]) <= TOL
+
+
+# ------------------------------------------------------------------ full size (G4)
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C4", "C5"])
+def test_fullsize_unit(dev, cfg):
+    """BASELINE.json shapes through the fused unit: index-map SHA-256, loss, auto-mask and
+    sampled gradients against what the reference produced on the same seeded inputs, and
+    the whole tensors against the oracle."""
+    from mono_vifi_amd import ops, synthetic
+    g = load_golden("g4_full_" + cfg)
+    B, H, W = (int(v) for v in g["shape"])
+    inp = synthetic.unit_inputs(int(g["seed"]), B, H, W, with_mask=True)
+    disp = T(inp["disp"], dev, True)
+    Tt = T(g["T"], dev, True)
+    cfgt = (2, 0, 1e-3, 0.1, 100.0, 1e-7, True, True)
+    loss, auto_mask, argmin, idx, _ = ops.Unit.apply(
+        disp, T(inp["tgt"], dev), Tt, T(inp["K"], dev), T(inp["inv_K"], dev),
+        T(inp["mask_rec"], dev), T(inp["noise"], dev), cfgt, T(inp["src"][0], dev),
+        T(inp["src"][1], dev))
+    loss.backward()
+    idx = N(idx)
+    for k in range(2):
+        assert hashlib.sha256(np.ascontiguousarray(idx[k, ..., 0]).tobytes()).hexdigest() == str(g[f"sha_x0_{k}"])
+        assert hashlib.sha256(np.ascontiguousarray(idx[k, ..., 1]).tobytes()).hexdigest() == str(g[f"sha_y0_{k}"])
+    n = B * H * W
+    sidx = g["sample_idx"]
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    am = N(auto_mask).reshape(n)
+    assert np.array_equal(am[sidx], g["auto_mask_s"])
+    assert abs(am.mean() - float(g["auto_mask_mean"])) <= 1e-6
+    gd = N(disp.grad)
+    assert rel_err(gd.reshape(n)[sidx], g["grad_disp_s"]) <= TOL
+    assert abs(np.linalg.norm(gd.astype(np.float64)) - float(g["grad_disp_norm"])) <= TOL * float(g["grad_disp_norm"])
+    # whole tensors vs the oracle (fp64 reductions on both sides)
+    ref = O.unit(inp["disp"], inp["tgt"], inp["src"], g["T"], inp["K"], inp["inv_K"], inp["noise"],
+                 inp["mask_rec"], 0, want_grads=True)
+    assert np.array_equal(N(argmin).astype(np.int32), ref["idx"])
+    assert rel_err(gd, ref["grad_disp"]) <= TOL
+    assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
+    # the reference itself reduces grad_P in fp32; its own value is only good to ~5e-3
+    assert rel_err(N(Tt.grad), g["grad_T"]) <= 5e-3
+
+
+# ------------------------------------------------------------------ ragged shapes vs oracle
+RAGGED = [(1, 2, 2), (1, 3, 5), (2, 14, 62), (1, 15, 63), (1, 16, 64), (2, 17, 65), (1, 31, 129),
+          (3, 33, 70), (1, 64, 200)]
+
+
+@pytest.mark.parametrize("shape", RAGGED)
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 6])
+def test_ragged_shapes_vs_oracle(dev, shape, flags):
+    """Tile-edge and tiny shapes (partial tiles, reflect halo == whole image, 1-tile
+    images) for every flag combination, staged and fused, against the oracle."""
+    from mono_vifi_amd import ops, synthetic
+    B, H, W = shape
+    inp = synthetic.unit_inputs(900 + H * W + flags, B, H, W, pose_scale=0.03, with_mask=True)
+    use_mask = not (flags & 4 and flags & 2)
+    mask_np = inp["mask_rec"] if use_mask else None
+    T_np = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
+                     for k in range(2)], 0)
+    noise_np = inp["noise"][:, :1] if flags & 2 else inp["noise"]
+    ref = O.unit(inp["disp"], inp["tgt"], inp["src"], T_np, inp["K"], inp["inv_K"],
+                 np.ascontiguousarray(noise_np), mask_np, flags, want_grads=True)
+    noise = None if flags & 4 else T(np.ascontiguousarray(noise_np), dev)
+    mask = T(mask_np, dev) if use_mask else None
+    disp = T(inp["disp"], dev, True)
+    Tt = T(T_np, dev, True)
+    cfgt = (2, flags, 1e-3, 0.1, 100.0, 1e-7, True, True)
+    loss, auto_mask, argmin, idx, _ = ops.Unit.apply(
+        disp, T(inp["tgt"], dev), Tt, T(inp["K"], dev), T(inp["inv_K"], dev), mask, noise, cfgt,
+        T(inp["src"][0], dev), T(inp["src"][1], dev))
+    loss.backward()
+    idx = N(idx)
+    for k in range(2):
+        assert np.array_equal(idx[k, ..., 0], ref["x0"][k])
+        assert np.array_equal(idx[k, ..., 1], ref["y0"][k])
+    am = N(argmin).astype(np.int32)
+    am[am == 255] = -1
+    assert np.array_equal(am, ref["idx"])
+    assert abs(float(loss) - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    assert rel_err(N(disp.grad), ref["grad_disp"]) <= TOL
+    assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
+
+
+# ------------------------------------------------------------------ properties at full size
+def test_properties_fullsize(dev):
+    """Size-independent properties at the benchmark shape (B12 640x192): determinism of the
+    whole unit, linearity of the backward in the upstream gradient, identity-pose warp
+    reproduces the source image, staged == fused."""
+    from mono_vifi_amd import ops, synthetic
+    B, H, W = 12, 192, 640
+    inp = synthetic.unit_inputs(77, B, H, W, with_mask=True)
+    T_np = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
+                     for k in range(2)], 0)
+    tens = dict(tgt=T(inp["tgt"], dev), K=T(inp["K"], dev), inv_K=T(inp["inv_K"], dev),
+                mask=T(inp["mask_rec"], dev), noise=T(inp["noise"], dev),
+                s0=T(inp["src"][0], dev), s1=T(inp["src"][1], dev))
+    cfgt = (2, 0, 1e-3, 0.1, 100.0, 1e-7, True, False)
+
+    def run(scale):
+        disp = T(inp["disp"], dev, True)
+        Tt = T(T_np, dev, True)
+        loss, am, argmin, _, _ = ops.Unit.apply(disp, tens["tgt"], Tt, tens["K"], tens["inv_K"],
+                                                tens["mask"], tens["noise"], cfgt, tens["s0"],
+                                                tens["s1"])
+        (loss * scale).backward()
+        return float(loss), N(disp.grad), N(Tt.grad), N(argmin)
+
+    l1, gd1, gT1, a1 = run(1.0)
+    l2, gd2, gT2, a2 = run(1.0)
+    assert l1 == l2 and np.array_equal(gd1, gd2) and np.array_equal(gT1, gT2) and np.array_equal(a1, a2)
+    l3, gd3, gT3, _ = run(4.0)   # power of two: exact scaling
+    assert np.array_equal(gd3, gd1 * 4.0) and rel_err(gT3, gT1 * 4.0) <= 1e-6
+
+    # identity pose + any depth: every pixel samples itself
+    eye = torch.eye(4, device=dev).repeat(B, 1, 1)
+    warped, pix, idx = ops.warp_debug(T(inp["disp"], dev), eye, tens["s0"], tens["K"], tens["inv_K"])
+    assert float((warped - tens["s0"]).abs().max()) <= 2e-4
+
+    # staged path == fused path
+    from mono_vifi_amd.losses import HotPathLosses
+
+    class S(FakeSelf, HotPathLosses):
+        pass
+    s = S()
+    s.tie_break_noise = tens["noise"]
+    disp = T(inp["disp"], dev, True)
+    Tt = T(T_np, dev, True)
+    ws = [s.generate_images_pred({("disp", 0): disp}, Tt[k], [tens["s0"], tens["s1"]][k], tens["K"],
+                                 tens["inv_K"]) for k in range(2)]
+    loss, _ = s.compute_losses_base({("disp", 0): disp}, tens["tgt"], ws, [tens["s0"], tens["s1"]],
+                                    tens["mask"])
+    loss.backward()
+    assert abs(float(loss) - l1) <= 1e-6 * abs(l1)
+    assert rel_err(N(disp.grad), gd1) <= 1e-5
+    assert rel_err(N(Tt.grad), gT1) <= 1e-5
+
+
+def test_error_behaviour(dev):
+    """Errors the reference raises at this boundary are kept."""
+    from mono_vifi_amd import layers
+    bp = layers.BackprojectDepth(2, 8, 8).to(dev)
+    with pytest.raises(RuntimeError):
+        bp(torch.rand(3, 1, 8, 8, device=dev), torch.eye(4, device=dev).repeat(3, 1, 1))
+    with pytest.raises(RuntimeError):   # no CPU fallback
+        layers.SSIM()(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
