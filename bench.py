@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the Mono-ViFI hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload hotpath|train]
+
+One process per GPU (the driver launches ``python -m torch.distributed.run`` for N > 1; RANK /
+LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment).  W untimed warm-up steps,
+then exactly K timed steps bracketed by barrier + synchronize on both sides; the maximum
+over ranks is used and rank 0 prints ONE JSON line.
+
+Workloads (config.workload in the JSON names the one that ran):
+
+* ``hotpath`` -- a step is one pass of the view-synthesis + photometric-loss path over one
+  batch: the 9 units ``Trainer.process_batch`` runs per optimisation step with
+  ``use_affine`` (reference train.py:747-883), each = 2 x generate_images_pred +
+  compute_losses_base, forward AND backward (grad_disp, grad_T), on synthetic
+  KITTI-shaped triplets (BASELINE.json configs[1]: batch 12, 640x192, 3-frame) resident in
+  HBM.  The 9 units use distinct buffers (531 MB > 256 MiB Infinity Cache).
+* ``train`` -- the whole optimisation step of the drop-in trainer (networks + hot path +
+  backward + clip + AdamW), see mono-vifi_amd/trainer.py.
+
+``roofline`` is for the dominant hot-path kernel (fused unit backward), from HIP events the
+library records around every launch of it inside the timed region.  ``cpu_baseline`` times
+the CPU oracle (a port of the reference's algorithm, checked bit-exact against it) on the
+host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+FWD_BYTES_PER_PX = 44          # disp 4 + tgt 12 + 2 src 24 read, 4 written
+BWD_BYTES_PER_PX = 45          # same reads + argmin 1, grad_disp 4 written
+UNITS_PER_STEP = 9             # reference train.py:747-883 with use_affine
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=os.environ.get("MVF_BENCH_WORKLOAD", "auto"),
+                    choices=["auto", "hotpath", "train"])
+    ap.add_argument("--batch", type=int, default=12)
+    ap.add_argument("--height", type=int, default=192)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--backbone", default="ResNet18")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group(backend="nccl", init_method="env://",
+                                             world_size=world, rank=rank,
+                                             device_id=torch.device("cuda", local))
+    if world != args.gpus and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    return world, rank, torch.device("cuda", local)
+
+
+def barrier_sync(world):
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+
+
+# ----------------------------------------------------------------------------- hot path
+class HotPathStep:
+    """9 fused units, forward + backward, on distinct HBM-resident buffers."""
+
+    def __init__(self, args, rank, dev):
+        from types import SimpleNamespace
+        from mono_vifi_amd import synthetic
+        from mono_vifi_amd.losses import HotPathLosses
+
+        class L(HotPathLosses):
+            pass
+        self.l = L()
+        self.l.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False,
+                                     avg_reprojection=False, disable_automasking=False,
+                                     disparity_smoothness=1e-3)
+        B, H, W = args.batch, args.height, args.width
+        self.units = []
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        from mono_vifi_amd import layers
+        for u in range(UNITS_PER_STEP):
+            affine = u >= 6          # the three affine units carry valid_mask_rec
+            inp = synthetic.unit_inputs(1234 + 97 * rank + u, B, H, W, with_mask=affine)
+            aa, tr = t(inp["axisangle"]), t(inp["translation"])
+            T = torch.stack([layers.transformation_from_parameters(aa[k], tr[k], invert=(k == 1))
+                             for k in range(2)], 0).detach()
+            self.units.append(dict(
+                disp=t(inp["disp"]).requires_grad_(True), T=T.requires_grad_(True),
+                tgt=t(inp["tgt"]), src=[t(inp["src"][0]), t(inp["src"][1])],
+                K=t(inp["K"]), inv_K=t(inp["inv_K"]),
+                mask=t(inp["mask_rec"]) if affine else None))
+        self.images_per_step = B
+
+    def __call__(self):
+        total = None
+        for u in self.units:
+            u["disp"].grad = None
+            u["T"].grad = None
+            loss, _ = self.l.compute_unit({("disp", 0): u["disp"]}, u["tgt"], u["T"], u["src"],
+                                          u["K"], u["inv_K"], u["mask"])
+            total = loss if total is None else total + loss
+        total.backward()
+        return total
+
+
+def cpu_baseline(args):
+    """The oracle (CPU port of the reference's algorithm) on a bounded sample: one unit,
+    forward + backward, batch 2 at the benchmark resolution, all host cores (OpenMP)."""
+    from mono_vifi_amd import synthetic
+    from oracle import oracle as O
+    Bs = 2
+    inp = synthetic.unit_inputs(4321, Bs, args.height, args.width, with_mask=True)
+    T = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
+                  for k in range(2)], 0)
+    cores = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+
+    def one():
+        O.unit(inp["disp"], inp["tgt"], inp["src"], T, inp["K"], inp["inv_K"], inp["noise"],
+               inp["mask_rec"], 0, want_grads=True)
+    one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= args.cpu_seconds or n >= 200:
+            break
+    t_unit = dt / n
+    return {"value": round(Bs / (UNITS_PER_STEP * t_unit), 3), "unit": "images/sec",
+            "cores": cores, "kind": "port",
+            "sample": f"{n} x (1 unit fwd+bwd, batch {Bs}, {args.width}x{args.height}) in "
+                      f"{dt:.1f} s; a step = {UNITS_PER_STEP} units; oracle/mvf_oracle.c, OpenMP"}
+
+
+def traffic_from_profiles(kernel):
+    """HBM bytes per launch measured offline with rocprofv3 --pmc (separate passes,
+    FETCH_SIZE doubled per the gfx950 note); committed under profiles/."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    world, rank, dev = dist_setup(args)
+    from mono_vifi_amd import _native as nat
+    nat.lib()   # fail loudly if the HIP library is missing
+
+    workload = args.workload
+    if workload == "auto":
+        workload = "train" if os.path.exists(os.path.join(ROOT, "mono-vifi_amd", "trainer.py")) \
+            else "hotpath"
+    if workload == "train":
+        from mono_vifi_amd.bench_train import TrainStep
+        step = TrainStep(args, rank, world, dev)
+    else:
+        step = HotPathStep(args, rank, dev)
+
+    for _ in range(args.warmup):
+        step()
+    nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
+    nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier_sync(world)
+    elapsed = time.perf_counter() - t0
+    nat.lib().mvf_profile_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    fwd_ms, fwd_n = nat.profile_read(nat.PROF_UNIT_FWD)
+    bwd_ms, bwd_n = nat.profile_read(nat.PROF_UNIT_BWD)
+    px = args.batch * args.height * args.width
+
+    def roof(ms, n, bytes_px, name):
+        if n == 0:
+            return None
+        avg_s = ms / n / 1e3
+        ach = bytes_px * px / avg_s / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic_from_profiles(name), "avg_us": round(avg_s * 1e6, 2),
+                "launches": n, "algorithmic_bytes_per_launch": bytes_px * px}
+
+    r_fwd = roof(fwd_ms, fwd_n, FWD_BYTES_PER_PX, "k_photo_fwd<fused>")
+    r_bwd = roof(bwd_ms, bwd_n, BWD_BYTES_PER_PX, "k_photo_bwd<fused>")
+    dominant = r_bwd if (r_bwd and (not r_fwd or bwd_ms >= fwd_ms)) else r_fwd
+
+    if rank == 0:
+        images = step.images_per_step * world * args.steps
+        out = {
+            "metric": "training images/sec (640x192, 3-frame)" if workload == "train"
+                      else "hot-path images/sec (9 view-synthesis + photometric-loss units "
+                           "fwd+bwd per batch, 640x192, 3-frame)",
+            "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{workload}: " + getattr(step, "describe", lambda: (
+                f"{UNITS_PER_STEP} units fwd+bwd, batch {args.batch}/GPU, "
+                f"{args.width}x{args.height}, 2 sources/unit, exact mode"))(),
+                "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+            "roofline": dominant,
+            "kernels": {"unit_fwd": r_fwd, "unit_bwd": r_bwd},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -169,6 +169,22 @@ MVF_API int mvf_pose_fwd(const float *axisangle, const float *translation, float
 MVF_API int mvf_pose_bwd(const float *axisangle, const float *translation, const float *g_M,
                  float *g_axisangle, float *g_translation, int invert, int B, void *stream);
 
+/* ---- measurement hooks (bench.py) ------------------------------------------------------
+ * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
+ * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded
+ * events and returns the summed kernel time and launch count for one kernel id since the
+ * last reset.  Off by default; the only process-global state in the library. */
+#define MVF_PROF_UNIT_FWD 0  /* fused unit forward tile kernel  */
+#define MVF_PROF_UNIT_BWD 1  /* fused unit backward tile kernel */
+#define MVF_PROF_PHOTO_FWD 2 /* staged compute_losses_base forward */
+#define MVF_PROF_PHOTO_BWD 3
+#define MVF_PROF_WARP_FWD 4  /* staged generate_images_pred */
+#define MVF_PROF_WARP_BWD 5
+#define MVF_PROF_COUNT 6
+MVF_API int mvf_profile_enable(int on);
+MVF_API int mvf_profile_reset(void);
+MVF_API int mvf_profile_read(int kernel_id, double *total_ms, int64_t *launches);
+
 /* floats of scratch the reducing entry points need for a [B,*,H,W] problem */
 MVF_API size_t mvf_workspace_floats(int B, int H, int W);
 

@@ -49,7 +49,11 @@ _SIGNATURES = {
                      _vp, _vp, _i, _i, _i, _vp],
     "mvf_pose_fwd": [_vp, _vp, _vp, _i, _i, _vp],
     "mvf_pose_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mvf_profile_enable": [_i],
+    "mvf_profile_reset": [],
+    "mvf_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
 }
+PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD = range(6)
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t}
 
 EXPORTS = tuple(_SIGNATURES)
@@ -108,3 +112,10 @@ def require_device(*tensors):
             raise RuntimeError(
                 "mono_vifi_amd hot-path ops run on a HIP device (MI355X) only; got a "
                 f"{t.device} tensor. There is no CPU fallback.")
+
+
+def profile_read(kernel_id):
+    """(total_ms, launches) of one dominant kernel since the last mvf_profile_reset()."""
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    check(lib().mvf_profile_read(kernel_id, C.byref(ms), C.byref(n)), "profile_read")
+    return ms.value, n.value

@@ -281,4 +281,14 @@ inline int hip_check_launch()
     return (int)hipGetLastError();
 }
 
+// measurement hooks (implemented in mvf_geom.hip): event pair around one kernel launch
+void prof_begin(int kernel_id, hipStream_t st);
+void prof_end(int kernel_id, hipStream_t st);
+struct ProfScope {
+    int id;
+    hipStream_t st;
+    ProfScope(int kernel_id, hipStream_t s) : id(kernel_id), st(s) { prof_begin(id, st); }
+    ~ProfScope() { prof_end(id, st); }
+};
+
 }  // namespace mvf

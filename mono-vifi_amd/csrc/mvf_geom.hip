@@ -469,6 +469,64 @@ __global__ void k_pose_bwd(const float *__restrict__ aa, const float *__restrict
 
 }  // namespace
 
+// ---------------------------------------------------------------- measurement hooks
+#include <mutex>
+#include <vector>
+namespace mvf {
+namespace {
+struct ProfState {
+    std::mutex mu;
+    bool on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[MVF_PROF_COUNT];
+    hipEvent_t open_start[MVF_PROF_COUNT] = {};
+    double acc_ms[MVF_PROF_COUNT] = {};
+    int64_t acc_n[MVF_PROF_COUNT] = {};
+};
+ProfState &prof() { static ProfState p; return p; }
+constexpr size_t kMaxPairs = 1 << 16;
+
+void drain(ProfState &p, int id)
+{
+    for (auto &pr : p.ev[id]) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(pr.second) == hipSuccess &&
+            hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+            p.acc_ms[id] += ms;
+            p.acc_n[id] += 1;
+        }
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    p.ev[id].clear();
+}
+}  // namespace
+
+void prof_begin(int id, hipStream_t st)
+{
+    ProfState &p = prof();
+    if (!p.on) return;
+    std::lock_guard<std::mutex> g(p.mu);
+    if (p.ev[id].size() >= kMaxPairs) drain(p, id);
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    hipEventRecord(e, st);
+    p.open_start[id] = e;
+}
+
+void prof_end(int id, hipStream_t st)
+{
+    ProfState &p = prof();
+    if (!p.on) return;
+    std::lock_guard<std::mutex> g(p.mu);
+    if (!p.open_start[id]) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    hipEventRecord(e, st);
+    p.ev[id].emplace_back(p.open_start[id], e);
+    p.open_start[id] = nullptr;
+}
+}  // namespace mvf
+
 // shared with mvf_photo.hip: fold the fused backward's per-tile grad_P partials
 namespace mvf_geom {
 int finish_gT(const float *ws, const float *K, float *gT, int B, int S, int nblk, void *stream)
@@ -482,6 +540,37 @@ int finish_gT(const float *ws, const float *K, float *gT, int B, int S, int nblk
 extern "C" {
 
 int mvf_abi_version(void) { return MVF_ABI_VERSION; }
+
+int mvf_profile_enable(int on)
+{
+    auto &p = mvf::prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.on = on != 0;
+    return 0;
+}
+
+int mvf_profile_reset(void)
+{
+    auto &p = mvf::prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    for (int i = 0; i < MVF_PROF_COUNT; ++i) {
+        mvf::drain(p, i);
+        p.acc_ms[i] = 0.0;
+        p.acc_n[i] = 0;
+    }
+    return 0;
+}
+
+int mvf_profile_read(int id, double *total_ms, int64_t *launches)
+{
+    if (id < 0 || id >= MVF_PROF_COUNT) return (int)hipErrorInvalidValue;
+    auto &p = mvf::prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    mvf::drain(p, id);
+    if (total_ms) *total_ms = p.acc_ms[id];
+    if (launches) *launches = p.acc_n[id];
+    return 0;
+}
 
 const char *mvf_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 
@@ -577,8 +666,11 @@ int mvf_warp_fwd(const float *disp, const float *inv_K, const float *K, const fl
                  int W, float min_disp, float range, float eps, void *stream)
 {
     if (B * H * W <= 0) return 0;
-    hipLaunchKernelGGL(k_warp_fwd, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream, disp,
-                       inv_K, K, T, src, warped, pix, idx_xy, H, W, min_disp, range, eps);
+    {
+        ProfScope ps(MVF_PROF_WARP_FWD, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_warp_fwd, pix_grid(H, W, B), dim3(NT), 0, (hipStream_t)stream, disp,
+                           inv_K, K, T, src, warped, pix, idx_xy, H, W, min_disp, range, eps);
+    }
     return hip_check_launch();
 }
 
@@ -589,8 +681,12 @@ int mvf_warp_bwd(const float *disp, const float *inv_K, const float *K, const fl
 {
     if (B * H * W <= 0) return 0;
     dim3 grid = pix_grid(H, W, B);
-    hipLaunchKernelGGL(k_warp_bwd, grid, dim3(NT), 0, (hipStream_t)stream, disp, inv_K, K, T, src,
-                       g_warped, g_disp, g_src, workspace, accumulate, H, W, min_disp, range, eps);
+    {
+        ProfScope ps(MVF_PROF_WARP_BWD, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_warp_bwd, grid, dim3(NT), 0, (hipStream_t)stream, disp, inv_K, K, T,
+                           src, g_warped, g_disp, g_src, workspace, accumulate, H, W, min_disp,
+                           range, eps);
+    }
     hipLaunchKernelGGL(k_finish_gT, dim3(B, 1), dim3(NT), 0, (hipStream_t)stream, workspace, K,
                        g_T, (int)grid.x);
     return hip_check_launch();

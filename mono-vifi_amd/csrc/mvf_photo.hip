@@ -961,10 +961,13 @@ int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *sta
     a.tiles_y = (a.H + TH - 1) / TH;
     hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, a.B), dim3(256), 0, st, a.disp, a.ws, N);
     dim3 grid(a.tiles_x, a.tiles_y, a.B);
-    if (fused)
-        hipLaunchKernelGGL(k_photo_fwd<true>, grid, dim3(NT), fwd_smem(), st, a);
-    else
-        hipLaunchKernelGGL(k_photo_fwd<false>, grid, dim3(NT), fwd_smem(), st, a);
+    {
+        ProfScope ps(fused ? MVF_PROF_UNIT_FWD : MVF_PROF_PHOTO_FWD, st);
+        if (fused)
+            hipLaunchKernelGGL(k_photo_fwd<true>, grid, dim3(NT), fwd_smem(), st, a);
+        else
+            hipLaunchKernelGGL(k_photo_fwd<false>, grid, dim3(NT), fwd_smem(), st, a);
+    }
     hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(256), 0, st, a.ws, loss, stats, a.B, a.H, a.W,
                        a.tiles_x * a.tiles_y, smoothness, 1);
     return hip_check_launch();
@@ -1092,8 +1095,11 @@ int mvf_photo_bwd(const float *disp, const float *tgt, const float *const *warpe
     a.S = S; a.flags = flags; a.B = B; a.H = H; a.W = W;
     a.tiles_x = (W + OW - 1) / OW; a.tiles_y = (H + OH - 1) / OH;
     a.smoothness = smoothness;
-    hipLaunchKernelGGL(k_photo_bwd<false>, dim3(a.tiles_x, a.tiles_y, B), dim3(NT), bwd_smem(),
-                       (hipStream_t)stream, a);
+    {
+        ProfScope ps(MVF_PROF_PHOTO_BWD, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_photo_bwd<false>, dim3(a.tiles_x, a.tiles_y, B), dim3(NT), bwd_smem(),
+                           (hipStream_t)stream, a);
+    }
     return hip_check_launch();
 }
 
@@ -1113,8 +1119,11 @@ int mvf_unit_bwd(const float *disp, const float *tgt, const float *const *src, c
     a.S = S; a.flags = flags; a.B = B; a.H = H; a.W = W;
     a.tiles_x = (W + OW - 1) / OW; a.tiles_y = (H + OH - 1) / OH;
     a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
-    hipLaunchKernelGGL(k_photo_bwd<true>, dim3(a.tiles_x, a.tiles_y, B), dim3(NT), bwd_smem(),
-                       (hipStream_t)stream, a);
+    {
+        ProfScope ps(MVF_PROF_UNIT_BWD, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_photo_bwd<true>, dim3(a.tiles_x, a.tiles_y, B), dim3(NT), bwd_smem(),
+                           (hipStream_t)stream, a);
+    }
     return mvf_geom::finish_gT(workspace, K, g_T, B, S, a.tiles_x * a.tiles_y, stream);
 }
 
