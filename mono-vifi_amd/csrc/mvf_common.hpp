@@ -181,6 +181,26 @@ MVF_DEV float warp_point_bwd(const WarpPoint &w, const float P[12], float gix, f
     return gd;
 }
 
+// ------------------------------------------------------------------------------- const divides
+// x/9 (3x3 window mean, reference layers.py:266-270) and x/3 (channel mean, train.py:977,982)
+// as  q = x*c ; r = fma(-d,q,x) ; q' = fma(r,c,q)  with c = RN(1/d): bit-identical to the IEEE
+// quotient for EVERY finite float (exhaustively verified by oracle/check_constdiv.c, run by
+// tests/test_constdiv.py) at 3 instructions instead of ~10.
+MVF_DEV float div9(float x)
+{
+    constexpr float c = 1.0f / 9.0f;
+    float q = x * c;
+    float r = fmaf(-9.0f, q, x);
+    return fmaf(r, c, q);
+}
+MVF_DEV float div3(float x)
+{
+    constexpr float c = 1.0f / 3.0f;
+    float q = x * c;
+    float r = fmaf(-3.0f, q, x);
+    return fmaf(r, c, q);
+}
+
 // ------------------------------------------------------------------------------- SSIM
 MVF_DEV int refl(int j, int n)
 {

@@ -8,8 +8,8 @@
 // plane it needs is staged once into LDS as an 18-row x 68-float plane (1-px reflect halo,
 // rows padded to a multiple of 16 B), and every lane then owns a 4-pixel row segment:
 // its 3x3 windows are three `ds_read_b128 + ds_read_b64` per plane (18 floats for 4
-// pixels instead of 36 scalar reads), neighbouring lanes read consecutive 16-B slots
-// (conflict-free), and global traffic is the coalesced plane staging only.
+// pixels instead of 36 scalar reads), and global traffic is the coalesced plane staging
+// plus the L2-served bilinear taps.
 //   forward : region = output tile (grid steps 64x16)
 //   backward: region = where the SSIM adjoint coefficients are formed; outputs are its
 //             62x14 interior (grid steps 62x14), so the 3x3 adjoint gather never leaves
@@ -30,6 +30,7 @@ constexpr int PW = TW + 2;               // staged plane width (1-px halo)
 constexpr int PH = TH + 2;
 constexpr int LDW = TW + 4;              // LDS row stride (floats), multiple of 4
 constexpr int PLANE = PH * LDW;          // floats per LDS plane
+constexpr int RPLANE = TH * LDW;         // floats per region-sized LDS plane
 constexpr int NMEAN = 32;                // partial sums per image of the disp mean
 constexpr int NPART = 4;                 // floats per tile partial (photo, sx, sy, pad)
 
@@ -53,6 +54,21 @@ MVF_DEV void stage_plane(float *__restrict__ lds, const float *__restrict__ img,
     }
 }
 
+// stage 3 channel planes with all loads of a lane in flight together
+MVF_DEV void stage_planes3(float *__restrict__ lds, const float *__restrict__ img, size_t N, int H,
+                           int W, int py0, int px0)
+{
+    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
+        int r = idx / PW, c = idx - r * PW;
+        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
+        size_t o = (size_t)gy * W + gx;
+        float v0 = img[o], v1 = img[N + o], v2 = img[2 * N + o];
+        lds[r * LDW + c] = v0;
+        lds[PLANE + r * LDW + c] = v1;
+        lds[2 * PLANE + r * LDW + c] = v2;
+    }
+}
+
 // 6 consecutive floats of an LDS plane row, starting at a 16-B aligned column
 struct Row6 {
     float v[6];
@@ -70,7 +86,7 @@ MVF_DEV Row6 load_row6(const float *__restrict__ p)
 // xs/ys point at plane element (row, 4*seg): the window of pixel j covers cols j..j+2.
 struct Stats4 {
     float sx[PX], sxx[PX], sxy[PX];
-    float xc[PX];   // centre values of x
+    float xc[PX], yc[PX];   // centre values
 };
 
 MVF_DEV void window_x(const float *__restrict__ xs, const float *__restrict__ ys, Stats4 &o)
@@ -99,13 +115,16 @@ MVF_DEV void window_x(const float *__restrict__ xs, const float *__restrict__ ys
                     o.sxy[j] = o.sxy[j] + xy[j + d];
                 }
             }
-            if (r == 1) o.xc[j] = x.v[j + 1];
+            if (r == 1) {
+                o.xc[j] = x.v[j + 1];
+                o.yc[j] = y.v[j + 1];
+            }
         }
     }
 }
 
 struct StatsY4 {
-    float mu[PX], eyy[PX], yc[PX];
+    float mu[PX], eyy[PX];
 };
 
 MVF_DEV void window_y(const float *__restrict__ ys, StatsY4 &o)
@@ -129,13 +148,12 @@ MVF_DEV void window_y(const float *__restrict__ ys, StatsY4 &o)
                     syy[j] = syy[j] + yy[j + d];
                 }
             }
-            if (r == 1) o.yc[j] = y.v[j + 1];
         }
     }
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
-        o.mu[j] = sy[j] / 9.0f;
-        o.eyy[j] = syy[j] / 9.0f;
+        o.mu[j] = div9(sy[j]);
+        o.eyy[j] = div9(syy[j]);
     }
 }
 
@@ -149,27 +167,27 @@ MVF_DEV void reproj4(const float *__restrict__ pred, const float *__restrict__ t
     for (int c = 0; c < 3; ++c) {
         if (no_ssim) {
             Row6 x = load_row6(pred + c * PLANE + off + LDW);
+            Row6 y = load_row6(tgt + c * PLANE + off + LDW);
 #pragma unroll
-            for (int j = 0; j < PX; ++j) ab[c][j] = fabsf(ty[c].yc[j] - x.v[j + 1]);
+            for (int j = 0; j < PX; ++j) ab[c][j] = fabsf(y.v[j + 1] - x.v[j + 1]);
         } else {
             Stats4 s;
             window_x(pred + c * PLANE + off, tgt + c * PLANE + off, s);
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
-                Win w = {s.sx[j] / 9.0f, ty[c].mu[j], s.sxx[j] / 9.0f, ty[c].eyy[j],
-                         s.sxy[j] / 9.0f};
+                Win w = {div9(s.sx[j]), ty[c].mu[j], div9(s.sxx[j]), ty[c].eyy[j], div9(s.sxy[j])};
                 ss[c][j] = clamp01(ssim_raw(w));
-                ab[c][j] = fabsf(ty[c].yc[j] - s.xc[j]);
+                ab[c][j] = fabsf(s.yc[j] - s.xc[j]);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
-        float l1 = ((ab[0][j] + ab[1][j]) + ab[2][j]) / 3.0f;
+        float l1 = div3((ab[0][j] + ab[1][j]) + ab[2][j]);
         if (no_ssim) {
             out[j] = l1;
         } else {
-            float sm = ((ss[0][j] + ss[1][j]) + ss[2][j]) / 3.0f;
+            float sm = div3((ss[0][j] + ss[1][j]) + ss[2][j]);
             out[j] = 0.85f * sm + 0.15f * l1;
         }
     }
@@ -201,9 +219,17 @@ MVF_DEV void warp_into_lds(float *__restrict__ pred, const float *__restrict__ d
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
         WarpPoint w = warp_point(dispP[r * LDW + c], iK, P, gx, gy, H, W, min_disp, range, eps);
-        pred[r * LDW + c] = bilerp(src, W, w.t);
-        pred[PLANE + r * LDW + c] = bilerp(src + N, W, w.t);
-        pred[2 * PLANE + r * LDW + c] = bilerp(src + 2 * N, W, w.t);
+        const float *s00 = src + w.t.y0 * W + w.t.x0, *s01 = src + w.t.y0 * W + w.t.x1;
+        const float *s10 = src + w.t.y1 * W + w.t.x0, *s11 = src + w.t.y1 * W + w.t.x1;
+        // all 12 taps in flight before the first use
+        float a0 = s00[0], b0 = s01[0], c0 = s10[0], d0 = s11[0];
+        float a1 = s00[N], b1 = s01[N], c1 = s10[N], d1 = s11[N];
+        float a2 = s00[2 * N], b2 = s01[2 * N], c2 = s10[2 * N], d2 = s11[2 * N];
+        float fw = w.t.wx, fe = 1.0f - fw, fn = w.t.wy, fs = 1.0f - fn;
+        float wnw = fs * fe, wne = fs * fw, wsw = fn * fe, wse = fn * fw;
+        pred[r * LDW + c] = a0 * wnw + b0 * wne + c0 * wsw + d0 * wse;
+        pred[PLANE + r * LDW + c] = a1 * wnw + b1 * wne + c1 * wsw + d1 * wse;
+        pred[2 * PLANE + r * LDW + c] = a2 * wnw + b2 * wne + c2 * wsw + d2 * wse;
         if (idx_xy) {
             // the un-reflected pixels of this tile own their index entry
             int y = py0 + r, x = px0 + c;
@@ -225,7 +251,7 @@ struct FwdArgs {
     float min_disp, range, eps;
 };
 
-template <bool FUSED>
+template <bool FUSED, int S>
 __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -235,7 +261,7 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
     PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + 7 * PLANE);
     float *scratch = smem + 7 * PLANE + sizeof(PoseLds) / 4;
 
-    const int H = a.H, W = a.W, S = a.S, b = blockIdx.z;
+    const int H = a.H, W = a.W, b = blockIdx.z;
     const size_t N = (size_t)H * W;
     const int ty0 = blockIdx.y * TH, tx0 = blockIdx.x * TW;
     const int py0 = ty0 - 1, px0 = tx0 - 1;
@@ -251,8 +277,7 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
         int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
         sh.P[k][e] = proj_entry(a.K + b * 16, a.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) stage_plane(tgtP + c * PLANE, a.tgt + ((size_t)b * 3 + c) * N, H, W, py0, px0);
+    stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
     stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
     __syncthreads();
 
@@ -261,11 +286,14 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
     const int y = ty0 + row, x0 = tx0 + seg * PX;
 
     StatsY4 ty[3];
+    if (!no_ssim) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) window_y(tgtP + c * PLANE + off, ty[c]);
+        for (int c = 0; c < 3; ++c) window_y(tgtP + c * PLANE + off, ty[c]);
+    }
 
-    float rp[MVF_MAX_SRC][PX], idl[MVF_MAX_SRC][PX];
+    float rp[S][PX], idl[S][PX];
     const int npred = automask ? 2 * S : S;
+#pragma unroll 1
     for (int p = 0; p < npred; ++p) {
         const bool is_id = p >= S;
         const int k = is_id ? p - S : p;
@@ -278,20 +306,17 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
                           a.idx_xy ? a.idx_xy + ((size_t)k * a.B + b) * N * 2 : nullptr, ty0, tx0);
         } else {
             const float *im = (is_id ? a.src.p[k] : a.warped.p[k]) + (size_t)b * 3 * N;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) stage_plane(predP + c * PLANE, im + (size_t)c * N, H, W, py0, px0);
+            stage_planes3(predP, im, N, H, W, py0, px0);
         }
         __syncthreads();
         float out[PX];
         reproj4(predP, tgtP, off, ty, no_ssim, out);
 #pragma unroll
-        for (int kk = 0; kk < MVF_MAX_SRC; ++kk)
-            if (kk == k) {
+        for (int kk = 0; kk < S; ++kk)     // static register indices only
 #pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    if (is_id) idl[kk][j] = out[j];
-                    else rp[kk][j] = out[j];
-                }
+            for (int j = 0; j < PX; ++j) {
+                if (kk == k && is_id) idl[kk][j] = out[j];
+                if (kk == k && !is_id) rp[kk][j] = out[j];
             }
     }
 
@@ -302,20 +327,22 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
     for (int j = 0; j < PX; ++j) {
         const int x = x0 + j;
         const bool live = (y < H) && (x < W);
-        const size_t pi = (size_t)b * N + (size_t)min(y, H - 1) * W + min(x, W - 1);
+        const size_t pix = (size_t)min(y, H - 1) * W + min(x, W - 1);
+        const size_t pi = (size_t)b * N + pix;
         float best = 0.0f;
         int bi = 0, nc = 0;
         if (automask) {
             if (avg) {
                 float m = idl[0][j];
+#pragma unroll
                 for (int k = 1; k < S; ++k) m = m + idl[k][j];
                 m = m / (float)S;
                 best = m + a.noise[pi] * 0.00001f;
                 nc = 1;
             } else {
+#pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    float v = idl[k][j] +
-                              a.noise[((size_t)b * S + k) * N + (pi - (size_t)b * N)] * 0.00001f;
+                    float v = idl[k][j] + a.noise[((size_t)b * S + k) * N + pix] * 0.00001f;
                     if (nc == 0 || v < best) { best = v; bi = nc; }
                     ++nc;
                 }
@@ -323,11 +350,13 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
         }
         if (avg) {
             float m = rp[0][j];
+#pragma unroll
             for (int k = 1; k < S; ++k) m = m + rp[k][j];
             m = m / (float)S;
             if (nc == 0 || m < best) { best = m; bi = nc; }
             ++nc;
         } else {
+#pragma unroll
             for (int k = 0; k < S; ++k) {
                 float v = rp[k][j];
                 if (nc == 0 || v < best) { best = v; bi = nc; }
@@ -343,19 +372,18 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
             photo += best;
             // ---- edge-aware smoothness (reference: layers.py:231-242 on disp/(mean+1e-7))
             const float *dc = dispP + (row + 1) * LDW + seg * PX + 1 + j;
+            const float *t0 = tgtP + (row + 1) * LDW + seg * PX + 1 + j;
             float nd = dc[0] / den;
             if (x + 1 < W) {
                 float gd = fabsf(nd - dc[1] / den);
-                const float *t0 = tgtP + (row + 1) * LDW + seg * PX + 1 + j;
-                float gi = ((fabsf(t0[0] - t0[1]) + fabsf(t0[PLANE] - t0[PLANE + 1])) +
-                            fabsf(t0[2 * PLANE] - t0[2 * PLANE + 1])) / 3.0f;
+                float gi = div3((fabsf(t0[0] - t0[1]) + fabsf(t0[PLANE] - t0[PLANE + 1])) +
+                                fabsf(t0[2 * PLANE] - t0[2 * PLANE + 1]));
                 sx += gd * expf(-gi);
             }
             if (y + 1 < H) {
                 float gd = fabsf(nd - dc[LDW] / den);
-                const float *t0 = tgtP + (row + 1) * LDW + seg * PX + 1 + j;
-                float gi = ((fabsf(t0[0] - t0[LDW]) + fabsf(t0[PLANE] - t0[PLANE + LDW])) +
-                            fabsf(t0[2 * PLANE] - t0[2 * PLANE + LDW])) / 3.0f;
+                float gi = div3((fabsf(t0[0] - t0[LDW]) + fabsf(t0[PLANE] - t0[PLANE + LDW])) +
+                                fabsf(t0[2 * PLANE] - t0[2 * PLANE + LDW]));
                 sy += gd * expf(-gi);
             }
         }
@@ -376,60 +404,82 @@ __global__ void __launch_bounds__(256) k_disp_mean(const float *__restrict__ dis
     int b = blockIdx.y, chunk = blockIdx.x;
     int per = (N + NMEAN - 1) / NMEAN;
     int lo = chunk * per, hi = min(lo + per, N);
-    float s = 0.0f;
-    for (int i = lo + threadIdx.x; i < hi; i += 256) s += disp[(size_t)b * N + i];
-    float r = block_sum<256>(s, scratch);
+    const float *d = disp + (size_t)b * N;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int i = lo + threadIdx.x;
+    for (; i + 3 * 256 < hi; i += 4 * 256) {
+        s0 += d[i];
+        s1 += d[i + 256];
+        s2 += d[i + 512];
+        s3 += d[i + 768];
+    }
+    for (; i < hi; i += 256) s0 += d[i];
+    float r = block_sum<256>((s0 + s1) + (s2 + s3), scratch);
     if (threadIdx.x == 0) ws[b * NMEAN + chunk] = r;
 }
 
-// fold tile partials: loss[0..2], stats[B][4] = {mean, den, sx_b/Nx, sy_b/Ny}
-__global__ void __launch_bounds__(256) k_finish_fwd(const float *__restrict__ ws,
-                                                    float *__restrict__ loss,
-                                                    float *__restrict__ stats, int B, int H, int W,
-                                                    int ntiles, float smoothness, int want_photo)
+// fold tile partials: loss[0..2], stats[B][4] = {mean, den, sx_b/Nx, sy_b/Ny}.
+// One wave per image (fixed order inside the wave), images of a batch folded in order.
+__global__ void __launch_bounds__(1024) k_finish_fwd(const float *__restrict__ ws,
+                                                     float *__restrict__ loss,
+                                                     float *__restrict__ stats, int B, int H, int W,
+                                                     int ntiles, float smoothness, int want_photo)
 {
-    __shared__ double sh[4][3];
-    __shared__ double tot[3];
+    __shared__ double shp[16], shs[16];
+    __shared__ double acc_photo, acc_smooth;
     const float *tp = ws + (size_t)B * NMEAN;
     const double N = (double)H * W;
-    double photo = 0.0, smooth = 0.0;
-    for (int b = 0; b < B; ++b) {
-        double acc[3] = {0.0, 0.0, 0.0};
-        for (int t = threadIdx.x; t < ntiles; t += 256)
-            for (int k = 0; k < 3; ++k) acc[k] += (double)tp[((size_t)b * ntiles + t) * NPART + k];
-        int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-        for (int k = 0; k < 3; ++k) {
-            double v = acc[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) sh[wid][k] = v;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if (threadIdx.x == 0) { acc_photo = 0.0; acc_smooth = 0.0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 16) {
+        const int b = b0 + wid;
+        if (b < B) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int t = lane; t < ntiles; t += 64) {
+                const float *q = tp + ((size_t)b * ntiles + t) * NPART;
+                a0 += (double)q[0];
+                a1 += (double)q[1];
+                a2 += (double)q[2];
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                a0 += __shfl_down(a0, off, 64);
+                a1 += __shfl_down(a1, off, 64);
+                a2 += __shfl_down(a2, off, 64);
+            }
+            if (lane == 0) {
+                double sxb = a1 / ((double)B * H * (W - 1));
+                double syb = a2 / ((double)B * (H - 1) * W);
+                shp[wid] = a0;
+                shs[wid] = sxb + syb;
+                if (stats) {
+                    float m = 0.0f;
+                    for (int i = 0; i < NMEAN; ++i) m += ws[b * NMEAN + i];
+                    float mean = m / (float)N;
+                    stats[b * 4 + 0] = mean;
+                    stats[b * 4 + 1] = mean + 1e-7f;
+                    stats[b * 4 + 2] = (float)sxb;
+                    stats[b * 4 + 3] = (float)syb;
+                }
+            }
         }
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int k = 0; k < 3; ++k) tot[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
-            double sxb = tot[1] / ((double)B * H * (W - 1));
-            double syb = tot[2] / ((double)B * (H - 1) * W);
-            photo += tot[0];
-            smooth += sxb + syb;
-            if (stats) {
-                float m = 0.0f;
-                for (int i = 0; i < NMEAN; ++i) m += ws[b * NMEAN + i];
-                float mean = m / (float)N;
-                stats[b * 4 + 0] = mean;
-                stats[b * 4 + 1] = mean + 1e-7f;
-                stats[b * 4 + 2] = (float)sxb;
-                stats[b * 4 + 3] = (float)syb;
+            for (int i = 0; i < 16 && b0 + i < B; ++i) {
+                acc_photo += shp[i];
+                acc_smooth += shs[i];
             }
         }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        double pm = photo / ((double)B * N);
+        double pm = acc_photo / ((double)B * N);
         if (want_photo) {
-            loss[0] = (float)(pm + (double)smoothness * smooth);
+            loss[0] = (float)(pm + (double)smoothness * acc_smooth);
             loss[1] = (float)pm;
-            loss[2] = (float)smooth;
+            loss[2] = (float)acc_smooth;
         } else {
-            loss[0] = (float)smooth;
+            loss[0] = (float)acc_smooth;
         }
     }
 }
@@ -447,18 +497,19 @@ struct BwdArgs {
 
 constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a backward region
 
-template <bool FUSED>
+template <bool FUSED, int S>
 __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *tgtP = smem;                 // 3 planes
     float *predP = smem + 3 * PLANE;    // 3 planes
     float *dispP = smem + 6 * PLANE;    // 1 plane
-    float *coefP = smem + 7 * PLANE;    // 3 planes of TH x LDW (A, B, G); row 0 = region row 0
-    PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + 7 * PLANE + 3 * TH * LDW);
-    float *scratch = smem + 7 * PLANE + 3 * TH * LDW + sizeof(PoseLds) / 4;
+    float *coefP = smem + 7 * PLANE;    // 3 region planes (A, B, G); reused for grad_warped
+    float *gdP = coefP + 3 * RPLANE;    // 1 region plane: grad_depth -> grad_disp accumulator
+    PoseLds &sh = *reinterpret_cast<PoseLds *>(gdP + RPLANE);
+    float *scratch = gdP + RPLANE + sizeof(PoseLds) / 4;
 
-    const int H = a.H, W = a.W, S = a.S, b = blockIdx.z;
+    const int H = a.H, W = a.W, b = blockIdx.z;
     const size_t N = (size_t)H * W;
     const int cy0 = blockIdx.y * OH - 1, cx0 = blockIdx.x * OW - 1;   // region origin
     const int py0 = cy0 - 1, px0 = cx0 - 1;                           // plane origin
@@ -476,36 +527,29 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
         int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
         sh.P[k][e] = proj_entry(a.K + b * 16, a.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) stage_plane(tgtP + c * PLANE, a.tgt + ((size_t)b * 3 + c) * N, H, W, py0, px0);
+    stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
     stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
+    for (int i = threadIdx.x; i < RPLANE; i += NT) gdP[i] = 0.0f;
     __syncthreads();
 
     const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
     const int off = row * LDW + seg * PX;
+    const int roff = row * LDW + seg * PX;   // region-plane element of this lane's first pixel
     const int y = cy0 + row, x0 = cx0 + seg * PX;
     const bool rowin = (y >= 0) && (y < H);
-    // interior (= output) pixels of this lane
-    const bool row_out = (row >= 1) && (row <= OH) && rowin;
+    const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
 
-    // selection weight of every region pixel for each source: gpix * [argmin picks k] * mask
-    float wsel[MVF_MAX_SRC][PX];
+    // base weight of every region pixel: gpix * mask (0 outside the image), and its argmin
+    float wbase[PX];
+    int sel[PX];
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         const int x = x0 + j;
         const bool in = rowin && (x >= 0) && (x < W);
         const size_t pi = (size_t)b * N + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-        int sel = in ? (int)a.argmin[pi] : 254;
+        sel[j] = in ? (int)a.argmin[pi] : 254;
         float m = (in && a.mask) ? a.mask[pi] : 1.0f;
-        float g = in ? sh.gpix * m : 0.0f;
-#pragma unroll
-        for (int k = 0; k < MVF_MAX_SRC; ++k) {
-            float w;
-            if (sel == 255) w = avg ? 1.0f / (float)S : 1.0f;        // single candidate
-            else if (avg) w = (sel == n_id) ? 1.0f / (float)S : 0.0f;
-            else w = (sel == n_id + k) ? 1.0f : 0.0f;
-            wsel[k][j] = (k < S) ? g * w : 0.0f;
-        }
+        wbase[j] = in ? sh.gpix * m : 0.0f;
     }
 
     StatsY4 ty[3];
@@ -513,21 +557,11 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
 #pragma unroll
         for (int c = 0; c < 3; ++c) window_y(tgtP + c * PLANE + off, ty[c]);
     }
-
-    // multiplicities of the reflect-padded window (refl_mult) for this lane's outputs
-    float mxl[PX], mxr[PX];
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-        const int x = x0 + j;
-        mxl[j] = (x == 1) ? 2.0f : 1.0f;           // left neighbour is image column 0
-        mxr[j] = (x == W - 2) ? 2.0f : 1.0f;       // right neighbour is image column W-1
-    }
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
 
-    float gdisp[PX] = {0.f, 0.f, 0.f, 0.f};
-    float accP[12];
-
+#pragma unroll 1
     for (int k = 0; k < S; ++k) {
+        asm volatile("" ::: "memory");   // keep k-invariant LDS reads inside the loop (VGPRs)
         __syncthreads();
         if (FUSED) {
             float P[12];
@@ -535,11 +569,20 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
             warp_into_lds(predP, dispP, a.src.p[k] + (size_t)b * 3 * N, a.invK + b * 16, P, H, W,
                           py0, px0, a.min_disp, a.range, a.eps, nullptr, 0, 0);
         } else {
-            const float *im = a.warped.p[k] + (size_t)b * 3 * N;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) stage_plane(predP + c * PLANE, im + (size_t)c * N, H, W, py0, px0);
+            stage_planes3(predP, a.warped.p[k] + (size_t)b * 3 * N, N, H, W, py0, px0);
         }
         __syncthreads();
+
+        // selection weight of this source: the argmin picked it (or the averaged channel)
+        float wk[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            float w;
+            if (sel[j] == 255) w = avg ? 1.0f / (float)S : 1.0f;        // single candidate
+            else if (avg) w = (sel[j] == n_id) ? 1.0f / (float)S : 0.0f;
+            else w = (sel[j] == n_id + k) ? 1.0f : 0.0f;
+            wk[j] = wbase[j] * w;
+        }
 
         float gw[3][PX];
 #pragma unroll
@@ -556,20 +599,20 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
                 float cA[PX], cB[PX], cG[PX];
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    Win w = {s.sx[j] / 9.0f, ty[c].mu[j], s.sxx[j] / 9.0f, ty[c].eyy[j],
-                             s.sxy[j] / 9.0f};
+                    Win w = {div9(s.sx[j]), ty[c].mu[j], div9(s.sxx[j]), ty[c].eyy[j],
+                             div9(s.sxy[j])};
                     DWin d = ssim_partials(w);
-                    float g = wsel[k][j] * (0.85f / 3.0f) / 9.0f;
+                    float g = wk[j] * ((0.85f / 3.0f) / 9.0f);
                     cA[j] = g * d.dmux;
                     cB[j] = g * 2.0f * d.dexx;
                     cG[j] = g * d.dexy;
                     xq[j] = s.xc[j];
-                    yq[j] = ty[c].yc[j];
+                    yq[j] = s.yc[j];
                 }
-                float *cp = coefP + row * LDW + seg * PX;
+                float *cp = coefP + roff;
                 *reinterpret_cast<float4 *>(cp) = make_float4(cA[0], cA[1], cA[2], cA[3]);
-                *reinterpret_cast<float4 *>(cp + TH * LDW) = make_float4(cB[0], cB[1], cB[2], cB[3]);
-                *reinterpret_cast<float4 *>(cp + 2 * TH * LDW) = make_float4(cG[0], cG[1], cG[2], cG[3]);
+                *reinterpret_cast<float4 *>(cp + RPLANE) = make_float4(cB[0], cB[1], cB[2], cB[3]);
+                *reinterpret_cast<float4 *>(cp + 2 * RPLANE) = make_float4(cG[0], cG[1], cG[2], cG[3]);
             }
             __syncthreads();
 #pragma unroll
@@ -577,32 +620,33 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
                 // L1 term: d|t-p|/dp = -sign(t-p), channel mean
                 float df = yq[j] - xq[j];
                 float sg = (df > 0.0f) ? -1.0f : ((df < 0.0f) ? 1.0f : 0.0f);
-                gw[c][j] = wsel[k][j] * (no_ssim ? 1.0f : 0.15f) * sg / 3.0f;
+                gw[c][j] = wk[j] * (no_ssim ? 1.0f : 0.15f) * sg / 3.0f;
             }
             if (!no_ssim && row >= 1 && row <= OH) {
                 float sA[PX] = {0.f, 0.f, 0.f, 0.f}, sB[PX] = {0.f, 0.f, 0.f, 0.f},
                       sG[PX] = {0.f, 0.f, 0.f, 0.f};
+                const bool hasl = seg > 0, hasr = seg < TW / PX - 1;
 #pragma unroll
                 for (int dr = -1; dr <= 1; ++dr) {
                     const float my = (dr < 0) ? myu : ((dr > 0) ? myd : 1.0f);
                     // coefficient columns 4*seg-1 .. 4*seg+4 of region row (row+dr)
-                    const float *cr = coefP + (row + dr) * LDW + seg * PX;
+                    const float *cr = coefP + roff + dr * LDW;
                     float4 mA = *reinterpret_cast<const float4 *>(cr);
-                    float4 mB = *reinterpret_cast<const float4 *>(cr + TH * LDW);
-                    float4 mG = *reinterpret_cast<const float4 *>(cr + 2 * TH * LDW);
-                    const bool hasl = seg > 0, hasr = seg < TW / PX - 1;
-                    float lA = hasl ? cr[-1] : 0.f, lB = hasl ? cr[TH * LDW - 1] : 0.f,
-                          lG = hasl ? cr[2 * TH * LDW - 1] : 0.f;
-                    float rA = hasr ? cr[4] : 0.f, rB = hasr ? cr[TH * LDW + 4] : 0.f,
-                          rG = hasr ? cr[2 * TH * LDW + 4] : 0.f;
-                    float vA[6] = {lA, mA.x, mA.y, mA.z, mA.w, rA};
-                    float vB[6] = {lB, mB.x, mB.y, mB.z, mB.w, rB};
-                    float vG[6] = {lG, mG.x, mG.y, mG.z, mG.w, rG};
+                    float4 mB = *reinterpret_cast<const float4 *>(cr + RPLANE);
+                    float4 mG = *reinterpret_cast<const float4 *>(cr + 2 * RPLANE);
+                    float vA[6] = {hasl ? cr[-1] : 0.f, mA.x, mA.y, mA.z, mA.w, hasr ? cr[4] : 0.f};
+                    float vB[6] = {hasl ? cr[RPLANE - 1] : 0.f, mB.x, mB.y, mB.z, mB.w,
+                                   hasr ? cr[RPLANE + 4] : 0.f};
+                    float vG[6] = {hasl ? cr[2 * RPLANE - 1] : 0.f, mG.x, mG.y, mG.z, mG.w,
+                                   hasr ? cr[2 * RPLANE + 4] : 0.f};
 #pragma unroll
                     for (int j = 0; j < PX; ++j) {
-                        sA[j] += my * (mxl[j] * vA[j] + vA[j + 1] + mxr[j] * vA[j + 2]);
-                        sB[j] += my * (mxl[j] * vB[j] + vB[j + 1] + mxr[j] * vB[j + 2]);
-                        sG[j] += my * (mxl[j] * vG[j] + vG[j + 1] + mxr[j] * vG[j + 2]);
+                        // reflect-pad multiplicity: neighbour column 0 seen twice from column 1, ...
+                        const float ml = (x0 + j == 1) ? 2.0f : 1.0f;
+                        const float mr = (x0 + j == W - 2) ? 2.0f : 1.0f;
+                        sA[j] += my * (ml * vA[j] + vA[j + 1] + mr * vA[j + 2]);
+                        sB[j] += my * (ml * vB[j] + vB[j + 1] + mr * vB[j + 2]);
+                        sG[j] += my * (ml * vG[j] + vG[j + 1] + mr * vG[j + 2]);
                     }
                 }
 #pragma unroll
@@ -611,33 +655,48 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
             __syncthreads();   // coefficient planes free for the next channel
         }
 
-        // ---- consume gw for this source
+        // ---- consume grad_warped of this source
+        if (!FUSED) {
 #pragma unroll
-        for (int q = 0; q < 12; ++q) accP[q] = 0.0f;
+            for (int j = 0; j < PX; ++j) {
+                const int x = x0 + j, col = seg * PX + j;
+                const bool outp = row_out && (col >= 1) && (col <= OW) && (x >= 0) && (x < W);
+                if (!outp) continue;
+                const size_t pi = (size_t)y * W + x;
 #pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            const int x = x0 + j;
-            const int col = seg * PX + j;
-            const bool outp = row_out && (col >= 1) && (col <= OW) && (x >= 0) && (x < W);
-            if (!outp) continue;
-            const size_t pi = (size_t)y * W + x;
-            if (FUSED) {
-                float P[12];
-                load_pose_regs(sh, k, P);
-                const float *sp = a.src.p[k] + (size_t)b * 3 * N;
+                for (int c = 0; c < 3; ++c) a.g_warped.p[k][((size_t)b * 3 + c) * N + pi] = gw[c][j];
+            }
+        } else {
+            // park grad_warped in the (now free) coefficient planes, then walk this lane's
+            // pixels one at a time through the projection adjoint (keeps the live set small)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                *reinterpret_cast<float4 *>(coefP + c * RPLANE + roff) =
+                    make_float4(gw[c][0], gw[c][1], gw[c][2], gw[c][3]);
+            float P[12];
+            load_pose_regs(sh, k, P);
+            const float *sp = a.src.p[k] + (size_t)b * 3 * N;
+            float accP[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) accP[q] = 0.0f;
+#pragma unroll 1
+            for (int j = 0; j < PX; ++j) {
+                const int x = x0 + j, col = seg * PX + j;
+                const bool outp = row_out && (col >= 1) && (col <= OW) && (x >= 0) && (x < W);
+                if (!outp) continue;
+                const float g0 = coefP[roff + j], g1 = coefP[RPLANE + roff + j],
+                            g2 = coefP[2 * RPLANE + roff + j];
                 WarpPoint w = warp_point(dispP[(row + 1) * LDW + col + 1], a.invK + b * 16, P, x, y,
                                          H, W, a.min_disp, a.range, a.eps);
-                float gix = 0.0f, giy = 0.0f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float dx, dy;
-                    bilerp_grad(sp + (size_t)c * N, W, w.t, dx, dy);
-                    gix += gw[c][j] * dx;
-                    giy += gw[c][j] * dy;
-                }
+                float dx0, dy0, dx1, dy1, dx2, dy2;
+                bilerp_grad(sp, W, w.t, dx0, dy0);
+                bilerp_grad(sp + N, W, w.t, dx1, dy1);
+                bilerp_grad(sp + 2 * N, W, w.t, dx2, dy2);
+                float gix = g0 * dx0 + g1 * dx1 + g2 * dx2;
+                float giy = g0 * dy0 + g1 * dy1 + g2 * dy2;
                 float gc[3];
                 float gd = warp_point_bwd(w, P, gix, giy, H, W, gc);
-                gdisp[j] += -gd * w.depth * w.depth * a.range;
+                gdP[roff + j] += -gd * w.depth * w.depth * a.range;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     accP[q * 4 + 0] += gc[q] * w.X[0];
@@ -645,12 +704,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
                     accP[q * 4 + 2] += gc[q] * w.X[2];
                     accP[q * 4 + 3] += gc[q];
                 }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) a.g_warped.p[k][((size_t)b * 3 + c) * N + pi] = gw[c][j];
             }
-        }
-        if (FUSED) {
             // per-tile partial of grad_P for source k: ws[((k*B + b)*ntiles + tile)*12 + q]
             const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
             float *part = a.ws + ((((size_t)k * a.B + b) * ntiles) +
@@ -673,7 +727,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
         // d/d disp_j of scale*smooth(disp/den): gn_j/den - (sum_i gn_i d_i)/(den^2 N); the sum is
         // den*scale*smooth_b because the per-image term is positively homogeneous of degree 1
         const float corr = scale * smooth_b / (float)N;
-#pragma unroll
+#pragma unroll 1
         for (int j = 0; j < PX; ++j) {
             const int x = x0 + j;
             const int col = seg * PX + j;
@@ -684,8 +738,8 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
             float nd = dc[0] / den;
             float gn = 0.0f;
             auto wgt = [&](int o) {
-                float gi = ((fabsf(t0[0] - t0[o]) + fabsf(t0[PLANE] - t0[PLANE + o])) +
-                            fabsf(t0[2 * PLANE] - t0[2 * PLANE + o])) / 3.0f;
+                float gi = div3((fabsf(t0[0] - t0[o]) + fabsf(t0[PLANE] - t0[PLANE + o])) +
+                                fabsf(t0[2 * PLANE] - t0[2 * PLANE + o]));
                 return expf(-gi);
             };
             auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
@@ -693,7 +747,7 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
             if (x - 1 >= 0) gn -= cx * wgt(-1) * sgn(dc[-1] / den - nd);
             if (y + 1 < H) gn += cy * wgt(LDW) * sgn(nd - dc[LDW] / den);
             if (y - 1 >= 0) gn -= cy * wgt(-LDW) * sgn(dc[-LDW] / den - nd);
-            a.g_disp[(size_t)b * N + (size_t)y * W + x] = gdisp[j] + gn / den - corr / den;
+            a.g_disp[(size_t)b * N + (size_t)y * W + x] = gdP[roff + j] + gn / den - corr / den;
         }
     }
 }
@@ -724,7 +778,7 @@ __global__ void __launch_bounds__(256) k_ssim_fwd(const float *__restrict__ x,
             sxy = sxy + a * bq;
         }
     }
-    Win w = {sx / 9.0f, sy / 9.0f, sxx / 9.0f, syy / 9.0f, sxy / 9.0f};
+    Win w = {div9(sx), div9(sy), div9(sxx), div9(syy), div9(sxy)};
     out[base + i] = clamp01(ssim_raw(w));
 }
 
@@ -746,7 +800,7 @@ MVF_DEV Win window_at(const float *__restrict__ x, const float *__restrict__ y, 
             sxy = sxy + a * bq;
         }
     }
-    Win w = {sx / 9.0f, sy / 9.0f, sxx / 9.0f, syy / 9.0f, sxy / 9.0f};
+    Win w = {div9(sx), div9(sy), div9(sxx), div9(syy), div9(sxy)};
     return w;
 }
 
@@ -808,11 +862,11 @@ __global__ void __launch_bounds__(256) k_reproj_fwd(const float *__restrict__ pr
             ss[c] = clamp01(ssim_raw(w));
         }
     }
-    float l1 = ((ab[0] + ab[1]) + ab[2]) / 3.0f;
+    float l1 = div3((ab[0] + ab[1]) + ab[2]);
     if (no_ssim) {
         out[(size_t)b * N + i] = l1;
     } else {
-        float sm = ((ss[0] + ss[1]) + ss[2]) / 3.0f;
+        float sm = div3((ss[0] + ss[1]) + ss[2]);
         out[(size_t)b * N + i] = 0.85f * sm + 0.15f * l1;
     }
 }
@@ -950,7 +1004,29 @@ __global__ void __launch_bounds__(256) k_smooth_bwd(const float *__restrict__ di
 inline size_t fwd_smem() { return (7 * PLANE) * sizeof(float) + sizeof(PoseLds) + 8 * sizeof(float); }
 inline size_t bwd_smem()
 {
-    return (7 * PLANE + 3 * TH * LDW) * sizeof(float) + sizeof(PoseLds) + 8 * sizeof(float);
+    return (7 * PLANE + 4 * RPLANE) * sizeof(float) + sizeof(PoseLds) + 8 * sizeof(float);
+}
+
+template <bool FUSED>
+void launch_fwd_kernel(const FwdArgs &a, dim3 grid, hipStream_t st)
+{
+    switch (a.S) {
+    case 1: hipLaunchKernelGGL((k_photo_fwd<FUSED, 1>), grid, dim3(NT), fwd_smem(), st, a); break;
+    case 2: hipLaunchKernelGGL((k_photo_fwd<FUSED, 2>), grid, dim3(NT), fwd_smem(), st, a); break;
+    case 3: hipLaunchKernelGGL((k_photo_fwd<FUSED, 3>), grid, dim3(NT), fwd_smem(), st, a); break;
+    default: hipLaunchKernelGGL((k_photo_fwd<FUSED, 4>), grid, dim3(NT), fwd_smem(), st, a); break;
+    }
+}
+
+template <bool FUSED>
+void launch_bwd_kernel(const BwdArgs &a, dim3 grid, hipStream_t st)
+{
+    switch (a.S) {
+    case 1: hipLaunchKernelGGL((k_photo_bwd<FUSED, 1>), grid, dim3(NT), bwd_smem(), st, a); break;
+    case 2: hipLaunchKernelGGL((k_photo_bwd<FUSED, 2>), grid, dim3(NT), bwd_smem(), st, a); break;
+    case 3: hipLaunchKernelGGL((k_photo_bwd<FUSED, 3>), grid, dim3(NT), bwd_smem(), st, a); break;
+    default: hipLaunchKernelGGL((k_photo_bwd<FUSED, 4>), grid, dim3(NT), bwd_smem(), st, a); break;
+    }
 }
 
 int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *stats, void *stream)
@@ -963,12 +1039,10 @@ int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *sta
     dim3 grid(a.tiles_x, a.tiles_y, a.B);
     {
         ProfScope ps(fused ? MVF_PROF_UNIT_FWD : MVF_PROF_PHOTO_FWD, st);
-        if (fused)
-            hipLaunchKernelGGL(k_photo_fwd<true>, grid, dim3(NT), fwd_smem(), st, a);
-        else
-            hipLaunchKernelGGL(k_photo_fwd<false>, grid, dim3(NT), fwd_smem(), st, a);
+        if (fused) launch_fwd_kernel<true>(a, grid, st);
+        else launch_fwd_kernel<false>(a, grid, st);
     }
-    hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(256), 0, st, a.ws, loss, stats, a.B, a.H, a.W,
+    hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(1024), 0, st, a.ws, loss, stats, a.B, a.H, a.W,
                        a.tiles_x * a.tiles_y, smoothness, 1);
     return hip_check_launch();
 }
@@ -1028,8 +1102,8 @@ int mvf_smooth_fwd(const float *disp, const float *img, float *out, float *stats
     hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, workspace, H * W);
     hipLaunchKernelGGL(k_smooth_fwd, dim3(nblk, B), dim3(256), 0, st, disp, img, workspace,
                        normalise, B, H, W);
-    hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(256), 0, st, workspace, out, stats, B, H, W, nblk,
-                       1.0f, 0);
+    hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(1024), 0, st, workspace, out, stats, B, H, W,
+                       nblk, 1.0f, 0);
     return hip_check_launch();
 }
 
@@ -1097,8 +1171,7 @@ int mvf_photo_bwd(const float *disp, const float *tgt, const float *const *warpe
     a.smoothness = smoothness;
     {
         ProfScope ps(MVF_PROF_PHOTO_BWD, (hipStream_t)stream);
-        hipLaunchKernelGGL(k_photo_bwd<false>, dim3(a.tiles_x, a.tiles_y, B), dim3(NT), bwd_smem(),
-                           (hipStream_t)stream, a);
+        launch_bwd_kernel<false>(a, dim3(a.tiles_x, a.tiles_y, B), (hipStream_t)stream);
     }
     return hip_check_launch();
 }
@@ -1121,8 +1194,7 @@ int mvf_unit_bwd(const float *disp, const float *tgt, const float *const *src, c
     a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
     {
         ProfScope ps(MVF_PROF_UNIT_BWD, (hipStream_t)stream);
-        hipLaunchKernelGGL(k_photo_bwd<true>, dim3(a.tiles_x, a.tiles_y, B), dim3(NT), bwd_smem(),
-                           (hipStream_t)stream, a);
+        launch_bwd_kernel<true>(a, dim3(a.tiles_x, a.tiles_y, B), (hipStream_t)stream);
     }
     return mvf_geom::finish_gT(workspace, K, g_T, B, S, a.tiles_x * a.tiles_y, stream);
 }
