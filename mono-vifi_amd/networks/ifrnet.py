@@ -1,0 +1,140 @@
+"""IFRNet video-frame-interpolation teacher (frozen, inference only in this trainer).
+
+Architecture, call signature and state-dict keys follow reference networks/IFRNet.py
+(``warp`` 7-15, encoders/decoders 160-349, ``IFRNet.forward`` 373-441) so the released
+``IFRNet_{L,S}_*.pth`` teacher weights load.  The VFI *training* losses of the reference
+(census / geometry / Charbonnier, IFRNet.py:18-126) belong to ``train_vfi.py`` and are out
+of scope: passing ``imgt`` raises.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def warp(img, flow):
+    """Backward-warp ``img`` by a pixel-unit flow field with the same bilinear / border /
+    align_corners=True gather the depth path uses (reference: IFRNet.py:7-15)."""
+    B, _, H, W = flow.shape
+    xs = torch.linspace(-1.0, 1.0, W, device=flow.device, dtype=flow.dtype).view(1, 1, 1, W)
+    ys = torch.linspace(-1.0, 1.0, H, device=flow.device, dtype=flow.dtype).view(1, 1, H, 1)
+    gx = xs + flow[:, 0:1] / ((W - 1.0) / 2.0)
+    gy = ys + flow[:, 1:2] / ((H - 1.0) / 2.0)
+    grid = torch.cat([gx, gy], 1).permute(0, 2, 3, 1)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
+
+
+def resize(x, scale_factor):
+    return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False)
+
+
+def convrelu(cin, cout, k=3, stride=1, pad=1):
+    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, pad), nn.PReLU(cout))
+
+
+class ResBlock(nn.Module):
+    """Five 3x3 convs; convs 2 and 4 act on the last ``side`` channels only."""
+
+    def __init__(self, ch, side):
+        super().__init__()
+        self.side_channels = side
+        self.conv1 = convrelu(ch, ch)
+        self.conv2 = convrelu(side, side)
+        self.conv3 = convrelu(ch, ch)
+        self.conv4 = convrelu(side, side)
+        self.conv5 = nn.Conv2d(ch, ch, 3, 1, 1)
+        self.prelu = nn.PReLU(ch)
+
+    def forward(self, x):
+        s = self.side_channels
+        out = self.conv1(x)
+        out = torch.cat([out[:, :-s], self.conv2(out[:, -s:])], 1)
+        out = self.conv3(out)
+        out = torch.cat([out[:, :-s], self.conv4(out[:, -s:])], 1)
+        return self.prelu(x + self.conv5(out))
+
+
+class Encoder(nn.Module):
+    def __init__(self, chans, first_kernel):
+        super().__init__()
+        c1, c2, c3, c4 = chans
+        k, p = first_kernel, first_kernel // 2
+        self.pyramid1 = nn.Sequential(convrelu(3, c1, k, 2, p), convrelu(c1, c1))
+        self.pyramid2 = nn.Sequential(convrelu(c1, c2, 3, 2, 1), convrelu(c2, c2))
+        self.pyramid3 = nn.Sequential(convrelu(c2, c3, 3, 2, 1), convrelu(c3, c3))
+        self.pyramid4 = nn.Sequential(convrelu(c3, c4, 3, 2, 1), convrelu(c4, c4))
+
+    def forward(self, img):
+        f1 = self.pyramid1(img)
+        f2 = self.pyramid2(f1)
+        f3 = self.pyramid3(f2)
+        f4 = self.pyramid4(f3)
+        return f1, f2, f3, f4
+
+
+class Decoder(nn.Module):
+    """convrelu -> ResBlock -> 4x4 stride-2 transposed conv."""
+
+    def __init__(self, cin, mid, side, cout, top=False):
+        super().__init__()
+        self.top = top
+        self.convblock = nn.Sequential(convrelu(cin, mid), ResBlock(mid, side),
+                                       nn.ConvTranspose2d(mid, cout, 4, 2, 1, bias=True))
+
+    def forward(self, *args):
+        if self.top:
+            f0, f1, embt = args
+            _, _, h, w = f0.shape
+            return self.convblock(torch.cat([f0, f1, embt.repeat(1, 1, h, w)], 1))
+        ft_, f0, f1, up0, up1 = args
+        return self.convblock(torch.cat([ft_, warp(f0, up0), warp(f1, up1), up0, up1], 1))
+
+
+_SCALES = {
+    # encoder channels, first kernel, side channels, decoder (cin, mid, cout) top..bottom
+    "large": ((64, 96, 144, 192), 7, 64, [(385, 384, 148), (436, 432, 100), (292, 288, 68), (196, 192, 8)]),
+    "small": ((24, 36, 54, 72), 3, 24, [(145, 144, 58), (166, 162, 40), (112, 108, 28), (76, 72, 8)]),
+}
+
+
+class IFRNet(nn.Module):
+    def __init__(self, scale="large"):
+        super().__init__()
+        chans, k, side, dec = _SCALES[scale]
+        self.encoder = Encoder(chans, k)
+        self.decoder4 = Decoder(dec[0][0], dec[0][1], side, dec[0][2], top=True)
+        self.decoder3 = Decoder(dec[1][0], dec[1][1], side, dec[1][2])
+        self.decoder2 = Decoder(dec[2][0], dec[2][1], side, dec[2][2])
+        self.decoder1 = Decoder(dec[3][0], dec[3][1], side, dec[3][2])
+
+    def forward(self, img0, img1, embt, imgt=None, scale_factor=(1.0, 0.5), onlyFlow=False):
+        if imgt is not None:
+            raise NotImplementedError("VFI training losses are out of scope (train_vfi.py)")
+        _, _, H, W = img0.shape
+        if H == 320 and W == 1024:
+            scale_factor = (0.6, 0.3125)
+        mean_ = torch.cat([img0, img1], 2).mean(1, keepdim=True).mean(2, keepdim=True).mean(3, keepdim=True)
+        img0 = img0 - mean_
+        img1 = img1 - mean_
+        fh, fw = int(H * scale_factor[0]), int(W * scale_factor[1])
+        f0 = self.encoder(F.interpolate(img0, size=(fh, fw), mode="bilinear", align_corners=False))
+        f1 = self.encoder(F.interpolate(img1, size=(fh, fw), mode="bilinear", align_corners=False))
+
+        out = self.decoder4(f0[3], f1[3], embt)
+        up0, up1, ft = out[:, 0:2], out[:, 2:4], out[:, 4:]
+        for dec, a, b in ((self.decoder3, f0[2], f1[2]), (self.decoder2, f0[1], f1[1]),
+                          (self.decoder1, f0[0], f1[0])):
+            out = dec(ft, a, b, up0, up1)
+            up0 = out[:, 0:2] + 2.0 * resize(up0, 2.0)
+            up1 = out[:, 2:4] + 2.0 * resize(up1, 2.0)
+            ft = out[:, 4:]
+        mask = torch.sigmoid(out[:, 4:5])
+
+        sx, sy = 1.0 / scale_factor[1], 1.0 / scale_factor[0]
+        scale = torch.tensor([sx, sy], device=up0.device, dtype=up0.dtype).view(1, 2, 1, 1)
+        up0 = F.interpolate(up0, size=(H, W), mode="bilinear", align_corners=False) * scale
+        up1 = F.interpolate(up1, size=(H, W), mode="bilinear", align_corners=False) * scale
+        mask = F.interpolate(mask, size=(H, W), mode="bilinear", align_corners=False)
+        if onlyFlow:
+            return up0, up1, mask
+        merged = mask * warp(img0, up0) + (1 - mask) * warp(img1, up1)
+        return torch.clamp(merged + mean_, 0, 1), up0, up1, mask

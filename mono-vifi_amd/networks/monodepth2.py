@@ -1,0 +1,66 @@
+"""Monodepth2-style depth network: ResNet encoder + U-Net decoder.
+
+API and state-dict keys follow reference networks/monodepth2.py (``DepthEncoder`` 11-45,
+``DepthDecoder`` 48-96): encoder parameters live under ``encoder.*``, decoder blocks under
+``decoder.<n>.conv.conv.*`` in the order upconv(4,0), upconv(4,1), ..., upconv(0,1),
+dispconv(s).  Plain PyTorch-ROCm modules: the convolutions are MIOpen / hipBLASLt GEMMs
+(MFMA for the genuine dense contractions); nothing here is hand-written.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..layers import Conv3x3, ConvBlock, upsample
+from .resnet import ResNetTrunk, pyramid_features
+
+
+class DepthEncoder(nn.Module):
+    def __init__(self, num_layers, pretrained=False):
+        super().__init__()
+        self.num_ch_enc = np.array([64, 64, 128, 256, 512])
+        if num_layers > 34:
+            self.num_ch_enc[1:] *= 4
+        # `pretrained` ImageNet weights cannot be fetched (no network): random init
+        self.encoder = ResNetTrunk(num_layers, 1)
+
+    def forward(self, input_image):
+        self.features = pyramid_features(self.encoder, input_image)
+        return self.features
+
+
+class DepthDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.scales = list(scales)
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        blocks, self._index = [], {}
+        for i in range(4, -1, -1):
+            cin = int(num_ch_enc[-1]) if i == 4 else int(self.num_ch_dec[i + 1])
+            self._index[("upconv", i, 0)] = len(blocks)
+            blocks.append(ConvBlock(cin, int(self.num_ch_dec[i])))
+            cin = int(self.num_ch_dec[i]) + (int(num_ch_enc[i - 1]) if use_skips and i > 0 else 0)
+            self._index[("upconv", i, 1)] = len(blocks)
+            blocks.append(ConvBlock(cin, int(self.num_ch_dec[i])))
+        for s in self.scales:
+            self._index[("dispconv", s)] = len(blocks)
+            blocks.append(Conv3x3(int(self.num_ch_dec[s]), num_output_channels))
+        self.decoder = nn.ModuleList(blocks)
+        self.sigmoid = nn.Sigmoid()
+
+    def _blk(self, *key):
+        return self.decoder[self._index[key]]
+
+    def forward(self, input_features):
+        self.outputs = {}
+        x = input_features[-1]
+        for i in range(4, -1, -1):
+            x = upsample(self._blk("upconv", i, 0)(x))
+            if self.use_skips and i > 0:
+                x = torch.cat([x, input_features[i - 1]], 1)
+            x = self._blk("upconv", i, 1)(x)
+            if i in self.scales:
+                self.outputs[("disp", i)] = self.sigmoid(self._blk("dispconv", i)(x))
+        return self.outputs

@@ -1,0 +1,168 @@
+"""Command-line / config-file options of the trainer.
+
+Same flag names, types, defaults and choices as the reference (options.py:8-226; 49 flags),
+read from a ``key = value`` config file given with ``-c`` (the reference's
+``configs/**/*.txt`` parse unchanged) plus command-line overrides.  Two differences, both
+deliberate: parsing is a function call, not an import side effect
+(the reference runs ``parser.parse_args()`` at import, options.py:226), and rank / world
+size are also taken from the ``torchrun`` environment (``LOCAL_RANK`` / ``RANK`` /
+``WORLD_SIZE``) besides ``--local_rank``.
+
+Build-specific additions are grouped at the end (``--synthetic`` etc.): neither box has the
+KITTI data, the ImageNet / IFRNet weights, torchvision or TensorBoard.
+"""
+import argparse
+import os
+
+file_dir = os.path.dirname(__file__)
+
+
+def _str2bool(v):
+    if isinstance(v, bool):
+        return v
+    return str(v).strip().lower() in ("1", "true", "yes", "y", "on")
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description="Mono-ViFI options (MI355X build)")
+    p.add_argument("-c", "--config", default=None, help="config file path (key = value lines)")
+    p.add_argument("--local_rank", "--local-rank", dest="local_rank", default=0, type=int)
+    p.add_argument("--global_rank", default=0, type=int)
+    p.add_argument("--world_size", default=1, type=int)
+
+    # PATHS
+    p.add_argument("--data_path", type=str, default=os.path.join(file_dir, "kitti_data"))
+    p.add_argument("--data_path_pre", type=str, default=None)
+    p.add_argument("--log_dir", type=str, default=os.path.join(os.path.expanduser("~"), "tmp"))
+
+    # TRAINING options
+    p.add_argument("--exp_name", type=str, default="mdp")
+    p.add_argument("--split", type=str, default="eigen_zhou",
+                   choices=["eigen_zhou", "eigen_full", "odom", "benchmark"])
+    p.add_argument("--eval_split", type=str, default="eigen",
+                   choices=["eigen", "eigen_benchmark", "benchmark", "odom_9", "odom_10"])
+    p.add_argument("--num_layers", type=int, default=18, choices=[18, 34, 50, 101, 152])
+    p.add_argument("--dataset", type=str, default="kitti",
+                   choices=["kitti", "kitti_odom", "kitti_depth", "kitti_test", "nyuv2", "cityscapes"])
+    p.add_argument("--jpg", action="store_true")
+    p.add_argument("--height", type=int, default=192)
+    p.add_argument("--width", type=int, default=640)
+    p.add_argument("--disparity_smoothness", type=float, default=1e-3)
+    p.add_argument("--num_scales", type=int, default=1)
+    p.add_argument("--min_depth", type=float, default=0.1)
+    p.add_argument("--max_depth", type=float, default=100.0)
+    p.add_argument("--lamda", type=float, default=0.2)
+    p.add_argument("--use_stereo", action="store_true")
+    p.add_argument("--frame_ids", nargs="+", type=int, default=[0, -1, 1])
+
+    # OPTIMIZATION options
+    p.add_argument("--optimizer", type=str, default="adamw", choices=["adamw", "adam", "sgd"])
+    p.add_argument("--lr_sche_type", type=str, default="step", choices=["cos", "step"])
+    p.add_argument("--eta_min", type=float, default=5e-6)
+    p.add_argument("--batch_size", type=int, default=12)
+    p.add_argument("--learning_rate", default=0.0001, type=float)
+    p.add_argument("--decay_rate", type=float, default=0.1)
+    p.add_argument("--decay_step", type=int, nargs="+", default=[15])
+    p.add_argument("--weight_decay", type=float, default=0.01)
+    p.add_argument("--beta1", type=float, default=0.9)
+    p.add_argument("--beta2", type=float, default=0.999)
+    p.add_argument("--momentum", default=0.9, type=float)
+    p.add_argument("--clip_grad", type=float, default=5)
+    p.add_argument("--num_epochs", type=int, default=20)
+    p.add_argument("--seed", type=int, default=1234)
+    p.add_argument("--resume", action="store_true")
+
+    # ABLATION options
+    p.add_argument("--avg_reprojection", action="store_true")
+    p.add_argument("--disable_automasking", action="store_true")
+    p.add_argument("--no_ssim", action="store_true")
+    p.add_argument("--weights_init", type=str, default="pretrained", choices=["pretrained", "scratch"])
+    p.add_argument("--backbone", type=str, default="ResNet18",
+                   choices=["ResNet18", "ResNet50", "LiteMono", "DHRNet"])
+    p.add_argument("--vfi_scale", type=str, default="small", choices=["large", "small"])
+    p.add_argument("--fuse_model_type", type=str, default="shared_encoder",
+                   choices=["shared_encoder", "separate_all", "shared_all"])
+    p.add_argument("--use_affine", action="store_true")
+
+    # SYSTEM options
+    p.add_argument("--num_workers", type=int, default=16)
+    p.add_argument("--pretrained_path", type=str, default=None)
+    p.add_argument("--log_frequency", type=int, default=500)
+    p.add_argument("--save_frequency", type=int, default=500)
+
+    # ---- additions of this build
+    p.add_argument("--synthetic", type=_str2bool, default=True,
+                   help="KITTI-shaped synthetic triplets generated on the fly (no datasets here)")
+    p.add_argument("--synthetic_len", type=int, default=39810,
+                   help="virtual training-set length (KITTI eigen_zhou has 39,810 items)")
+    p.add_argument("--vfi_weights_dir", type=str, default="./weights",
+                   help="IFRNet_{L,S}_{KITTI,CS}.pth; random-init teacher when absent")
+    p.add_argument("--sync_bn", type=_str2bool, default=True,
+                   help="SyncBatchNorm under world_size > 1 (reference: train.py:207)")
+    p.add_argument("--fused_units", type=_str2bool, default=True,
+                   help="fused unit kernels (warped images in LDS) instead of the staged "
+                        "generate_images_pred + compute_losses_base pair")
+    p.add_argument("--bucket_mb", type=float, default=32.0, help="gradient all-reduce bucket size")
+    p.add_argument("--channels_last", type=_str2bool, default=False)
+    p.add_argument("--amp_bf16", type=_str2bool, default=False,
+                   help="bf16 autocast for the conv networks (the hot path stays fp32)")
+    return p
+
+
+_STORE_TRUE = None
+
+
+def read_config_file(path):
+    """``key = value`` lines ('#' comments); the reference's configs use this format
+    (e.g. configs/resnet18/ResNet18_KITTI_MR.txt:1-21)."""
+    items = []
+    with open(path) as f:
+        for raw in f:
+            line = raw.split("#", 1)[0].strip()
+            if not line:
+                continue
+            if "=" in line:
+                k, v = line.split("=", 1)
+            else:
+                k, v = line, "True"
+            items.append((k.strip().lstrip("-"), v.strip()))
+    return items
+
+
+def parse_args(argv=None):
+    parser = build_parser()
+    pre, _ = parser.parse_known_args(argv)
+    cfg_argv = []
+    if pre.config:
+        flags = {a.dest: a for a in parser._actions}
+        for k, v in read_config_file(pre.config):
+            act = flags.get(k)
+            if act is None:
+                raise SystemExit(f"unknown option '{k}' in {pre.config}")
+            if isinstance(act, argparse._StoreTrueAction):
+                if _str2bool(v):
+                    cfg_argv.append("--" + k)
+            elif act.nargs in ("+", "*"):
+                cfg_argv += ["--" + k] + v.replace("[", "").replace("]", "").replace(",", " ").split()
+            else:
+                cfg_argv += ["--" + k, v]
+    # command line wins over the file
+    opts = parser.parse_args(cfg_argv + list(argv if argv is not None else os.sys.argv[1:]))
+    # torchrun / torch.distributed.run environment (reference reads --local_rank only)
+    if "LOCAL_RANK" in os.environ:
+        opts.local_rank = int(os.environ["LOCAL_RANK"])
+    if "RANK" in os.environ:
+        opts.global_rank = int(os.environ["RANK"])
+    if "WORLD_SIZE" in os.environ:
+        opts.world_size = int(os.environ["WORLD_SIZE"])
+    return opts
+
+
+def default_options(**overrides):
+    """Options namespace with the reference's defaults (for tests and benchmarks)."""
+    opts = build_parser().parse_args([])
+    for k, v in overrides.items():
+        if not hasattr(opts, k):
+            raise AttributeError(k)
+        setattr(opts, k, v)
+    return opts

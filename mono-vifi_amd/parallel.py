@@ -1,0 +1,180 @@
+"""Data-parallel plumbing: one process per GPU, gradients averaged by RCCL over xGMI.
+
+The hot path shards by batch with no data-path collective; the one
+exchange step of an optimisation step is the gradient all-reduce.  Instead of wrapping
+each of the reference's seven sub-models in its own ``DistributedDataParallel``
+(reference: train.py:205-208 -- two wrappers around the SAME module when
+``fuse_model_type=shared_encoder``, ``find_unused_parameters=True`` for the dead ImageNet
+``fc``, a buffer broadcast on every one of ~32 forwards per step), one reducer owns all
+trainable parameters:
+
+* parameters are de-duplicated by identity and laid out, in reverse registration order
+  (the order backward produces them), in a few large flat fp32 buckets -- xGMI is
+  point-to-point, so fewer / larger collectives win (bucket default 32 MB);
+* ``param.grad`` is a *view* into its bucket, so there is no copy in or out;
+* a post-accumulate-grad hook counts arrivals; when a bucket is complete its
+  ``all_reduce`` is issued asynchronously (RCCL runs it on its own stream) and overlaps
+  the rest of backward; ``finish()`` waits, and also reduces buckets whose parameters got
+  no gradient this step (so every rank issues the same collectives -- no
+  ``find_unused_parameters`` graph walk);
+* works unchanged on ``gloo`` (CPU) -- that is how tests/test_parallel.py covers N > 1.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(opts, backend=None):
+    """Initialise the default process group from the torchrun environment (or the
+    reference's --local_rank / --world_size flags).  Returns (rank, world_size)."""
+    import os
+    if opts.world_size <= 1:
+        return 0, 1
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", opts.local_rank)
+        dist.init_process_group(backend=backend, init_method="env://",
+                                world_size=opts.world_size, rank=opts.global_rank, **kw)
+    return dist.get_rank(), dist.get_world_size()
+
+
+def unique_parameters(modules):
+    """Trainable parameters of an iterable of modules, de-duplicated by identity (the
+    reference appends the aliased encoder_mf parameters twice, train.py:198-200)."""
+    seen, out = set(), []
+    for m in modules:
+        for p in m.parameters():
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                out.append(p)
+    return out
+
+
+def unique_modules(models):
+    """name -> module with aliases removed (first name wins)."""
+    seen, out = set(), {}
+    for k, m in models.items():
+        if id(m) not in seen:
+            seen.add(id(m))
+            out[k] = m
+    return out
+
+
+@torch.no_grad()
+def broadcast_module_states(modules, src=0):
+    """Make every rank start from rank ``src``'s parameters and buffers."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors, seen = [], set()
+    for m in modules:
+        for t in list(m.parameters()) + list(m.buffers()):
+            if id(t) not in seen and t.is_floating_point():
+                seen.add(id(t))
+                tensors.append(t)
+    by_dev = {}
+    for t in tensors:
+        by_dev.setdefault((t.device, t.dtype), []).append(t)
+    for group in by_dev.values():
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.broadcast(flat, src)
+        off = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+class _Bucket:
+    __slots__ = ("buf", "params", "pending", "handle", "launched")
+
+    def __init__(self, buf, params):
+        self.buf, self.params = buf, params
+        self.pending, self.handle, self.launched = len(params), None, False
+
+
+class BucketedGradReducer:
+    """Flat-bucket gradient averaging overlapped with backward (see module docstring)."""
+
+    def __init__(self, params, world_size=None, bucket_mb=32.0, process_group=None):
+        self.group = process_group
+        self.world = world_size if world_size is not None else (
+            dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        self.params = list(params)
+        self.buckets = []
+        self._owner = {}
+        cap = max(int(bucket_mb * (1 << 20) // 4), 1)
+        cur, cur_n = [], 0
+        for p in reversed(self.params):          # backward order
+            if cur and (cur_n + p.numel() > cap or p.device != cur[0].device):
+                self._seal(cur)
+                cur, cur_n = [], 0
+            cur.append(p)
+            cur_n += p.numel()
+        if cur:
+            self._seal(cur)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _seal(self, params):
+        n = sum(p.numel() for p in params)
+        buf = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        off = 0
+        for p in params:
+            p.grad = buf[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        b = _Bucket(buf, params)
+        for p in params:
+            self._owner[id(p)] = b
+        self.buckets.append(b)
+
+    # ---------------------------------------------------------------- step protocol
+    def zero_grad(self):
+        """Replaces optimizer.zero_grad(): keeps ``param.grad`` aliased to the buckets."""
+        for b in self.buckets:
+            b.buf.zero_()
+            b.pending, b.handle, b.launched = len(b.params), None, False
+            off = 0
+            for p in b.params:      # re-alias if something replaced .grad (set_to_none etc.)
+                if p.grad is None or p.grad.data_ptr() != b.buf.data_ptr() + 4 * off:
+                    p.grad = b.buf[off:off + p.numel()].view_as(p)
+                off += p.numel()
+
+    def _launch(self, b):
+        b.launched = True
+        if self.world > 1:
+            b.buf.div_(self.world)
+            b.handle = dist.all_reduce(b.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self._owner[id(p)]
+        b.pending -= 1
+        if b.pending == 0 and not b.launched:
+            self._launch(b)
+
+    def finish(self):
+        """Call after ``loss.backward()``: reduces the buckets that never filled (unused
+        parameters) and waits for every collective."""
+        for b in self.buckets:
+            if not b.launched:
+                self._launch(b)
+        for b in self.buckets:
+            if b.handle is not None:
+                b.handle.wait()
+                b.handle = None
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+
+    @property
+    def num_buckets(self):
+        return len(self.buckets)
+
+    @property
+    def total_bytes(self):
+        return sum(b.buf.numel() for b in self.buckets) * 4

@@ -1,0 +1,577 @@
+"""Drop-in ``Trainer`` for Mono-ViFI on MI355X.
+
+Keeps the reference's ``Trainer`` surface (reference: train.py:27-1176) -- constructor
+from an options namespace, ``train() / run_epoch() / process_batch() / predict_poses() /
+generate_images_pred() / compute_reprojection_loss() / compute_losses_base() /
+compute_SI_log_depth_loss() / compute_depth_consistency_loss_affine() / affine_transform()
+/ save_model() / load_ckpt() / load_pretrained_model()`` and the checkpoint file format --
+while the view-synthesis + photometric hot path runs in the hand-written gfx950 kernels
+(``losses.HotPathLosses``) and the data-parallel exchange is one bucketed RCCL all-reduce
+overlapped with backward (``parallel.BucketedGradReducer``).
+
+Known reference quirks that are fixed rather than replicated:
+``checkpoint`` is initialised to ``None``; the aliased ``encoder_mf`` parameters are
+trained once; the dead ImageNet ``fc`` head is gone; the per-sample Python loops with five
+``.item()`` host syncs each in the affine branch (train.py:891-896, 906-911) are batched
+tensor ops; the per-step ``dist.barrier()`` (train.py:692-693) is dropped.  The per-epoch
+accuracy evaluation (train.py:291-301) needs KITTI ground truth and is skipped.
+"""
+from __future__ import annotations
+
+import copy
+import json
+import logging
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.data import DataLoader
+
+from . import datasets, parallel
+from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
+from .losses import HotPathLosses
+from .networks import FusionModule, IFRNet, monodepth2, posenet
+
+
+def setup_logging(log_file=None, filemode="w", rank=0):
+    level = logging.INFO if rank == 0 else logging.WARNING
+    handlers = [logging.StreamHandler()]
+    if log_file and rank == 0:
+        handlers.append(logging.FileHandler(log_file, mode=filemode))
+    logging.basicConfig(level=level, format="%(asctime)s %(message)s", handlers=handlers, force=True)
+
+
+def sec_to_hm_str(t):
+    t = int(t)
+    return "{:02d}h{:02d}m{:02d}s".format(t // 3600, (t % 3600) // 60, t % 60)
+
+
+# --------------------------------------------------------------------------- batched affine ops
+def rotate_bilinear(img, angle_deg):
+    """Rotate every image of a batch counter-clockwise by its own angle about the centre,
+    bilinear, zero fill -- torchvision ``functional.rotate(img, angle, interpolation=2)``
+    semantics (inverse-mapped pixel-centre grid, ``align_corners=False``), which the
+    reference calls once per sample (train.py:898, 915).  torchvision is absent on both
+    boxes, so this restatement is parity-unpinned."""
+    B, _, H, W = img.shape
+    a = angle_deg.reshape(B).to(img.dtype) * (math.pi / 180.0)
+    cos, sin = torch.cos(a).view(B, 1, 1), torch.sin(a).view(B, 1, 1)
+    xs = torch.arange(W, device=img.device, dtype=img.dtype).view(1, 1, W) + 0.5 - W / 2.0
+    ys = torch.arange(H, device=img.device, dtype=img.dtype).view(1, H, 1) + 0.5 - H / 2.0
+    sx = (cos * xs - sin * ys) / (0.5 * W)
+    sy = (sin * xs + cos * ys) / (0.5 * H)
+    grid = torch.stack([sx, sy], -1)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+def _box_fields(box, dtype):
+    b = box.to(dtype)
+    return b[:, 0].view(-1, 1, 1), b[:, 1].view(-1, 1, 1), b[:, 2].view(-1, 1, 1), b[:, 3].view(-1, 1, 1)
+
+
+def crop_resize_bilinear(img, box):
+    """img[b, :, y0:y0+h, x0:x0+w] resized to the full [H,W] (bilinear,
+    align_corners=False) for a per-sample integer box (x0,y0,w,h) -- batched form of
+    train.py:899-900."""
+    B, _, H, W = img.shape
+    x0, y0, w, h = _box_fields(box, img.dtype)
+    j = torch.arange(W, device=img.device, dtype=img.dtype).view(1, 1, W)
+    i = torch.arange(H, device=img.device, dtype=img.dtype).view(1, H, 1)
+    sx = x0 + torch.minimum(torch.clamp((j + 0.5) * (w / W) - 0.5, min=0.0), w - 1)
+    sy = y0 + torch.minimum(torch.clamp((i + 0.5) * (h / H) - 0.5, min=0.0), h - 1)
+    grid = torch.stack([(2 * sx / (W - 1) - 1).expand(B, H, W), (2 * sy / (H - 1) - 1).expand(B, H, W)], -1)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
+
+
+def paste_resized(img, box):
+    """Zeros canvas [H,W] holding ``img`` resized to (h,w) at (x0,y0) -- batched form of
+    train.py:912-914."""
+    B, _, H, W = img.shape
+    x0, y0, w, h = _box_fields(box, img.dtype)
+    X = torch.arange(W, device=img.device, dtype=img.dtype).view(1, 1, W)
+    Y = torch.arange(H, device=img.device, dtype=img.dtype).view(1, H, 1)
+    inside = ((X >= x0) & (X < x0 + w) & (Y >= y0) & (Y < y0 + h)).unsqueeze(1).to(img.dtype)
+    sx = torch.clamp((X - x0 + 0.5) * (W / w) - 0.5, 0.0, W - 1.0)
+    sy = torch.clamp((Y - y0 + 0.5) * (H / h) - 0.5, 0.0, H - 1.0)
+    grid = torch.stack([(2 * sx / (W - 1) - 1).expand(B, H, W), (2 * sy / (H - 1) - 1).expand(B, H, W)], -1)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True) * inside
+
+
+class Trainer(HotPathLosses):
+    def __init__(self, options):
+        self.opt = options
+        o = self.opt
+        self.log_path = os.path.join(o.log_dir, o.exp_name)
+        if o.global_rank == 0:
+            os.makedirs(self.log_path, exist_ok=True)
+            self.save_opts()
+            resume_log = os.path.exists(os.path.join(self.log_path, "ckpt.pth"))
+            setup_logging(os.path.join(self.log_path, "logger.log"), "a" if resume_log else "w",
+                          rank=o.global_rank)
+            logging.info("Experiment is named: %s", o.exp_name)
+            logging.info("GPU numbers: %d", o.world_size)
+        else:
+            setup_logging(rank=o.global_rank)
+
+        self.device = torch.device("cuda", o.local_rank) if torch.cuda.is_available() \
+            else torch.device("cpu")
+        if o.seed > 0:
+            self.set_seed(o.seed)
+
+        assert o.height % 32 == 0, "'height' must be a multiple of 32"
+        assert o.width % 32 == 0, "'width' must be a multiple of 32"
+        assert o.frame_ids[0] == 0, "frame_ids must start with 0"
+
+        self.models = {}
+        self.num_input_frames = len(o.frame_ids)
+        self.num_pose_frames = 2
+        self.ep_start = 0
+        self.batch_start = 0
+        self.step = 0
+        self.epoch = 0
+        self.use_pose_net = not (o.use_stereo and o.frame_ids == [0])
+
+        # ---- data (synthetic: no datasets on either box)
+        if not o.synthetic:
+            raise NotImplementedError(
+                "only --synthetic True is available: the KITTI/Cityscapes loaders of the "
+                "reference need data and libraries neither box has (DESIGN.md section 9)")
+        train_dataset = datasets.SyntheticTripletDataset(o.height, o.width, o.synthetic_len,
+                                                         o.use_affine, o.seed)
+        self.num_steps_per_epoch = len(train_dataset) // o.world_size // o.batch_size
+        self.num_total_steps = self.num_steps_per_epoch * o.num_epochs
+        if o.world_size > 1:
+            self.sampler = datasets.CustomDistributedSampler(train_dataset, o.seed, o.world_size,
+                                                             o.global_rank)
+        else:
+            self.sampler = datasets.CustomSampler(train_dataset, o.seed)
+        self.train_loader = DataLoader(train_dataset, o.batch_size, shuffle=False,
+                                       sampler=self.sampler, num_workers=o.num_workers,
+                                       pin_memory=torch.cuda.is_available(), drop_last=True)
+
+        # ---- models (reference: train.py:140-190)
+        if o.backbone in ("ResNet18", "ResNet50"):
+            layers_n = 18 if o.backbone == "ResNet18" else 50
+            self.models["encoder"] = monodepth2.DepthEncoder(layers_n, o.weights_init == "pretrained")
+            self.models["depth"] = monodepth2.DepthDecoder(self.models["encoder"].num_ch_enc,
+                                                           range(o.num_scales))
+        else:
+            raise NotImplementedError(
+                f"backbone {o.backbone}: DHRNet / LiteMono are the next rows (SURVEY.md section 8f)")
+        if o.fuse_model_type == "shared_all":
+            self.models["encoder_mf"] = self.models["encoder"]
+            self.models["depth_mf"] = self.models["depth"]
+        elif o.fuse_model_type == "shared_encoder":
+            self.models["encoder_mf"] = self.models["encoder"]
+            self.models["depth_mf"] = copy.deepcopy(self.models["depth"])
+        else:
+            self.models["encoder_mf"] = copy.deepcopy(self.models["encoder"])
+            self.models["depth_mf"] = copy.deepcopy(self.models["depth"])
+        self.models["fusion_module"] = FusionModule(o, self.models["encoder_mf"].num_ch_enc)
+        if self.use_pose_net:
+            self.models["pose_encoder"] = posenet.ResnetEncoder(
+                o.num_layers, o.weights_init == "pretrained", num_input_images=self.num_pose_frames)
+            self.models["pose"] = posenet.PoseDecoder(self.models["pose_encoder"].num_ch_enc,
+                                                      num_input_features=1, num_frames_to_predict_for=2)
+
+        if o.pretrained_path and (not o.resume or not os.path.exists(os.path.join(self.log_path, "ckpt.pth"))):
+            self.load_pretrained_model()
+
+        self._modules_unique = parallel.unique_modules(self.models)
+        for m in self._modules_unique.values():
+            m.to(self.device)
+            if o.channels_last:
+                m.to(memory_format=torch.channels_last)
+        self.parameters_to_train = parallel.unique_parameters(self._modules_unique.values())
+
+        checkpoint = self.load_ckpt() if o.resume else None
+
+        if o.world_size > 1:
+            if o.sync_bn and self.device.type == "cuda":
+                for k in list(self._modules_unique):
+                    conv = nn.SyncBatchNorm.convert_sync_batchnorm(self._modules_unique[k])
+                    for name, m in self.models.items():
+                        if m is self._modules_unique[k]:
+                            self.models[name] = conv
+                    self._modules_unique[k] = conv
+                self.parameters_to_train = parallel.unique_parameters(self._modules_unique.values())
+            parallel.broadcast_module_states(self._modules_unique.values(), src=0)
+
+        # ---- frozen VFI teacher (reference: train.py:210-227)
+        self.model_vfi_train = IFRNet(scale="large")
+        self.model_vfi_test = IFRNet(scale="small")
+        tag = {"kitti": "KITTI", "cityscapes": "CS"}.get(o.dataset)
+        for net, sz in ((self.model_vfi_train, "L"), (self.model_vfi_test, "S")):
+            path = os.path.join(o.vfi_weights_dir, f"IFRNet_{sz}_{tag}.pth") if tag else None
+            if path and os.path.exists(path):
+                net.load_state_dict(torch.load(path, map_location="cpu")["VFI"])
+            else:
+                logging.info("IFRNet_%s weights not found: random-init teacher (synthetic run)", sz)
+            net.to(self.device).eval()
+            for p in net.parameters():
+                p.requires_grad_(False)
+        if o.world_size > 1:
+            parallel.broadcast_module_states([self.model_vfi_train, self.model_vfi_test], src=0)
+
+        # ---- optimiser (reference: train.py:229-246)
+        if o.optimizer == "adamw":
+            self.model_optimizer = torch.optim.AdamW(self.parameters_to_train, lr=o.learning_rate,
+                                                     betas=(o.beta1, o.beta2), weight_decay=o.weight_decay)
+        elif o.optimizer == "adam":
+            self.model_optimizer = torch.optim.Adam(self.parameters_to_train, lr=o.learning_rate,
+                                                    betas=(o.beta1, o.beta2))
+        else:
+            self.model_optimizer = torch.optim.SGD(self.parameters_to_train, lr=o.learning_rate,
+                                                   momentum=o.momentum)
+        if o.lr_sche_type == "cos":
+            self.model_lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(
+                self.model_optimizer, T_max=max(self.num_total_steps, 1), eta_min=o.eta_min)
+        else:
+            self.model_lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(
+                self.model_optimizer, o.decay_step, o.decay_rate)
+        if checkpoint:
+            self.model_optimizer.load_state_dict(checkpoint["optimizer"])
+            self.model_lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
+            del checkpoint
+
+        self.reducer = parallel.BucketedGradReducer(self.parameters_to_train, o.world_size,
+                                                    o.bucket_mb)
+
+        # ---- hot-path modules (reference: train.py:248-256)
+        if not o.no_ssim:
+            self.ssim = SSIM().to(self.device)
+        self.backproject_depth = BackprojectDepth(o.batch_size, o.height, o.width).to(self.device)
+        self.project_3d = Project3D(o.batch_size, o.height, o.width).to(self.device)
+
+        logging.info("There are %d training items (synthetic)", len(train_dataset))
+        if o.world_size > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------ misc
+    def set_seed(self, seed=1234):
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        if torch.cuda.is_available():
+            torch.cuda.manual_seed_all(seed)
+
+    def set_train(self):
+        for m in self.models.values():
+            m.train()
+
+    def set_eval(self):
+        for m in self.models.values():
+            m.eval()
+
+    def save_opts(self):
+        os.makedirs(os.path.join(self.log_path, "models"), exist_ok=True)
+        with open(os.path.join(self.log_path, "models", "opt.json"), "w") as f:
+            json.dump({k: v for k, v in vars(self.opt).items()}, f, indent=2, default=str)
+
+    # ------------------------------------------------------------------ loop
+    def train(self):
+        """Run the entire training pipeline (reference: train.py:284-303)."""
+        for self.epoch in range(self.ep_start, self.opt.num_epochs):
+            self.run_epoch()
+            if self.opt.lr_sche_type == "step":
+                self.model_lr_scheduler.step()
+            logging.info("per-epoch accuracy evaluation skipped: needs KITTI ground truth")
+            if self.opt.global_rank == 0:
+                self.save_model(ep_end=True)
+
+    def optimisation_step(self, inputs):
+        """process_batch -> backward (bucketed all-reduce overlapped) -> clip -> optimiser
+        step (reference: train.py:654-669)."""
+        _, losses = self.process_batch(inputs)
+        self.reducer.zero_grad()
+        losses["loss"].backward()
+        self.reducer.finish()
+        if self.opt.clip_grad != -1:
+            for group in self.model_optimizer.param_groups:
+                nn.utils.clip_grad_norm_(group["params"], max_norm=self.opt.clip_grad)
+        self.model_optimizer.step()
+        if self.opt.lr_sche_type == "cos":
+            self.model_lr_scheduler.step()
+        return losses
+
+    def run_epoch(self, max_steps=None):
+        logging.info("Training epoch %d\n", self.epoch)
+        self.sampler.set_epoch(self.epoch)
+        self.sampler.set_start_iter(self.batch_start * self.opt.batch_size)
+        self.set_train()
+        if self.opt.world_size > 1:
+            dist.barrier()
+        t_data = time.time()
+        for batch_idx, inputs in enumerate(self.train_loader):
+            self.step += 1
+            t_fp = time.time()
+            losses = self.optimisation_step(inputs)
+            idx = batch_idx + self.batch_start
+            if idx % self.opt.log_frequency == 0:
+                if self.opt.world_size > 1:
+                    stacked = torch.stack([losses[k].detach().float() for k in sorted(losses)])
+                    dist.all_reduce(stacked, op=dist.ReduceOp.SUM)
+                    stacked /= self.opt.world_size
+                    for i, k in enumerate(sorted(losses)):
+                        losses[k] = stacked[i]
+                if self.opt.global_rank == 0:
+                    if self.device.type == "cuda":
+                        torch.cuda.synchronize()
+                    self.log_time(idx, t_fp - t_data, time.time() - t_fp, float(losses["loss"]))
+                    self.log_tensorboard("train", losses)
+            if idx > 0 and idx % self.opt.save_frequency == 0 and self.opt.global_rank == 0:
+                self.save_model(batch_idx=idx + 1)
+            t_data = time.time()
+            if max_steps is not None and batch_idx + 1 >= max_steps:
+                break
+        self.batch_start = 0
+
+    # ------------------------------------------------------------------ one batch
+    def _nets(self, fn):
+        if self.opt.amp_bf16 and self.device.type == "cuda":
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                return fn()
+        return fn()
+
+    def _depth(self, decoder, feats):
+        """decoder -> {("disp",0): fp32 disparity} (the hot path computes in fp32)."""
+        out = self._nets(lambda: self.models[decoder](feats))
+        return {k: v.float() for k, v in out.items()}
+
+    def _encode(self, name, img):
+        if self.opt.channels_last:
+            img = img.contiguous(memory_format=torch.channels_last)
+        return self._nets(lambda: self.models[name](img))
+
+    def _unit(self, disp, tgt, poses, srcs, K, inv_K, mask_rec=None):
+        """One hot-path unit (reference: e.g. train.py:747-749)."""
+        if self.opt.fused_units:
+            loss, _ = self.compute_unit(disp, tgt, poses, srcs, K, inv_K, mask_rec)
+            return loss
+        warped = [self.generate_images_pred(disp, poses[k], srcs[k], K, inv_K) for k in range(len(srcs))]
+        loss, _ = self.compute_losses_base(disp, tgt, warped, srcs, mask_rec)
+        return loss
+
+    def _affine_pose(self, pose, Rc, Rc_inv):
+        """Pose of the affine-augmented view: [Rc R Rc^-1 | Rc t] (reference: train.py:820-823)."""
+        out = torch.zeros_like(pose)
+        out[:, :3, :3] = torch.matmul(Rc, torch.matmul(pose[:, :3, :3], Rc_inv))
+        out[:, :3, 3:4] = torch.matmul(Rc, pose[:, :3, 3:4])
+        return out
+
+    def process_batch(self, inputs):
+        """Pass a minibatch through the networks and the 9 hot-path units
+        (reference: train.py:698-886)."""
+        o = self.opt
+        for key, ipt in inputs.items():
+            if torch.is_tensor(ipt):
+                inputs[key] = ipt.to(self.device, non_blocking=True)
+        B = inputs[("color", 0, 0)].shape[0]
+        embt = torch.full((B, 1, 1, 1), 0.5, device=self.device)
+        img_n1, img_p1, img_0 = inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("color", 0, 0)]
+
+        with torch.no_grad():
+            img_nt, flow_nt_n1, flow_nt_0, merge_mask_nt = self._nets(
+                lambda: self.model_vfi_train(img_n1, img_0, embt))
+            img_pt, flow_pt_0, flow_pt_p1, merge_mask_pt = self._nets(
+                lambda: self.model_vfi_train(img_0, img_p1, embt))
+            flow_0_n1, flow_0_p1, merge_mask_01 = self._nets(
+                lambda: self.model_vfi_train(img_n1, img_p1, embt, onlyFlow=True))
+            img_nt, img_pt = img_nt.float(), img_pt.float()
+            flows = [t.float() for t in (flow_nt_n1, flow_nt_0, flow_pt_0, flow_pt_p1, flow_0_n1,
+                                         flow_0_p1, merge_mask_nt, merge_mask_pt, merge_mask_01)]
+            (flow_nt_n1, flow_nt_0, flow_pt_0, flow_pt_p1, flow_0_n1, flow_0_p1, merge_mask_nt,
+             merge_mask_pt, merge_mask_01) = flows
+
+        K, inv_K = inputs[("K", 0)], inputs[("inv_K", 0)]
+        losses = {"loss_base": torch.zeros((), device=self.device),
+                  "loss_dc": torch.zeros((), device=self.device)}
+
+        aug = lambda f: inputs[("color_aug", f, 0)]  # noqa: E731
+        pose_n1_0, pose_0_n1 = self.predict_poses(aug(-1), aug(0))
+        pose_0_p1, pose_p1_0 = self.predict_poses(aug(0), aug(1))
+        pose_n1_nt, pose_nt_n1 = self.predict_poses(img_n1, img_nt)
+        pose_nt_p1, pose_p1_nt = self.predict_poses(img_nt, img_p1)
+        pose_n1_pt, pose_pt_n1 = self.predict_poses(img_n1, img_pt)
+        pose_pt_p1, pose_p1_pt = self.predict_poses(img_pt, img_p1)
+
+        # ---- single-frame depths
+        feats_0 = self._encode("encoder", aug(0))
+        feats_nt = self._encode("encoder", img_nt)
+        feats_pt = self._encode("encoder", img_pt)
+        disp_0, disp_pt, disp_nt = (self._depth("depth", f) for f in (feats_0, feats_pt, feats_nt))
+        _, depth_0 = disp_to_depth(disp_0[("disp", 0)], o.min_depth, o.max_depth)
+        _, depth_pt = disp_to_depth(disp_pt[("disp", 0)], o.min_depth, o.max_depth)
+        _, depth_nt = disp_to_depth(disp_nt[("disp", 0)], o.min_depth, o.max_depth)
+
+        srcs = [img_n1, img_p1]
+        losses["loss_base"] = losses["loss_base"] + self._unit(disp_0, img_0, [pose_0_n1, pose_0_p1], srcs, K, inv_K)
+        losses["loss_base"] = losses["loss_base"] + self._unit(disp_pt, img_pt, [pose_pt_n1, pose_pt_p1], srcs, K, inv_K)
+        losses["loss_base"] = losses["loss_base"] + self._unit(disp_nt, img_nt, [pose_nt_n1, pose_nt_p1], srcs, K, inv_K)
+
+        # ---- multi-frame depths
+        if o.fuse_model_type == "separate_all":
+            feats_0 = self._encode("encoder_mf", aug(0))
+            feats_nt = self._encode("encoder_mf", img_nt)
+            feats_pt = self._encode("encoder_mf", img_pt)
+            feats_n1 = self._encode("encoder_mf", aug(-1))
+            feats_p1 = self._encode("encoder_mf", aug(1))
+        else:
+            feats_n1 = self._encode("encoder", aug(-1))
+            feats_p1 = self._encode("encoder", aug(1))
+
+        def fuse(feats, fl, mask):
+            f = self._nets(lambda: self.models["fusion_module"](
+                [[t.float() for t in lvl] for lvl in feats], fl, mask))
+            d = self._depth("depth_mf", f)
+            return d, disp_to_depth(d[("disp", 0)], o.min_depth, o.max_depth)[1]
+
+        disp_0_fuse, depth_0_fuse = fuse([feats_n1, feats_0, feats_p1], [flow_0_n1, flow_0_p1], merge_mask_01)
+        disp_nt_fuse, depth_nt_fuse = fuse([feats_n1, feats_nt, feats_0], [flow_nt_n1, flow_nt_0], merge_mask_nt)
+        disp_pt_fuse, depth_pt_fuse = fuse([feats_0, feats_pt, feats_p1], [flow_pt_0, flow_pt_p1], merge_mask_pt)
+
+        losses["loss_base"] = losses["loss_base"] + self._unit(disp_0_fuse, img_0, [pose_0_n1, pose_0_p1], srcs, K, inv_K)
+        losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_0, depth_0_fuse)
+        losses["loss_base"] = losses["loss_base"] + self._unit(disp_nt_fuse, img_nt, [pose_nt_n1, pose_nt_p1], srcs, K, inv_K)
+        losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_nt, depth_nt_fuse)
+        losses["loss_base"] = losses["loss_base"] + self._unit(disp_pt_fuse, img_pt, [pose_pt_n1, pose_pt_p1], srcs, K, inv_K)
+        losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_pt, depth_pt_fuse)
+
+        # ---- affine-augmentation losses
+        if o.use_affine:
+            Rc = inputs["Rc"]
+            Rc_inv = torch.inverse(Rc)
+            srcs_a = [inputs[("color_affine", -1, 0)], inputs[("color_affine", 1, 0)]]
+            mask_rec = inputs["valid_mask_rec"]
+            todo = (
+                (inputs[("color_affine_aug", 0, 0)], inputs[("color_affine", 0, 0)], pose_0_n1, pose_0_p1,
+                 depth_0, depth_0_fuse),
+                (None, img_nt, pose_nt_n1, pose_nt_p1, depth_nt, depth_nt_fuse),
+                (None, img_pt, pose_pt_n1, pose_pt_p1, depth_pt, depth_pt_fuse),
+            )
+            for net_in, tgt, pa, pb, depth_s, depth_f in todo:
+                if net_in is None:
+                    tgt = self.affine_transform(tgt, inputs)
+                    net_in = tgt
+                disp_a = self._depth("depth", self._encode("encoder", net_in))
+                _, depth_a = disp_to_depth(disp_a[("disp", 0)], o.min_depth, o.max_depth)
+                poses_a = [self._affine_pose(pa, Rc, Rc_inv), self._affine_pose(pb, Rc, Rc_inv)]
+                losses["loss_base"] = losses["loss_base"] + self._unit(disp_a, tgt, poses_a, srcs_a, K, inv_K, mask_rec)
+                losses["loss_dc"] = losses["loss_dc"] + self.compute_depth_consistency_loss_affine(
+                    depth_a, depth_s, depth_f, inputs)
+
+        losses["loss"] = losses["loss_base"] + o.lamda * losses["loss_dc"]
+        return None, losses
+
+    # ------------------------------------------------------------------ loss helpers
+    def affine_transform(self, img, inputs):
+        """Rotate, crop the box, resize back -- batched (reference: train.py:888-902)."""
+        rot = rotate_bilinear(img, inputs["angle"])
+        return crop_resize_bilinear(rot, inputs["box"])
+
+    def compute_depth_consistency_loss_affine(self, depth_affine, depth, depth_fuse, inputs):
+        """Scale-aware depth consistency (SADC), batched (reference: train.py:904-922)."""
+        restored = paste_resized(depth_affine, inputs["box"])
+        restored = rotate_bilinear(restored, -inputs["angle"])
+        restored = restored * inputs["ratio_local"].view(-1, 1, 1, 1)
+        mask = inputs["valid_mask_cons"]
+        return self.compute_SI_log_depth_loss(restored, depth_fuse, mask) + \
+            self.compute_SI_log_depth_loss(restored, depth, mask)
+
+    def compute_SI_log_depth_loss(self, pred, target, mask=None, beta=0.5):
+        """Scale-invariant log loss (reference: train.py:924-941)."""
+        if mask is None:
+            mask = torch.ones_like(pred)
+        mask = mask[:, 0]
+        log_diff = torch.log(pred[:, 0] + 1e-7) * mask - torch.log(target[:, 0] + 1e-7) * mask
+        valid = mask.sum(1).sum(1) + 1e-8
+        sq_sum = (log_diff ** 2).sum(1).sum(1)
+        sum_sq = log_diff.sum(1).sum(1) ** 2
+        return (sq_sum / valid - beta * sum_sq / (valid ** 2)).mean()
+
+    def predict_poses(self, img_0, img1):
+        """Pose between two frames, forward and inverted (reference: train.py:943-954)."""
+        feats = [self._encode("pose_encoder", torch.cat([img_0, img1], 1))]
+        axisangle, translation = self._nets(lambda: self.models["pose"]([[f.float() for f in feats[0]]]))
+        axisangle, translation = axisangle.float(), translation.float()
+        pose = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=False)
+        pose_inv = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=True)
+        return pose, pose_inv
+
+    # ------------------------------------------------------------------ logging / ckpt
+    def log_time(self, batch_idx, data_time, batch_time, loss):
+        left = (self.num_total_steps - self.step) * batch_time if self.step > 1 else 0
+        lr = self.model_optimizer.state_dict()["param_groups"][0]["lr"]
+        logging.info("epoch: %2d/%d | batch: %4d/%d | data time: %.4f | batch time: %.3f | loss: %.4f | "
+                     "lr: %.2e | time left: %s", self.epoch, self.opt.num_epochs - 1, batch_idx,
+                     self.num_steps_per_epoch, data_time, batch_time, loss, lr, sec_to_hm_str(left))
+
+    def log_tensorboard(self, mode, losses):
+        """Scalars as JSON lines (TensorBoard is absent on both boxes; reference: train.py:1062-1067)."""
+        with open(os.path.join(self.log_path, f"scalars_{mode}.jsonl"), "a") as f:
+            f.write(json.dumps({"step": self.step, **{k: float(v) for k, v in losses.items()}}) + "\n")
+
+    def _state_dicts(self):
+        return {name: m.state_dict() for name, m in self.models.items()}
+
+    def save_model(self, ep_end=False, batch_idx=0):
+        """Checkpoint in the reference's format (reference: train.py:1108-1136)."""
+        models_dir = os.path.join(self.log_path, "models")
+        os.makedirs(models_dir, exist_ok=True)
+        to_save = self._state_dicts()
+        to_save["height"], to_save["width"] = self.opt.height, self.opt.width
+        to_save["use_stereo"] = self.opt.use_stereo
+        if ep_end:
+            torch.save(to_save, os.path.join(models_dir, "model_{}.pth".format(self.epoch)))
+            to_save["epoch"] = self.epoch + 1
+        else:
+            to_save["epoch"] = self.epoch
+        to_save["step_in_total"] = self.step
+        to_save["batch_idx"] = batch_idx
+        to_save["optimizer"] = self.model_optimizer.state_dict()
+        to_save["lr_scheduler"] = self.model_lr_scheduler.state_dict()
+        torch.save(to_save, os.path.join(self.log_path, "ckpt.pth"))
+
+    def _load_into_models(self, checkpoint):
+        for name, model in self.models.items():
+            if name not in checkpoint:
+                continue
+            own = model.state_dict()
+            own.update({k: v for k, v in checkpoint[name].items() if k in own})
+            model.load_state_dict(own)
+
+    def load_ckpt(self):
+        """Resume (reference: train.py:1138-1159)."""
+        path = os.path.join(self.log_path, "ckpt.pth")
+        if not os.path.exists(path):
+            logging.info("No checkpoint to resume, train from epoch 0.")
+            return None
+        checkpoint = torch.load(path, map_location="cpu", weights_only=False)
+        self._load_into_models(checkpoint)
+        self.ep_start = checkpoint["epoch"]
+        self.batch_start = checkpoint["batch_idx"]
+        self.step = checkpoint["step_in_total"]
+        logging.info("Start at epoch %d, batch index %d", self.ep_start, self.batch_start)
+        return checkpoint
+
+    def load_pretrained_model(self):
+        """Initialise from a weights file (reference: train.py:1161-1176)."""
+        path = os.path.abspath(self.opt.pretrained_path)
+        assert os.path.exists(path), "Cannot find folder {}".format(path)
+        self._load_into_models(torch.load(path, map_location="cpu", weights_only=False))
+
+
+def main(argv=None):
+    """``python -m mono_vifi_amd.trainer -c configs/...txt`` (reference: train.py:1178-1185)."""
+    from .options import parse_args
+    opts = parse_args(argv)
+    parallel.init_distributed(opts)
+    Trainer(opts).train()
+
+
+if __name__ == "__main__":
+    main()

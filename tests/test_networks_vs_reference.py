@@ -1,0 +1,112 @@
+"""Network restatements vs the reference's own modules, weights copied across.
+
+Runs only where /root/reference exists (the build container); the reference never travels
+to the GPU box, so there these tests skip.  The ResNet trunks cannot be compared: the
+reference builds them from torchvision, which is absent ("parity
+unpinned"); everything importable is compared: DepthDecoder, PoseDecoder, FusionModule,
+IFRNet (large and small)."""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference not present on this box")
+
+
+@pytest.fixture(scope="module")
+def ref():
+    sys.dont_write_bytecode = True
+    saved_path, saved_mods = list(sys.path), dict(sys.modules)
+    sys.path.insert(0, REF)
+    tv = types.ModuleType("torchvision")
+    tv.models = types.ModuleType("torchvision.models")
+    tv.models.ResNet = torch.nn.Module
+    tv.models.resnet18 = tv.models.resnet34 = tv.models.resnet50 = None
+    tv.models.resnet101 = tv.models.resnet152 = None
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = tv.models
+    pkg = types.ModuleType("networks")
+    pkg.__path__ = [os.path.join(REF, "networks")]
+    sys.modules["networks"] = pkg
+    sys.modules.pop("layers", None)
+    mods = {n: importlib.import_module("networks." + n)
+            for n in ("IFRNet", "fusion_module", "monodepth2", "posenet")}
+    yield mods
+    sys.path[:] = saved_path
+    for k in list(sys.modules):
+        if k not in saved_mods:
+            del sys.modules[k]
+
+
+def _copy(dst, src):
+    sd, dd = src.state_dict(), dst.state_dict()
+    assert list(sd) == list(dd), "state-dict keys / order differ from the reference"
+    dst.load_state_dict(sd)
+
+
+def test_depth_decoder(ref):
+    from mono_vifi_amd.networks import monodepth2
+    ch = np.array([64, 64, 128, 256, 512])
+    torch.manual_seed(0)
+    theirs = ref["monodepth2"].DepthDecoder(ch, range(1))
+    ours = monodepth2.DepthDecoder(ch, range(1))
+    _copy(ours, theirs)
+    feats = [torch.randn(2, c, 32 // 2 ** i, 48 // 2 ** i) for i, c in enumerate(ch)]
+    a, b = theirs(feats)[("disp", 0)], ours(feats)[("disp", 0)]
+    assert torch.allclose(a, b, atol=1e-6)
+
+
+def test_pose_decoder(ref):
+    from mono_vifi_amd.networks import posenet
+    ch = np.array([64, 64, 128, 256, 512])
+    torch.manual_seed(1)
+    theirs = ref["posenet"].PoseDecoder(ch, 1, 2)
+    ours = posenet.PoseDecoder(ch, 1, 2)
+    _copy(ours, theirs)
+    feats = [[torch.randn(2, c, 6, 20) for c in ch]]
+    for x, y in zip(theirs(feats), ours(feats)):
+        assert torch.allclose(x, y, atol=1e-7)
+
+
+@pytest.mark.parametrize("scale", ["small", "large"])
+def test_ifrnet(ref, scale):
+    from mono_vifi_amd.networks import IFRNet
+    torch.manual_seed(2)
+    theirs = ref["IFRNet"].IFRNet(scale).eval()
+    ours = IFRNet(scale).eval()
+    _copy(ours, theirs)
+    img0, img1 = torch.rand(1, 3, 64, 128), torch.rand(1, 3, 64, 128)
+    embt = torch.full((1, 1, 1, 1), 0.5)
+    with torch.no_grad():
+        for x, y in zip(theirs(img0, img1, embt), ours(img0, img1, embt)):
+            assert torch.allclose(x, y, atol=2e-5), float((x - y).abs().max())
+        for x, y in zip(theirs(img0, img1, embt, onlyFlow=True), ours(img0, img1, embt, onlyFlow=True)):
+            assert torch.allclose(x, y, atol=2e-5)
+    f = torch.rand(1, 5, 16, 24)
+    fl = 3 * torch.randn(1, 2, 16, 24)
+    from mono_vifi_amd.networks.ifrnet import warp
+    assert torch.allclose(ref["IFRNet"].warp(f, fl), warp(f, fl), atol=1e-6)
+
+
+def test_fusion_module(ref):
+    from types import SimpleNamespace
+    from mono_vifi_amd.networks import FusionModule
+    ch = np.array([64, 64, 128, 256, 512])
+    args = SimpleNamespace(backbone="ResNet18")
+    torch.manual_seed(3)
+    theirs = ref["fusion_module"].FusionModule(args, ch)
+    ours = FusionModule(args, ch)
+    _copy(ours, theirs)
+    mk = lambda: [torch.randn(2, c, 32 // 2 ** i, 48 // 2 ** i) for i, c in enumerate(ch)]  # noqa: E731
+    feats = [mk(), mk(), mk()]
+    flows = [2 * torch.randn(2, 2, 64, 96), 2 * torch.randn(2, 2, 64, 96)]
+    mask = torch.rand(2, 1, 64, 96)
+    a = theirs([list(f) for f in feats], [fl.clone() for fl in flows], mask.clone())
+    b = ours(feats, flows, mask)
+    for x, y in zip(a, b):
+        assert torch.allclose(x, y, atol=1e-5), float((x - y).abs().max())
