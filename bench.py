@@ -55,6 +55,11 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--backbone", default="ResNet18")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--amp-bf16", dest="amp_bf16", action="store_true",
+                    help="bf16 autocast for the conv networks (reduced precision: not the default)")
+    ap.add_argument("--channels-last", dest="channels_last", action="store_true")
+    ap.add_argument("--miopen-find", dest="miopen_find", action="store_true",
+                    help="torch.backends.cudnn.benchmark=True (MIOpen exhaustive find in warm-up)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -64,13 +69,16 @@ def dist_setup(args):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.distributed.init_process_group(backend="nccl", init_method="env://",
-                                             world_size=world, rank=rank,
-                                             device_id=torch.device("cuda", local))
+        # RCCL ("nccl" on ROCm) over xGMI; MVF_DIST_BACKEND=gloo only for single-GPU dry runs
+        backend = os.environ.get("MVF_DIST_BACKEND", "nccl")
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        torch.distributed.init_process_group(backend=backend, init_method="env://",
+                                             world_size=world, rank=rank, **kw)
     if world != args.gpus and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     return world, rank, torch.device("cuda", local)
@@ -178,6 +186,7 @@ def main():
         workload = "train" if os.path.exists(os.path.join(ROOT, "mono-vifi_amd", "trainer.py")) \
             else "hotpath"
     if workload == "train":
+        torch.backends.cudnn.benchmark = bool(args.miopen_find)
         from mono_vifi_amd.bench_train import TrainStep
         step = TrainStep(args, rank, world, dev)
     else:

@@ -118,8 +118,8 @@ class Trainer(HotPathLosses):
         else:
             setup_logging(rank=o.global_rank)
 
-        self.device = torch.device("cuda", o.local_rank) if torch.cuda.is_available() \
-            else torch.device("cpu")
+        self.device = torch.device("cuda", o.local_rank % torch.cuda.device_count()) \
+            if torch.cuda.is_available() else torch.device("cpu")
         if o.seed > 0:
             self.set_seed(o.seed)
 
