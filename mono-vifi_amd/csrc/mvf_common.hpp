@@ -201,6 +201,36 @@ MVF_DEV float div3(float x)
     return fmaf(r, c, q);
 }
 
+// packed pairs: two IEEE fp32 operations per lane per instruction (v_pk_*_f32)
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+MVF_DEV f2 f2s(float a)
+{
+    f2 r = {a, a};
+    return r;
+}
+MVF_DEV f2 mk2(float a, float b)
+{
+    f2 r = {a, b};
+    return r;
+}
+MVF_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+MVF_DEV f2 pk_abs(f2 a) { return __builtin_elementwise_abs(a); }
+MVF_DEV f2 div9(f2 x)
+{
+    const f2 c = f2s(1.0f / 9.0f);
+    f2 q = x * c;
+    f2 r = pk_fma(f2s(-9.0f), q, x);
+    return pk_fma(r, c, q);
+}
+MVF_DEV f2 div3(f2 x)
+{
+    const f2 c = f2s(1.0f / 3.0f);
+    f2 q = x * c;
+    f2 r = pk_fma(f2s(-3.0f), q, x);
+    return pk_fma(r, c, q);
+}
+
 // ------------------------------------------------------------------------------- SSIM
 MVF_DEV int refl(int j, int n)
 {
@@ -292,6 +322,29 @@ MVF_DEV float block_sum(float v, float *scratch)
     if (threadIdx.x == 0) {
 #pragma unroll
         for (int i = 0; i < NW; ++i) r += scratch[i];
+    }
+    return r;
+}
+
+// sum NV per-lane values over the workgroup with TWO barriers in total: wave shuffles,
+// one LDS row per wave, then lane q < NV folds the waves.  Result for value q is returned
+// in lane q of the workgroup (threadIdx.x == q); `scratch` holds >= (NT/64)*NV floats.
+template <int NT, int NV>
+MVF_DEV float block_sum_many(const float (&v)[NV], float *scratch)
+{
+    constexpr int NW = NT / kWave;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        float s = wave_sum(v[q]);
+        if (lane == 0) scratch[wid * NV + q] = s;
+    }
+    __syncthreads();
+    float r = 0.0f;
+    if (threadIdx.x < NV) {
+#pragma unroll
+        for (int i = 0; i < NW; ++i) r += scratch[i * NV + threadIdx.x];
     }
     return r;
 }

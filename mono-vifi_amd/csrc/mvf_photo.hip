@@ -7,9 +7,10 @@
 // Tile engine.  A workgroup of 256 lanes owns a 64x16-pixel compute region.  Every image
 // plane it needs is staged once into LDS as an 18-row x 68-float plane (1-px reflect halo,
 // rows padded to a multiple of 16 B), and every lane then owns a 4-pixel row segment:
-// its 3x3 windows are three `ds_read_b128 + ds_read_b64` per plane (18 floats for 4
-// pixels instead of 36 scalar reads), and global traffic is the coalesced plane staging
-// plus the L2-served bilinear taps.
+// its 3x3 windows are a few wide LDS reads per plane (18 values for 4 pixels instead of 36
+// scalar reads), candidates are evaluated two at a time with packed fp32 math (see "packed
+// fp32 pairs" below), and global traffic is the coalesced plane staging plus the L2-served
+// bilinear taps.
 //   forward : region = output tile (grid steps 64x16)
 //   backward: region = where the SSIM adjoint coefficients are formed; outputs are its
 //             62x14 interior (grid steps 62x14), so the 3x3 adjoint gather never leaves
@@ -92,6 +93,16 @@ MVF_DEV void stage_planes3(float *__restrict__ lds, const float *__restrict__ im
     }
 }
 
+// ---- packed fp32 pairs -----------------------------------------------------------------
+// gfx950 VALU executes v_pk_{add,mul,fma}_f32: two IEEE fp32 operations per lane per
+// instruction.  The tile kernels evaluate candidates TWO AT A TIME (e.g. the two warped
+// sources, then the two identity sources): the pair is stored interleaved in LDS as
+// float2, so one ds_read_b128 feeds both, every window add / product / formula step is one
+// packed instruction for both candidates, and no register shuffles are needed.  Each lane
+// of a packed op is the same IEEE operation as the scalar form, so exact mode is unchanged.
+constexpr int PPLANE = PH * LDW;   // f2 elements per staged pair plane
+constexpr int RPPLANE = TH * LDW;  // f2 elements per region-sized pair plane
+
 // 6 consecutive floats of an LDS plane row, starting at a 16-B aligned column
 struct Row6 {
     float v[6];
@@ -104,25 +115,43 @@ MVF_DEV Row6 load_row6(const float *__restrict__ p)
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y;
     return r;
 }
+// 6 consecutive pairs of a pair-plane row (48 B, 16-B aligned)
+struct Row6P {
+    f2 v[6];
+};
+MVF_DEV Row6P load_row6p(const f2 *__restrict__ p)
+{
+    Row6P r;
+    const float4 *q = reinterpret_cast<const float4 *>(p);
+    float4 a = q[0], b = q[1], c = q[2];
+    r.v[0] = mk2(a.x, a.y); r.v[1] = mk2(a.z, a.w); r.v[2] = mk2(b.x, b.y);
+    r.v[3] = mk2(b.z, b.w); r.v[4] = mk2(c.x, c.y); r.v[5] = mk2(c.z, c.w);
+    return r;
+}
 
-// Window sums of the 4 pixels of a lane, row-major sequential order (exact mode).
-// xs/ys point at plane element (row, 4*seg): the window of pixel j covers cols j..j+2.
-struct Stats4 {
-    float sx[PX], sxx[PX], sxy[PX];
-    float xc[PX], yc[PX];   // centre values
+// Window sums of the 4 pixels of a lane for a candidate PAIR and for the target, row-major
+// sequential order (exact mode).  xs/ys point at plane element (row, 4*seg): window of pixel
+// j = cols j..j+2.  The target statistics ride along as a packed (y, y*y) accumulator; they
+// are recomputed per pair instead of being held in 24 registers across the whole kernel.
+struct Stats4P {
+    f2 sx[PX], sxx[PX], sxy[PX];
+    f2 sy[PX];      // (sum y, sum y*y)
+    f2 xc[PX];      // centre values of the pair
+    float yc[PX];   // centre values of the target
 };
 
-MVF_DEV void window_x(const float *__restrict__ xs, const float *__restrict__ ys, Stats4 &o)
+MVF_DEV void window_xp(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4P &o)
 {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        Row6 x = load_row6(xs + r * LDW);
+        Row6P x = load_row6p(xs + r * LDW);
         Row6 y = load_row6(ys + r * LDW);
-        float xx[6], xy[6];
+        f2 xx[6], xy[6], yy[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             xx[i] = x.v[i] * x.v[i];
-            xy[i] = x.v[i] * y.v[i];
+            xy[i] = x.v[i] * f2s(y.v[i]);
+            yy[i] = mk2(y.v[i], y.v[i] * y.v[i]);
         }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
@@ -132,10 +161,12 @@ MVF_DEV void window_x(const float *__restrict__ xs, const float *__restrict__ ys
                     o.sx[j] = x.v[j];
                     o.sxx[j] = xx[j];
                     o.sxy[j] = xy[j];
+                    o.sy[j] = yy[j];
                 } else {
                     o.sx[j] = o.sx[j] + x.v[j + d];
                     o.sxx[j] = o.sxx[j] + xx[j + d];
                     o.sxy[j] = o.sxy[j] + xy[j + d];
+                    o.sy[j] = o.sy[j] + yy[j + d];
                 }
             }
             if (r == 1) {
@@ -146,78 +177,80 @@ MVF_DEV void window_x(const float *__restrict__ xs, const float *__restrict__ ys
     }
 }
 
-struct StatsY4 {
-    float mu[PX], eyy[PX];
-};
-
-MVF_DEV void window_y(const float *__restrict__ ys, StatsY4 &o)
+// reference: layers.py:281-290 for a candidate pair -- literal expression order per lane
+MVF_DEV f2 ssim_raw_pk(f2 mu_x, f2 mu_y, f2 exx, f2 eyy, f2 exy)
 {
-    float sy[PX], syy[PX];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        Row6 y = load_row6(ys + r * LDW);
-        float yy[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) yy[i] = y.v[i] * y.v[i];
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                if (r == 0 && d == 0) {
-                    sy[j] = y.v[j];
-                    syy[j] = yy[j];
-                } else {
-                    sy[j] = sy[j] + y.v[j + d];
-                    syy[j] = syy[j] + yy[j + d];
-                }
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-        o.mu[j] = div9(sy[j]);
-        o.eyy[j] = div9(syy[j]);
-    }
+    f2 sigma_x = exx - mu_x * mu_x;
+    f2 sigma_y = eyy - mu_y * mu_y;
+    f2 sigma_xy = exy - mu_x * mu_y;
+    f2 n = (2.0f * mu_x * mu_y + f2s(kC1)) * (2.0f * sigma_xy + f2s(kC2));
+    f2 d = (mu_x * mu_x + mu_y * mu_y + f2s(kC1)) * (sigma_x + sigma_y + f2s(kC2));
+    return (f2s(1.0f) - n / d) / 2.0f;
 }
 
-// reprojection map of one staged pred (3 planes) against the staged target for the 4
-// pixels of this lane.   reference: train.py:973-985
-MVF_DEV void reproj4(const float *__restrict__ pred, const float *__restrict__ tgt, int off,
-                     const StatsY4 ty[3], bool no_ssim, float out[PX])
+MVF_DEV f2 clamp01_pk(f2 v) { return mk2(clamp01(v.x), clamp01(v.y)); }
+
+// x-side partial derivatives of the clamped SSIM map for a candidate pair
+MVF_DEV void ssim_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &dmux, f2 &dexx, f2 &dexy)
 {
-    float ab[3][PX], ss[3][PX];
+    f2 sigma_x = exx - mx * mx, sigma_y = eyy - my * my, sigma_xy = exy - mx * my;
+    f2 A1 = 2.0f * mx * my + f2s(kC1), A2 = 2.0f * sigma_xy + f2s(kC2);
+    f2 B1 = mx * mx + my * my + f2s(kC1), B2 = sigma_x + sigma_y + f2s(kC2);
+    f2 n = A1 * A2, d = B1 * B2;
+    f2 raw = (f2s(1.0f) - n / d) / 2.0f;
+    f2 live = mk2((raw.x >= 0.0f && raw.x <= 1.0f) ? 1.0f : 0.0f,
+                  (raw.y >= 0.0f && raw.y <= 1.0f) ? 1.0f : 0.0f);
+    f2 inv_d = f2s(1.0f) / d;
+    f2 kn = -0.5f * inv_d * live;
+    f2 kd = 0.5f * n * inv_d * inv_d * live;
+    f2 dn_dmx = 2.0f * my * A2 - 2.0f * my * A1;
+    f2 dd_dmx = 2.0f * mx * B2 - 2.0f * mx * B1;
+    dmux = kn * dn_dmx + kd * dd_dmx;
+    dexy = kn * 2.0f * A1;
+    dexx = kd * B1;
+}
+
+// reprojection maps of a staged candidate pair against the staged target for the 4 pixels
+// of this lane.   reference: train.py:973-985.  Channel sums accumulate in the reference's
+// order ((c0 + c1) + c2).
+MVF_DEV void reproj4p(const f2 *__restrict__ pair, const float *__restrict__ tgt, int off,
+                      bool no_ssim, f2 out[PX])
+{
+    f2 ab[PX], ss[PX];
 #pragma unroll
+    for (int j = 0; j < PX; ++j) ab[j] = ss[j] = f2s(0.0f);
+#pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         if (no_ssim) {
-            Row6 x = load_row6(pred + c * PLANE + off + LDW);
+            Row6P x = load_row6p(pair + c * PPLANE + off + LDW);
             Row6 y = load_row6(tgt + c * PLANE + off + LDW);
 #pragma unroll
-            for (int j = 0; j < PX; ++j) ab[c][j] = fabsf(y.v[j + 1] - x.v[j + 1]);
+            for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(y.v[j + 1]) - x.v[j + 1]);
         } else {
-            Stats4 s;
-            window_x(pred + c * PLANE + off, tgt + c * PLANE + off, s);
+            Stats4P s;
+            window_xp(pair + c * PPLANE + off, tgt + c * PLANE + off, s);
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
-                Win w = {div9(s.sx[j]), ty[c].mu[j], div9(s.sxx[j]), ty[c].eyy[j], div9(s.sxy[j])};
-                ss[c][j] = clamp01(ssim_raw(w));
-                ab[c][j] = fabsf(s.yc[j] - s.xc[j]);
+                f2 my = div9(s.sy[j]);     // (mu_y, E[y*y])
+                f2 raw = ssim_raw_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
+                                     div9(s.sxy[j]));
+                ss[j] = ss[j] + clamp01_pk(raw);
+                ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
             }
         }
     }
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
-        float l1 = div3((ab[0][j] + ab[1][j]) + ab[2][j]);
+        f2 l1 = div3(ab[j]);
         if (no_ssim) {
             out[j] = l1;
         } else {
-            float sm = div3((ss[0][j] + ss[1][j]) + ss[2][j]);
+            f2 sm = div3(ss[j]);
             out[j] = 0.85f * sm + 0.15f * l1;
         }
     }
 }
 
-// ---- fused warp into LDS: pred planes <- bilinear samples of src at the projected
-// positions of every plane pixel (reflect-mapped into the image)
 struct PoseLds {
     float P[MVF_MAX_SRC][12];
     float den;    // per-image mean disparity + 1e-7
@@ -226,38 +259,135 @@ struct PoseLds {
     float pad;
 };
 
-MVF_DEV void load_pose_regs(const PoseLds &sh, int k, float P[12])
+MVF_DEV void load_pose_pair(const PoseLds &sh, int ka, int kb, f2 P2[12])
 {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) P[i] = sh.P[k][i];
+    for (int i = 0; i < 12; ++i) P2[i] = mk2(sh.P[ka][i], sh.P[kb][i]);
 }
 
-MVF_DEV void warp_into_lds(float *__restrict__ pred, const float *__restrict__ dispP,
-                           const float *__restrict__ src, const float *__restrict__ iK,
-                           const float P[12], int H, int W, int py0, int px0, float min_disp,
-                           float range, float eps, int32_t *__restrict__ idx_xy, int ty0, int tx0)
+// stage two [3,H,W] images interleaved into the 3 pair planes (reflect addressing)
+MVF_DEV void stage_pair3(f2 *__restrict__ pairP, const float *__restrict__ im0,
+                         const float *__restrict__ im1, size_t N, int H, int W, int py0, int px0)
 {
-    size_t N = (size_t)H * W;
     for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        WarpPoint w = warp_point(dispP[r * LDW + c], iK, P, gx, gy, H, W, min_disp, range, eps);
-        const float *s00 = src + w.t.y0 * W + w.t.x0, *s01 = src + w.t.y0 * W + w.t.x1;
-        const float *s10 = src + w.t.y1 * W + w.t.x0, *s11 = src + w.t.y1 * W + w.t.x1;
-        // all 12 taps in flight before the first use
-        float a0 = s00[0], b0 = s01[0], c0 = s10[0], d0 = s11[0];
-        float a1 = s00[N], b1 = s01[N], c1 = s10[N], d1 = s11[N];
-        float a2 = s00[2 * N], b2 = s01[2 * N], c2 = s10[2 * N], d2 = s11[2 * N];
-        float fw = w.t.wx, fe = 1.0f - fw, fn = w.t.wy, fs = 1.0f - fn;
-        float wnw = fs * fe, wne = fs * fw, wsw = fn * fe, wse = fn * fw;
-        pred[r * LDW + c] = a0 * wnw + b0 * wne + c0 * wsw + d0 * wse;
-        pred[PLANE + r * LDW + c] = a1 * wnw + b1 * wne + c1 * wsw + d1 * wse;
-        pred[2 * PLANE + r * LDW + c] = a2 * wnw + b2 * wne + c2 * wsw + d2 * wse;
-        if (idx_xy) {
+        unsigned o = (unsigned)gy * W + gx;
+        float a0 = im0[o], a1 = im0[N + o], a2 = im0[2 * N + o];
+        float b0 = im1[o], b1 = im1[N + o], b2 = im1[2 * N + o];
+        pairP[r * LDW + c] = mk2(a0, b0);
+        pairP[PPLANE + r * LDW + c] = mk2(a1, b1);
+        pairP[2 * PPLANE + r * LDW + c] = mk2(a2, b2);
+    }
+}
+
+// overwrite one lane (0/1) of the pair planes with a staged image
+MVF_DEV void stage_lane3(f2 *__restrict__ pairP, int lane, const float *__restrict__ im, size_t N,
+                         int H, int W, int py0, int px0)
+{
+    float *base = reinterpret_cast<float *>(pairP) + lane;
+    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
+        int r = idx / PW, c = idx - r * PW;
+        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
+        unsigned o = (unsigned)gy * W + gx;
+        float a0 = im[o], a1 = im[N + o], a2 = im[2 * N + o];
+        base[2 * (r * LDW + c)] = a0;
+        base[2 * (PPLANE + r * LDW + c)] = a1;
+        base[2 * (2 * PPLANE + r * LDW + c)] = a2;
+    }
+}
+
+// generate_images_pred for TWO sources at one pixel: the ray, depth and camera point are
+// shared, the projection runs packed (lane 0 = source a, lane 1 = source b).
+struct WarpPair {
+    Tap ta, tb;
+    f2 u, v, z;
+    float X[3], r[3], depth;
+};
+
+MVF_DEV WarpPair warp_point_pair(float disp, const float *__restrict__ iK, const f2 P2[12], int x,
+                                 int y, int H, int W, float min_disp, float range, float eps)
+{
+    WarpPair w;
+    ray_of(iK, (float)x, (float)y, w.r);
+    w.depth = depth_of(disp, min_disp, range);
+    w.X[0] = w.depth * w.r[0];
+    w.X[1] = w.depth * w.r[1];
+    w.X[2] = w.depth * w.r[2];
+    f2 c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        f2 a = P2[i * 4 + 0] * f2s(w.X[0]);
+        a = pk_fma(P2[i * 4 + 1], f2s(w.X[1]), a);
+        a = pk_fma(P2[i * 4 + 2], f2s(w.X[2]), a);
+        a = pk_fma(P2[i * 4 + 3], f2s(1.0f), a);
+        c[i] = a;
+    }
+    w.z = c[2] + f2s(eps);
+    w.u = c[0] / w.z;
+    w.v = c[1] / w.z;
+    f2 un = w.u / f2s((float)(W - 1));
+    f2 vn = w.v / f2s((float)(H - 1));
+    f2 gx = (un - f2s(0.5f)) * 2.0f;
+    f2 gy = (vn - f2s(0.5f)) * 2.0f;
+    w.ta = tap_of(gx.x, gy.x, H, W);
+    w.tb = tap_of(gx.y, gy.y, H, W);
+    return w;
+}
+
+struct Taps4 {
+    unsigned o00, o01, o10, o11;
+    float wnw, wne, wsw, wse;
+};
+MVF_DEV Taps4 taps_of(const Tap &t, int W)
+{
+    Taps4 q;
+    q.o00 = (unsigned)t.y0 * W + t.x0;
+    q.o01 = (unsigned)t.y0 * W + t.x1;
+    q.o10 = (unsigned)t.y1 * W + t.x0;
+    q.o11 = (unsigned)t.y1 * W + t.x1;
+    float fw = t.wx, fe = 1.0f - fw, fn = t.wy, fs = 1.0f - fn;
+    q.wnw = fs * fe; q.wne = fs * fw; q.wsw = fn * fe; q.wse = fn * fw;
+    return q;
+}
+
+// fused warp of a source pair into the pair planes: bilinear samples of src_a / src_b at
+// the projected position of every plane pixel (reflect-mapped into the image); all 24 taps
+// of a position are in flight before the first use.
+MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict__ dispP,
+                                const float *__restrict__ sa, const float *__restrict__ sb,
+                                const float *__restrict__ iK, const f2 P2[12], int H, int W, int py0,
+                                int px0, float min_disp, float range, float eps,
+                                int32_t *__restrict__ idx_a, int32_t *__restrict__ idx_b, int ty0,
+                                int tx0)
+{
+    const size_t N = (size_t)H * W;
+    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
+        int r = idx / PW, c = idx - r * PW;
+        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
+        WarpPair w = warp_point_pair(dispP[r * LDW + c], iK, P2, gx, gy, H, W, min_disp, range, eps);
+        Taps4 qa = taps_of(w.ta, W), qb = taps_of(w.tb, W);
+        float a[3][4], bq[3][4];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float *pa = sa + ch * N, *pb = sb + ch * N;
+            a[ch][0] = pa[qa.o00]; a[ch][1] = pa[qa.o01]; a[ch][2] = pa[qa.o10]; a[ch][3] = pa[qa.o11];
+            bq[ch][0] = pb[qb.o00]; bq[ch][1] = pb[qb.o01]; bq[ch][2] = pb[qb.o10]; bq[ch][3] = pb[qb.o11];
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float va = a[ch][0] * qa.wnw + a[ch][1] * qa.wne + a[ch][2] * qa.wsw + a[ch][3] * qa.wse;
+            float vb = bq[ch][0] * qb.wnw + bq[ch][1] * qb.wne + bq[ch][2] * qb.wsw + bq[ch][3] * qb.wse;
+            pairP[ch * PPLANE + r * LDW + c] = mk2(va, vb);
+        }
+        if (idx_a) {
             // the un-reflected pixels of this tile own their index entry
             int y = py0 + r, x = px0 + c;
-            if (y >= ty0 && y < min(ty0 + TH, H) && x >= tx0 && x < min(tx0 + TW, W))
-                reinterpret_cast<int2 *>(idx_xy)[(size_t)y * W + x] = make_int2(w.t.x0, w.t.y0);
+            if (y >= ty0 && y < min(ty0 + TH, H) && x >= tx0 && x < min(tx0 + TW, W)) {
+                reinterpret_cast<int2 *>(idx_a)[(size_t)y * W + x] = make_int2(w.ta.x0, w.ta.y0);
+                if (idx_b != idx_a)
+                    reinterpret_cast<int2 *>(idx_b)[(size_t)y * W + x] = make_int2(w.tb.x0, w.tb.y0);
+            }
         }
     }
 }
@@ -274,15 +404,25 @@ struct FwdArgs {
     float min_disp, range, eps;
 };
 
+// LDS carve (floats): target 3 planes | pair 3 planes of f2 | disparity 1 plane | pose | scratch
+constexpr int FWD_TGT = 0, FWD_PAIR = 3 * PLANE, FWD_DISP = FWD_PAIR + 6 * PLANE,
+              FWD_POSE = FWD_DISP + PLANE;
+
+#ifndef MVF_FWD_WAVES
+#define MVF_FWD_WAVES 1
+#endif
+#ifndef MVF_BWD_WAVES
+#define MVF_BWD_WAVES 1
+#endif
 template <bool FUSED, int S>
-__global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
+__global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tgtP = smem;                 // 3 planes
-    float *predP = smem + 3 * PLANE;    // 3 planes
-    float *dispP = smem + 6 * PLANE;    // 1 plane
-    PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + 7 * PLANE);
-    float *scratch = smem + 7 * PLANE + sizeof(PoseLds) / 4;
+    float *tgtP = smem + FWD_TGT;
+    f2 *pairP = reinterpret_cast<f2 *>(smem + FWD_PAIR);
+    float *dispP = smem + FWD_DISP;
+    PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + FWD_POSE);
+    float *scratch = smem + FWD_POSE + sizeof(PoseLds) / 4;
 
     const TileId tid = tile_of_block(a.tiles_x, a.tiles_y, a.B);
     const int H = a.H, W = a.W, b = tid.b;
@@ -309,42 +449,53 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
     const int off = row * LDW + seg * PX;   // plane element of the window's top-left
     const int y = ty0 + row, x0 = tx0 + seg * PX;
 
-    StatsY4 ty[3];
-    if (!no_ssim) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) window_y(tgtP + c * PLANE + off, ty[c]);
-    }
-
-    float rp[S][PX], idl[S][PX];
-    const int npred = automask ? 2 * S : S;
+    // candidates in evaluation order: S warped sources, then (auto-masking) S identity
+    // sources; evaluated two at a time
+    constexpr int NC = 2 * S;
+    float val[NC][PX];
+    const int ncand = automask ? 2 * S : S;
+    const int npair = (ncand + 1) >> 1;
 #pragma unroll 1
-    for (int p = 0; p < npred; ++p) {
-        const bool is_id = p >= S;
-        const int k = is_id ? p - S : p;
-        __syncthreads();   // previous pred fully consumed
-        if (FUSED && !is_id) {
-            float P[12];
-            load_pose_regs(sh, k, P);
-            warp_into_lds(predP, dispP, a.src.p[k] + (size_t)b * 3 * N, a.invK + b * 16, P, H, W,
-                          py0, px0, a.min_disp, a.range, a.eps,
-                          a.idx_xy ? a.idx_xy + ((size_t)k * a.B + b) * N * 2 : nullptr, ty0, tx0);
+    for (int pr = 0; pr < npair; ++pr) {
+        const int ca = 2 * pr, cb = (2 * pr + 1 < ncand) ? 2 * pr + 1 : 2 * pr;
+        const bool wa = ca < S, wb = cb < S;              // warped (vs identity) candidates
+        const int ka = wa ? ca : ca - S, kb = wb ? cb : cb - S;
+        __syncthreads();   // previous pair fully consumed
+        if (FUSED) {
+            if (wa) {
+                // lane 0 (and lane 1 when it is a warped source too) by the fused warp
+                f2 P2[12];
+                const int kb2 = wb ? kb : ka;
+                load_pose_pair(sh, ka, kb2, P2);
+                int32_t *ia = a.idx_xy ? a.idx_xy + ((size_t)ka * a.B + b) * N * 2 : nullptr;
+                int32_t *ib = a.idx_xy ? a.idx_xy + ((size_t)kb2 * a.B + b) * N * 2 : nullptr;
+                warp_pair_into_lds(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
+                                   a.src.p[kb2] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0,
+                                   px0, a.min_disp, a.range, a.eps, ia, ib, ty0, tx0);
+                if (!wb) stage_lane3(pairP, 1, a.src.p[kb] + (size_t)b * 3 * N, N, H, W, py0, px0);
+            } else {
+                stage_pair3(pairP, a.src.p[ka] + (size_t)b * 3 * N, a.src.p[kb] + (size_t)b * 3 * N, N,
+                            H, W, py0, px0);
+            }
         } else {
-            const float *im = (is_id ? a.src.p[k] : a.warped.p[k]) + (size_t)b * 3 * N;
-            stage_planes3(predP, im, N, H, W, py0, px0);
+            const float *ima = (wa ? a.warped.p[ka] : a.src.p[ka]) + (size_t)b * 3 * N;
+            const float *imb = (wb ? a.warped.p[kb] : a.src.p[kb]) + (size_t)b * 3 * N;
+            stage_pair3(pairP, ima, imb, N, H, W, py0, px0);
         }
         __syncthreads();
-        float out[PX];
-        reproj4(predP, tgtP, off, ty, no_ssim, out);
+        f2 out[PX];
+        reproj4p(pairP, tgtP, off, no_ssim, out);
 #pragma unroll
-        for (int kk = 0; kk < S; ++kk)     // static register indices only
+        for (int cc = 0; cc < NC; ++cc)     // static register indices only
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
-                if (kk == k && is_id) idl[kk][j] = out[j];
-                if (kk == k && !is_id) rp[kk][j] = out[j];
+                if (cc == ca) val[cc][j] = out[j].x;
+                if (cc == cb && cb != ca) val[cc][j] = out[j].y;
             }
     }
 
     // ---- candidates, min / argmin, mask, outputs (reference: train.py:1010-1043)
+    // rp[k] = val[k], idl[k] = val[S + k]
     float photo = 0.0f, sx = 0.0f, sy = 0.0f;
     const float den = sh.den;
 #pragma unroll
@@ -357,32 +508,32 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
         int bi = 0, nc = 0;
         if (automask) {
             if (avg) {
-                float m = idl[0][j];
+                float m = val[S][j];
 #pragma unroll
-                for (int k = 1; k < S; ++k) m = m + idl[k][j];
+                for (int k = 1; k < S; ++k) m = m + val[S + k][j];
                 m = m / (float)S;
                 best = m + a.noise[pi] * 0.00001f;
                 nc = 1;
             } else {
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    float v = idl[k][j] + a.noise[((size_t)b * S + k) * N + pix] * 0.00001f;
+                    float v = val[S + k][j] + a.noise[((size_t)b * S + k) * N + pix] * 0.00001f;
                     if (nc == 0 || v < best) { best = v; bi = nc; }
                     ++nc;
                 }
             }
         }
         if (avg) {
-            float m = rp[0][j];
+            float m = val[0][j];
 #pragma unroll
-            for (int k = 1; k < S; ++k) m = m + rp[k][j];
+            for (int k = 1; k < S; ++k) m = m + val[k][j];
             m = m / (float)S;
             if (nc == 0 || m < best) { best = m; bi = nc; }
             ++nc;
         } else {
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                float v = rp[k][j];
+                float v = val[k][j];
                 if (nc == 0 || v < best) { best = v; bi = nc; }
                 ++nc;
             }
@@ -414,10 +565,9 @@ __global__ void __launch_bounds__(NT) k_photo_fwd(FwdArgs a)
     }
     float *part = a.ws + (size_t)a.B * NMEAN +
                   (((size_t)b * a.tiles_y + tid.by) * a.tiles_x + tid.bx) * NPART;
-    float r0 = block_sum<NT>(photo, scratch);
-    float r1 = block_sum<NT>(sx, scratch);
-    float r2 = block_sum<NT>(sy, scratch);
-    if (threadIdx.x == 0) { part[0] = r0; part[1] = r1; part[2] = r2; part[3] = 0.0f; }
+    const float sums[4] = {photo, sx, sy, 0.0f};
+    const float tot = block_sum_many<NT, 4>(sums, scratch);
+    if (threadIdx.x < 4) part[threadIdx.x] = tot;
 }
 
 // per-image mean of disp: NMEAN partial sums per image, folded in fixed order by consumers
@@ -521,23 +671,28 @@ struct BwdArgs {
 
 constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a backward region
 
+// LDS carve (floats): target 3 planes | pair 3 f2 planes | disparity | coefficient 3 f2 region
+// planes (A,B,G; reused to park grad_warped) | grad_disp accumulator region plane | pose | scratch
+constexpr int BWD_TGT = 0, BWD_PAIR = 3 * PLANE, BWD_DISP = BWD_PAIR + 6 * PLANE,
+              BWD_COEF = BWD_DISP + PLANE, BWD_GD = BWD_COEF + 6 * RPLANE, BWD_POSE = BWD_GD + RPLANE;
+
 template <bool FUSED, int S>
-__global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
+__global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *tgtP = smem;                 // 3 planes
-    float *predP = smem + 3 * PLANE;    // 3 planes
-    float *dispP = smem + 6 * PLANE;    // 1 plane
-    float *coefP = smem + 7 * PLANE;    // 3 region planes (A, B, G); reused for grad_warped
-    float *gdP = coefP + 3 * RPLANE;    // 1 region plane: grad_depth -> grad_disp accumulator
-    PoseLds &sh = *reinterpret_cast<PoseLds *>(gdP + RPLANE);
-    float *scratch = gdP + RPLANE + sizeof(PoseLds) / 4;
+    float *tgtP = smem + BWD_TGT;
+    f2 *pairP = reinterpret_cast<f2 *>(smem + BWD_PAIR);
+    float *dispP = smem + BWD_DISP;
+    f2 *coefP = reinterpret_cast<f2 *>(smem + BWD_COEF);
+    float *gdP = smem + BWD_GD;
+    PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + BWD_POSE);
+    float *scratch = smem + BWD_POSE + sizeof(PoseLds) / 4;
 
     const TileId tid = tile_of_block(a.tiles_x, a.tiles_y, a.B);
     const int H = a.H, W = a.W, b = tid.b;
     const size_t N = (size_t)H * W;
     const int cy0 = tid.by * OH - 1, cx0 = tid.bx * OW - 1;   // region origin
-    const int py0 = cy0 - 1, px0 = cx0 - 1;                           // plane origin
+    const int py0 = cy0 - 1, px0 = cx0 - 1;                   // plane origin
     const bool no_ssim = a.flags & MVF_NO_SSIM, avg = a.flags & MVF_AVG_REPROJ;
     const bool automask = !(a.flags & MVF_NO_AUTOMASK);
     const int n_id = automask ? (avg ? 1 : S) : 0;
@@ -577,110 +732,133 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
         wbase[j] = in ? sh.gpix * m : 0.0f;
     }
 
-    StatsY4 ty[3];
-    if (!no_ssim) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) window_y(tgtP + c * PLANE + off, ty[c]);
-    }
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
 
+    constexpr int NPAIR = (S + 1) / 2;
 #pragma unroll 1
-    for (int k = 0; k < S; ++k) {
-        asm volatile("" ::: "memory");   // keep k-invariant LDS reads inside the loop (VGPRs)
+    for (int pr = 0; pr < NPAIR; ++pr) {
+        const int ka = 2 * pr;
+        const bool hasb = 2 * pr + 1 < S;
+        const int kb = hasb ? 2 * pr + 1 : ka;
+        asm volatile("" ::: "memory");
         __syncthreads();
+        f2 P2[12];
         if (FUSED) {
-            float P[12];
-            load_pose_regs(sh, k, P);
-            warp_into_lds(predP, dispP, a.src.p[k] + (size_t)b * 3 * N, a.invK + b * 16, P, H, W,
-                          py0, px0, a.min_disp, a.range, a.eps, nullptr, 0, 0);
+            load_pose_pair(sh, ka, kb, P2);
+            warp_pair_into_lds(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
+                               a.src.p[kb] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0, px0,
+                               a.min_disp, a.range, a.eps, nullptr, nullptr, 0, 0);
         } else {
-            stage_planes3(predP, a.warped.p[k] + (size_t)b * 3 * N, N, H, W, py0, px0);
+            stage_pair3(pairP, a.warped.p[ka] + (size_t)b * 3 * N, a.warped.p[kb] + (size_t)b * 3 * N, N,
+                        H, W, py0, px0);
         }
         __syncthreads();
 
-        // selection weight of this source: the argmin picked it (or the averaged channel)
-        float wk[PX];
+        // selection weights of the two sources: the argmin picked it (or the averaged channel)
+        f2 wk[PX];
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            float w;
-            if (sel[j] == 255) w = avg ? 1.0f / (float)S : 1.0f;        // single candidate
-            else if (avg) w = (sel[j] == n_id) ? 1.0f / (float)S : 0.0f;
-            else w = (sel[j] == n_id + k) ? 1.0f : 0.0f;
-            wk[j] = wbase[j] * w;
+            float wa, wb;
+            if (sel[j] == 255) wa = wb = avg ? 1.0f / (float)S : 1.0f;        // single candidate
+            else if (avg) wa = wb = (sel[j] == n_id) ? 1.0f / (float)S : 0.0f;
+            else { wa = (sel[j] == n_id + ka) ? 1.0f : 0.0f; wb = (sel[j] == n_id + kb) ? 1.0f : 0.0f; }
+            wk[j] = mk2(wbase[j] * wa, hasb ? wbase[j] * wb : 0.0f);
         }
 
-        float gw[3][PX];
-#pragma unroll
+#pragma unroll 1
         for (int c = 0; c < 3; ++c) {
-            const float *xp = predP + c * PLANE, *yp = tgtP + c * PLANE;
-            float xq[PX], yq[PX];
+            f2 gw[PX];
+            const f2 *xp = pairP + c * PPLANE;
+            const float *yp = tgtP + c * PLANE;
+            f2 xq[PX];
+            float yq[PX];
             if (no_ssim) {
-                Row6 xr = load_row6(xp + off + LDW), yr = load_row6(yp + off + LDW);
+                Row6P xr = load_row6p(xp + off + LDW);
+                Row6 yr = load_row6(yp + off + LDW);
 #pragma unroll
                 for (int j = 0; j < PX; ++j) { xq[j] = xr.v[j + 1]; yq[j] = yr.v[j + 1]; }
             } else {
-                Stats4 s;
-                window_x(xp + off, yp + off, s);
-                float cA[PX], cB[PX], cG[PX];
+                Stats4P s;
+                window_xp(xp + off, yp + off, s);
+                f2 cA[PX], cB[PX], cG[PX];
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    Win w = {div9(s.sx[j]), ty[c].mu[j], div9(s.sxx[j]), ty[c].eyy[j],
-                             div9(s.sxy[j])};
-                    DWin d = ssim_partials(w);
-                    float g = wk[j] * ((0.85f / 3.0f) / 9.0f);
-                    cA[j] = g * d.dmux;
-                    cB[j] = g * 2.0f * d.dexx;
-                    cG[j] = g * d.dexy;
+                    f2 dmux, dexx, dexy;
+                    f2 my = div9(s.sy[j]);     // (mu_y, E[y*y])
+                    ssim_partials_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
+                                     div9(s.sxy[j]), dmux, dexx, dexy);
+                    f2 g = wk[j] * ((0.85f / 3.0f) / 9.0f);
+                    cA[j] = g * dmux;
+                    cB[j] = g * 2.0f * dexx;
+                    cG[j] = g * dexy;
                     xq[j] = s.xc[j];
                     yq[j] = s.yc[j];
                 }
-                float *cp = coefP + roff;
-                *reinterpret_cast<float4 *>(cp) = make_float4(cA[0], cA[1], cA[2], cA[3]);
-                *reinterpret_cast<float4 *>(cp + RPLANE) = make_float4(cB[0], cB[1], cB[2], cB[3]);
-                *reinterpret_cast<float4 *>(cp + 2 * RPLANE) = make_float4(cG[0], cG[1], cG[2], cG[3]);
+                float4 *cp = reinterpret_cast<float4 *>(coefP + roff);
+                cp[0] = make_float4(cA[0].x, cA[0].y, cA[1].x, cA[1].y);
+                cp[1] = make_float4(cA[2].x, cA[2].y, cA[3].x, cA[3].y);
+                cp = reinterpret_cast<float4 *>(coefP + RPPLANE + roff);
+                cp[0] = make_float4(cB[0].x, cB[0].y, cB[1].x, cB[1].y);
+                cp[1] = make_float4(cB[2].x, cB[2].y, cB[3].x, cB[3].y);
+                cp = reinterpret_cast<float4 *>(coefP + 2 * RPPLANE + roff);
+                cp[0] = make_float4(cG[0].x, cG[0].y, cG[1].x, cG[1].y);
+                cp[1] = make_float4(cG[2].x, cG[2].y, cG[3].x, cG[3].y);
             }
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
                 // L1 term: d|t-p|/dp = -sign(t-p), channel mean
-                float df = yq[j] - xq[j];
-                float sg = (df > 0.0f) ? -1.0f : ((df < 0.0f) ? 1.0f : 0.0f);
-                gw[c][j] = wk[j] * (no_ssim ? 1.0f : 0.15f) * sg / 3.0f;
+                f2 df = f2s(yq[j]) - xq[j];
+                f2 sg = mk2((df.x > 0.0f) ? -1.0f : ((df.x < 0.0f) ? 1.0f : 0.0f),
+                            (df.y > 0.0f) ? -1.0f : ((df.y < 0.0f) ? 1.0f : 0.0f));
+                gw[j] = wk[j] * (no_ssim ? 1.0f : 0.15f) * sg / 3.0f;
             }
             if (!no_ssim && row >= 1 && row <= OH) {
-                float sA[PX] = {0.f, 0.f, 0.f, 0.f}, sB[PX] = {0.f, 0.f, 0.f, 0.f},
-                      sG[PX] = {0.f, 0.f, 0.f, 0.f};
+                f2 sA[PX], sB[PX], sG[PX];
+#pragma unroll
+                for (int j = 0; j < PX; ++j) sA[j] = sB[j] = sG[j] = f2s(0.0f);
                 const bool hasl = seg > 0, hasr = seg < TW / PX - 1;
 #pragma unroll
                 for (int dr = -1; dr <= 1; ++dr) {
                     const float my = (dr < 0) ? myu : ((dr > 0) ? myd : 1.0f);
                     // coefficient columns 4*seg-1 .. 4*seg+4 of region row (row+dr)
-                    const float *cr = coefP + roff + dr * LDW;
-                    float4 mA = *reinterpret_cast<const float4 *>(cr);
-                    float4 mB = *reinterpret_cast<const float4 *>(cr + RPLANE);
-                    float4 mG = *reinterpret_cast<const float4 *>(cr + 2 * RPLANE);
-                    float vA[6] = {hasl ? cr[-1] : 0.f, mA.x, mA.y, mA.z, mA.w, hasr ? cr[4] : 0.f};
-                    float vB[6] = {hasl ? cr[RPLANE - 1] : 0.f, mB.x, mB.y, mB.z, mB.w,
-                                   hasr ? cr[RPLANE + 4] : 0.f};
-                    float vG[6] = {hasl ? cr[2 * RPLANE - 1] : 0.f, mG.x, mG.y, mG.z, mG.w,
-                                   hasr ? cr[2 * RPLANE + 4] : 0.f};
 #pragma unroll
-                    for (int j = 0; j < PX; ++j) {
-                        // reflect-pad multiplicity: neighbour column 0 seen twice from column 1, ...
-                        const float ml = (x0 + j == 1) ? 2.0f : 1.0f;
-                        const float mr = (x0 + j == W - 2) ? 2.0f : 1.0f;
-                        sA[j] += my * (ml * vA[j] + vA[j + 1] + mr * vA[j + 2]);
-                        sB[j] += my * (ml * vB[j] + vB[j + 1] + mr * vB[j + 2]);
-                        sG[j] += my * (ml * vG[j] + vG[j + 1] + mr * vG[j + 2]);
+                    for (int pl = 0; pl < 3; ++pl) {
+                        const f2 *cr = coefP + pl * RPPLANE + roff + dr * LDW;
+                        const float4 *q = reinterpret_cast<const float4 *>(cr);
+                        float4 m0 = q[0], m1 = q[1];
+                        f2 v[6];
+                        v[0] = hasl ? cr[-1] : f2s(0.0f);
+                        v[1] = mk2(m0.x, m0.y); v[2] = mk2(m0.z, m0.w);
+                        v[3] = mk2(m1.x, m1.y); v[4] = mk2(m1.z, m1.w);
+                        v[5] = hasr ? cr[4] : f2s(0.0f);
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) {
+                            // reflect-pad multiplicity: column 0 is seen twice from column 1, ...
+                            const float ml = (x0 + j == 1) ? 2.0f : 1.0f;
+                            const float mr = (x0 + j == W - 2) ? 2.0f : 1.0f;
+                            f2 t = my * (ml * v[j] + v[j + 1] + mr * v[j + 2]);
+                            if (pl == 0) sA[j] += t;
+                            else if (pl == 1) sB[j] += t;
+                            else sG[j] += t;
+                        }
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < PX; ++j) gw[c][j] += sA[j] + xq[j] * sB[j] + yq[j] * sG[j];
+                for (int j = 0; j < PX; ++j) gw[j] += sA[j] + xq[j] * sB[j] + f2s(yq[j]) * sG[j];
+            }
+            // park grad_warped of this channel in its own pair plane: every window read of
+            // the plane finished before the barrier above, and each lane only touches the
+            // entries of its own 4 pixels
+            {
+                f2 *gp = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
+#pragma unroll
+                for (int j = 0; j < PX; ++j) gp[j] = gw[j];
             }
             __syncthreads();   // coefficient planes free for the next channel
         }
 
-        // ---- consume grad_warped of this source
+        // ---- consume grad_warped of this source pair
         if (!FUSED) {
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
@@ -689,39 +867,53 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
                 if (!outp) continue;
                 const size_t pi = (size_t)y * W + x;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) a.g_warped.p[k][((size_t)b * 3 + c) * N + pi] = gw[c][j];
+                for (int c = 0; c < 3; ++c) {
+                    const f2 g = pairP[c * PPLANE + (row + 1) * LDW + col + 1];
+                    a.g_warped.p[ka][((size_t)b * 3 + c) * N + pi] = g.x;
+                    if (hasb) a.g_warped.p[kb][((size_t)b * 3 + c) * N + pi] = g.y;
+                }
             }
         } else {
-            // park grad_warped in the (now free) coefficient planes, then walk this lane's
-            // pixels one at a time through the projection adjoint (keeps the live set small)
+            // walk this lane's pixels one at a time through the projection adjoint (keeps
+            // the live set small); grad_warped comes back from the pair planes
+            const float *sa = a.src.p[ka] + (size_t)b * 3 * N, *sb = a.src.p[kb] + (size_t)b * 3 * N;
+            f2 accP[12];
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
-                *reinterpret_cast<float4 *>(coefP + c * RPLANE + roff) =
-                    make_float4(gw[c][0], gw[c][1], gw[c][2], gw[c][3]);
-            float P[12];
-            load_pose_regs(sh, k, P);
-            const float *sp = a.src.p[k] + (size_t)b * 3 * N;
-            float accP[12];
-#pragma unroll
-            for (int q = 0; q < 12; ++q) accP[q] = 0.0f;
+            for (int q = 0; q < 12; ++q) accP[q] = f2s(0.0f);
 #pragma unroll 1
             for (int j = 0; j < PX; ++j) {
                 const int x = x0 + j, col = seg * PX + j;
                 const bool outp = row_out && (col >= 1) && (col <= OW) && (x >= 0) && (x < W);
                 if (!outp) continue;
-                const float g0 = coefP[roff + j], g1 = coefP[RPLANE + roff + j],
-                            g2 = coefP[2 * RPLANE + roff + j];
-                WarpPoint w = warp_point(dispP[(row + 1) * LDW + col + 1], a.invK + b * 16, P, x, y,
-                                         H, W, a.min_disp, a.range, a.eps);
-                float dx0, dy0, dx1, dy1, dx2, dy2;
-                bilerp_grad(sp, W, w.t, dx0, dy0);
-                bilerp_grad(sp + N, W, w.t, dx1, dy1);
-                bilerp_grad(sp + 2 * N, W, w.t, dx2, dy2);
-                float gix = g0 * dx0 + g1 * dx1 + g2 * dx2;
-                float giy = g0 * dy0 + g1 * dy1 + g2 * dy2;
-                float gc[3];
-                float gd = warp_point_bwd(w, P, gix, giy, H, W, gc);
-                gdP[roff + j] += -gd * w.depth * w.depth * a.range;
+                const f2 *gp = pairP + (row + 1) * LDW + col + 1;
+                const f2 g0 = gp[0], g1 = gp[PPLANE], g2 = gp[2 * PPLANE];
+                WarpPair w = warp_point_pair(dispP[(row + 1) * LDW + col + 1], a.invK + b * 16, P2, x, y,
+                                             H, W, a.min_disp, a.range, a.eps);
+                float dxa[3], dya[3], dxb[3], dyb[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    bilerp_grad(sa + c * N, W, w.ta, dxa[c], dya[c]);
+                    bilerp_grad(sb + c * N, W, w.tb, dxb[c], dyb[c]);
+                }
+                f2 gix = g0 * mk2(dxa[0], dxb[0]) + g1 * mk2(dxa[1], dxb[1]) + g2 * mk2(dxa[2], dxb[2]);
+                f2 giy = g0 * mk2(dya[0], dyb[0]) + g1 * mk2(dya[1], dyb[1]) + g2 * mk2(dya[2], dyb[2]);
+                // adjoint of unnormalise / normalise / perspective divide (see warp_point_bwd)
+                const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+                f2 ggx = mk2(w.ta.inx ? gix.x * (wm1 / 2.0f) : 0.0f, w.tb.inx ? gix.y * (wm1 / 2.0f) : 0.0f);
+                f2 ggy = mk2(w.ta.iny ? giy.x * (hm1 / 2.0f) : 0.0f, w.tb.iny ? giy.y * (hm1 / 2.0f) : 0.0f);
+                f2 gu = ggx * 2.0f / wm1, gv = ggy * 2.0f / hm1;
+                f2 gc[3];
+                gc[0] = gu / w.z;
+                gc[1] = gv / w.z;
+                gc[2] = -(gu * w.u + gv * w.v) / w.z;
+                f2 gd = f2s(0.0f);
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) {
+                    f2 gX = gc[0] * P2[0 * 4 + jj] + gc[1] * P2[1 * 4 + jj] + gc[2] * P2[2 * 4 + jj];
+                    gd += gX * w.r[jj];
+                }
+                const float gdsum = hasb ? gd.x + gd.y : gd.x;
+                gdP[roff + j] += -gdsum * w.depth * w.depth * a.range;
 #pragma unroll
                 for (int q = 0; q < 3; ++q) {
                     accP[q * 4 + 0] += gc[q] * w.X[0];
@@ -730,15 +922,17 @@ __global__ void __launch_bounds__(NT) k_photo_bwd(BwdArgs a)
                     accP[q * 4 + 3] += gc[q];
                 }
             }
-            // per-tile partial of grad_P for source k: ws[((k*B + b)*ntiles + tile)*12 + q]
+            // per-tile partials of grad_P: ws[((k*B + b)*ntiles + tile)*12 + q]
             const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
-            float *part = a.ws + ((((size_t)k * a.B + b) * ntiles) +
-                                  (size_t)tid.by * a.tiles_x + tid.bx) * 12;
+            const size_t tile = (size_t)tid.by * a.tiles_x + tid.bx;
+            float *parta = a.ws + (((size_t)ka * a.B + b) * ntiles + tile) * 12;
+            float *partb = a.ws + (((size_t)kb * a.B + b) * ntiles + tile) * 12;
+            float flat[24];
 #pragma unroll
-            for (int q = 0; q < 12; ++q) {
-                float s = block_sum<NT>(accP[q], scratch);
-                if (threadIdx.x == 0) part[q] = s;
-            }
+            for (int q = 0; q < 12; ++q) { flat[q] = accP[q].x; flat[12 + q] = accP[q].y; }
+            const float tot = block_sum_many<NT, 24>(flat, scratch);
+            if (threadIdx.x < 12) parta[threadIdx.x] = tot;
+            else if (threadIdx.x < 24 && hasb) partb[threadIdx.x - 12] = tot;
         }
     }
 
@@ -1026,11 +1220,8 @@ __global__ void __launch_bounds__(256) k_smooth_bwd(const float *__restrict__ di
     g_disp[o] = accumulate ? g_disp[o] + g : g;
 }
 
-inline size_t fwd_smem() { return (7 * PLANE) * sizeof(float) + sizeof(PoseLds) + 8 * sizeof(float); }
-inline size_t bwd_smem()
-{
-    return (7 * PLANE + 4 * RPLANE) * sizeof(float) + sizeof(PoseLds) + 8 * sizeof(float);
-}
+inline size_t fwd_smem() { return FWD_POSE * sizeof(float) + sizeof(PoseLds) + 128 * sizeof(float); }
+inline size_t bwd_smem() { return BWD_POSE * sizeof(float) + sizeof(PoseLds) + 128 * sizeof(float); }
 
 template <bool FUSED>
 void launch_fwd_kernel(const FwdArgs &a, dim3 grid, hipStream_t st)
