@@ -54,6 +54,9 @@ def parse():
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--backbone", default="ResNet18")
+    ap.add_argument("--disp", default="smooth", choices=["smooth", "noise"],
+                    help="hotpath workload: disparity statistics (smooth = like a depth network's "
+                         "output; noise = i.i.d. uniform, worst case for gather locality)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--amp-bf16", dest="amp_bf16", action="store_true",
                     help="bf16 autocast for the conv networks (reduced precision: not the default)")
@@ -111,7 +114,8 @@ class HotPathStep:
         from mono_vifi_amd import layers
         for u in range(UNITS_PER_STEP):
             affine = u >= 6          # the three affine units carry valid_mask_rec
-            inp = synthetic.unit_inputs(1234 + 97 * rank + u, B, H, W, with_mask=affine)
+            inp = synthetic.unit_inputs(1234 + 97 * rank + u, B, H, W, with_mask=affine,
+                                        disp_mode=args.disp)
             aa, tr = t(inp["axisangle"]), t(inp["translation"])
             T = torch.stack([layers.transformation_from_parameters(aa[k], tr[k], invert=(k == 1))
                              for k in range(2)], 0).detach()
@@ -238,7 +242,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}: " + getattr(step, "describe", lambda: (
                 f"{UNITS_PER_STEP} units fwd+bwd, batch {args.batch}/GPU, "
-                f"{args.width}x{args.height}, 2 sources/unit, exact mode"))(),
+                f"{args.width}x{args.height}, 2 sources/unit, exact mode, {args.disp} disparity"))(),
                 "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": dominant,
             "kernels": {"unit_fwd": r_fwd, "unit_bwd": r_bwd},

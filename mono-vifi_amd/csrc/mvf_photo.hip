@@ -68,13 +68,26 @@ MVF_DEV int refl_clamp(int j, int n)
 }
 
 // stage one [H,W] plane into LDS with reflect addressing; plane origin (py0, px0)
+constexpr int NSTAGE = (PH * PW + NT - 1) / NT;   // plane elements per lane (5)
+
+// All global loads of a lane are issued before its first LDS store (fully unrolled,
+// constant trip count): one exposed memory latency per staging phase instead of five.
 MVF_DEV void stage_plane(float *__restrict__ lds, const float *__restrict__ img, int H, int W,
                          int py0, int px0)
 {
-    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
+    float v[NSTAGE];
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        lds[r * LDW + c] = img[(size_t)gy * W + gx];
+        v[it] = img[(unsigned)gy * W + gx];
+    }
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = threadIdx.x + it * NT;
+        int r = idx / PW, c = idx - r * PW;
+        if (idx < PH * PW) lds[r * LDW + c] = v[it];
     }
 }
 
@@ -82,14 +95,24 @@ MVF_DEV void stage_plane(float *__restrict__ lds, const float *__restrict__ img,
 MVF_DEV void stage_planes3(float *__restrict__ lds, const float *__restrict__ img, size_t N, int H,
                            int W, int py0, int px0)
 {
-    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
+    float v[NSTAGE][3];
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        size_t o = (size_t)gy * W + gx;
-        float v0 = img[o], v1 = img[N + o], v2 = img[2 * N + o];
-        lds[r * LDW + c] = v0;
-        lds[PLANE + r * LDW + c] = v1;
-        lds[2 * PLANE + r * LDW + c] = v2;
+        unsigned o = (unsigned)gy * W + gx;
+        v[it][0] = img[o]; v[it][1] = img[N + o]; v[it][2] = img[2 * N + o];
+    }
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = threadIdx.x + it * NT;
+        int r = idx / PW, c = idx - r * PW;
+        if (idx < PH * PW) {
+            lds[r * LDW + c] = v[it][0];
+            lds[PLANE + r * LDW + c] = v[it][1];
+            lds[2 * PLANE + r * LDW + c] = v[it][2];
+        }
     }
 }
 
@@ -265,36 +288,40 @@ MVF_DEV void load_pose_pair(const PoseLds &sh, int ka, int kb, f2 P2[12])
     for (int i = 0; i < 12; ++i) P2[i] = mk2(sh.P[ka][i], sh.P[kb][i]);
 }
 
-// stage two [3,H,W] images interleaved into the 3 pair planes (reflect addressing)
-MVF_DEV void stage_pair3(f2 *__restrict__ pairP, const float *__restrict__ im0,
-                         const float *__restrict__ im1, size_t N, int H, int W, int py0, int px0)
-{
-    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
-        int r = idx / PW, c = idx - r * PW;
-        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        unsigned o = (unsigned)gy * W + gx;
-        float a0 = im0[o], a1 = im0[N + o], a2 = im0[2 * N + o];
-        float b0 = im1[o], b1 = im1[N + o], b2 = im1[2 * N + o];
-        pairP[r * LDW + c] = mk2(a0, b0);
-        pairP[PPLANE + r * LDW + c] = mk2(a1, b1);
-        pairP[2 * PPLANE + r * LDW + c] = mk2(a2, b2);
-    }
-}
-
-// overwrite one lane (0/1) of the pair planes with a staged image
+// overwrite one lane (0/1) of the 3 pair planes with a staged [3,H,W] image (reflect
+// addressing); all 15 loads of a lane are in flight before the first LDS store
 MVF_DEV void stage_lane3(f2 *__restrict__ pairP, int lane, const float *__restrict__ im, size_t N,
                          int H, int W, int py0, int px0)
 {
     float *base = reinterpret_cast<float *>(pairP) + lane;
-    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
+    float v[NSTAGE][3];
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
         unsigned o = (unsigned)gy * W + gx;
-        float a0 = im[o], a1 = im[N + o], a2 = im[2 * N + o];
-        base[2 * (r * LDW + c)] = a0;
-        base[2 * (PPLANE + r * LDW + c)] = a1;
-        base[2 * (2 * PPLANE + r * LDW + c)] = a2;
+        v[it][0] = im[o]; v[it][1] = im[N + o]; v[it][2] = im[2 * N + o];
     }
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = threadIdx.x + it * NT;
+        int r = idx / PW, c = idx - r * PW;
+        if (idx < PH * PW) {
+            base[2 * (r * LDW + c)] = v[it][0];
+            base[2 * (PPLANE + r * LDW + c)] = v[it][1];
+            base[2 * (2 * PPLANE + r * LDW + c)] = v[it][2];
+        }
+    }
+}
+
+// stage two images interleaved into the pair planes (two passes of 15 loads per lane)
+MVF_DEV void stage_pair3(f2 *__restrict__ pairP, const float *__restrict__ im0,
+                         const float *__restrict__ im1, size_t N, int H, int W, int py0, int px0)
+{
+    stage_lane3(pairP, 0, im0, N, H, W, py0, px0);
+    asm volatile("" ::: "memory");   // keep the passes apart: 15 live values, not 30
+    stage_lane3(pairP, 1, im1, N, H, W, py0, px0);
 }
 
 // generate_images_pred for TWO sources at one pixel: the ray, depth and camera point are
@@ -352,8 +379,46 @@ MVF_DEV Taps4 taps_of(const Tap &t, int W)
 }
 
 // fused warp of a source pair into the pair planes: bilinear samples of src_a / src_b at
-// the projected position of every plane pixel (reflect-mapped into the image); all 24 taps
-// of a position are in flight before the first use.
+// the projected position of every plane pixel (reflect-mapped into the image).  Two plane
+// positions are processed per iteration: their projection chains (long dependent sequences
+// of divides) interleave, and all 48 taps are in flight before the first use.
+struct WarpSlot {
+    Taps4 qa, qb;
+    int r, c, x0a, y0a, x0b, y0b;
+    bool live;
+};
+
+MVF_DEV WarpSlot warp_slot(int idx, const float *__restrict__ dispP, const float *__restrict__ iK,
+                           const f2 P2[12], int H, int W, int py0, int px0, float min_disp,
+                           float range, float eps)
+{
+    WarpSlot s;
+    s.live = idx < PH * PW;
+    idx = min(idx, PH * PW - 1);
+    s.r = idx / PW;
+    s.c = idx - s.r * PW;
+    int gy = refl_clamp(py0 + s.r, H), gx = refl_clamp(px0 + s.c, W);
+#ifdef MVF_ABL_NOCHAIN
+    WarpPair w = {};
+#else
+    WarpPair w = warp_point_pair(dispP[s.r * LDW + s.c], iK, P2, gx, gy, H, W, min_disp, range, eps);
+#endif
+    s.qa = taps_of(w.ta, W);
+    s.qb = taps_of(w.tb, W);
+#ifdef MVF_ABL_COALESCED   // ablation: taps at the pixel itself (perfectly coalesced gathers)
+    s.qa.o00 = s.qa.o01 = s.qa.o10 = s.qa.o11 = (unsigned)gy * W + gx;
+    s.qb.o00 = s.qb.o01 = s.qb.o10 = s.qb.o11 = (unsigned)gy * W + gx;
+#endif
+#ifdef MVF_ABL_NOCHAIN     // ablation: no projection chain (taps from the disparity bits)
+    s.qa.o00 = s.qa.o01 = s.qa.o10 = s.qa.o11 = (unsigned)gy * W + gx;
+    s.qb.o00 = s.qb.o01 = s.qb.o10 = s.qb.o11 = (unsigned)gy * W + gx;
+    s.qa.wnw = s.qb.wnw = dispP[s.r * LDW + s.c];
+#endif
+    s.x0a = w.ta.x0; s.y0a = w.ta.y0; s.x0b = w.tb.x0; s.y0b = w.tb.y0;
+    return s;
+}
+
+template <int U>   // plane positions per iteration (1: fewest registers, 2: more overlap)
 MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict__ dispP,
                                 const float *__restrict__ sa, const float *__restrict__ sb,
                                 const float *__restrict__ iK, const f2 P2[12], int H, int W, int py0,
@@ -362,31 +427,45 @@ MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict_
                                 int tx0)
 {
     const size_t N = (size_t)H * W;
-    for (int idx = threadIdx.x; idx < PH * PW; idx += NT) {
-        int r = idx / PW, c = idx - r * PW;
-        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        WarpPair w = warp_point_pair(dispP[r * LDW + c], iK, P2, gx, gy, H, W, min_disp, range, eps);
-        Taps4 qa = taps_of(w.ta, W), qb = taps_of(w.tb, W);
-        float a[3][4], bq[3][4];
+    constexpr int NIT = (NSTAGE + U - 1) / U;
+#pragma unroll 1
+    for (int it = 0; it < NIT; ++it) {
+        WarpSlot s[U];
+        float a[U][3][4], bq[U][3][4];
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            const float *pa = sa + ch * N, *pb = sb + ch * N;
-            a[ch][0] = pa[qa.o00]; a[ch][1] = pa[qa.o01]; a[ch][2] = pa[qa.o10]; a[ch][3] = pa[qa.o11];
-            bq[ch][0] = pb[qb.o00]; bq[ch][1] = pb[qb.o01]; bq[ch][2] = pb[qb.o10]; bq[ch][3] = pb[qb.o11];
-        }
+        for (int u = 0; u < U; ++u)
+            s[u] = warp_slot((int)threadIdx.x + (U * it + u) * NT, dispP, iK, P2, H, W, py0, px0,
+                             min_disp, range, eps);
 #pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            float va = a[ch][0] * qa.wnw + a[ch][1] * qa.wne + a[ch][2] * qa.wsw + a[ch][3] * qa.wse;
-            float vb = bq[ch][0] * qb.wnw + bq[ch][1] * qb.wne + bq[ch][2] * qb.wsw + bq[ch][3] * qb.wse;
-            pairP[ch * PPLANE + r * LDW + c] = mk2(va, vb);
-        }
-        if (idx_a) {
-            // the un-reflected pixels of this tile own their index entry
-            int y = py0 + r, x = px0 + c;
-            if (y >= ty0 && y < min(ty0 + TH, H) && x >= tx0 && x < min(tx0 + TW, W)) {
-                reinterpret_cast<int2 *>(idx_a)[(size_t)y * W + x] = make_int2(w.ta.x0, w.ta.y0);
-                if (idx_b != idx_a)
-                    reinterpret_cast<int2 *>(idx_b)[(size_t)y * W + x] = make_int2(w.tb.x0, w.tb.y0);
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                const float *pa = sa + ch * N, *pb = sb + ch * N;
+                a[u][ch][0] = pa[s[u].qa.o00]; a[u][ch][1] = pa[s[u].qa.o01];
+                a[u][ch][2] = pa[s[u].qa.o10]; a[u][ch][3] = pa[s[u].qa.o11];
+                bq[u][ch][0] = pb[s[u].qb.o00]; bq[u][ch][1] = pb[s[u].qb.o01];
+                bq[u][ch][2] = pb[s[u].qb.o10]; bq[u][ch][3] = pb[s[u].qb.o11];
+            }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!s[u].live) continue;
+            const Taps4 &qa = s[u].qa, &qb = s[u].qb;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                float va = a[u][ch][0] * qa.wnw + a[u][ch][1] * qa.wne + a[u][ch][2] * qa.wsw +
+                           a[u][ch][3] * qa.wse;
+                float vb = bq[u][ch][0] * qb.wnw + bq[u][ch][1] * qb.wne + bq[u][ch][2] * qb.wsw +
+                           bq[u][ch][3] * qb.wse;
+                pairP[ch * PPLANE + s[u].r * LDW + s[u].c] = mk2(va, vb);
+            }
+            if (idx_a) {
+                // the un-reflected pixels of this tile own their index entry
+                int y = py0 + s[u].r, x = px0 + s[u].c;
+                if (y >= ty0 && y < min(ty0 + TH, H) && x >= tx0 && x < min(tx0 + TW, W)) {
+                    reinterpret_cast<int2 *>(idx_a)[(size_t)y * W + x] = make_int2(s[u].x0a, s[u].y0a);
+                    if (idx_b != idx_a)
+                        reinterpret_cast<int2 *>(idx_b)[(size_t)y * W + x] = make_int2(s[u].x0b, s[u].y0b);
+                }
             }
         }
     }
@@ -409,7 +488,7 @@ constexpr int FWD_TGT = 0, FWD_PAIR = 3 * PLANE, FWD_DISP = FWD_PAIR + 6 * PLANE
               FWD_POSE = FWD_DISP + PLANE;
 
 #ifndef MVF_FWD_WAVES
-#define MVF_FWD_WAVES 1
+#define MVF_FWD_WAVES 3   // <=168 VGPRs: 3 waves/SIMD, matching the 3 workgroups/CU the 49 KB of LDS allow
 #endif
 #ifndef MVF_BWD_WAVES
 #define MVF_BWD_WAVES 1
@@ -454,23 +533,32 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
     constexpr int NC = 2 * S;
     float val[NC][PX];
     const int ncand = automask ? 2 * S : S;
+#ifdef MVF_ABL_ONEPAIR
+    const int npair = 1;
+#else
     const int npair = (ncand + 1) >> 1;
+#endif
 #pragma unroll 1
     for (int pr = 0; pr < npair; ++pr) {
         const int ca = 2 * pr, cb = (2 * pr + 1 < ncand) ? 2 * pr + 1 : 2 * pr;
         const bool wa = ca < S, wb = cb < S;              // warped (vs identity) candidates
         const int ka = wa ? ca : ca - S, kb = wb ? cb : cb - S;
         __syncthreads();   // previous pair fully consumed
+#ifdef MVF_ABL_NOWARP
+        if (false) {
+            if (wa) {
+#else
         if (FUSED) {
             if (wa) {
+#endif
                 // lane 0 (and lane 1 when it is a warped source too) by the fused warp
                 f2 P2[12];
                 const int kb2 = wb ? kb : ka;
                 load_pose_pair(sh, ka, kb2, P2);
                 int32_t *ia = a.idx_xy ? a.idx_xy + ((size_t)ka * a.B + b) * N * 2 : nullptr;
                 int32_t *ib = a.idx_xy ? a.idx_xy + ((size_t)kb2 * a.B + b) * N * 2 : nullptr;
-                warp_pair_into_lds(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
-                                   a.src.p[kb2] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0,
+                warp_pair_into_lds<1>(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
+                                      a.src.p[kb2] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0,
                                    px0, a.min_disp, a.range, a.eps, ia, ib, ty0, tx0);
                 if (!wb) stage_lane3(pairP, 1, a.src.p[kb] + (size_t)b * 3 * N, N, H, W, py0, px0);
             } else {
@@ -478,13 +566,25 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
                             H, W, py0, px0);
             }
         } else {
+#ifdef MVF_ABL_NOWARP
+            const float *ima = a.src.p[ka] + (size_t)b * 3 * N;
+            const float *imb = a.src.p[kb] + (size_t)b * 3 * N;
+#else
             const float *ima = (wa ? a.warped.p[ka] : a.src.p[ka]) + (size_t)b * 3 * N;
             const float *imb = (wb ? a.warped.p[kb] : a.src.p[kb]) + (size_t)b * 3 * N;
+#endif
             stage_pair3(pairP, ima, imb, N, H, W, py0, px0);
         }
         __syncthreads();
         f2 out[PX];
+#ifdef MVF_ABL_NOREPROJ
+        {
+            f2 t = pairP[off + LDW + 1] + f2s(tgtP[off + LDW + 1]);
+            for (int j = 0; j < PX; ++j) out[j] = t;
+        }
+#else
         reproj4p(pairP, tgtP, off, no_ssim, out);
+#endif
 #pragma unroll
         for (int cc = 0; cc < NC; ++cc)     // static register indices only
 #pragma unroll
@@ -545,6 +645,7 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
             if (a.auto_mask) a.auto_mask[pi] = (bi > n_id - 1) ? 1.0f : 0.0f;
             if (a.to_opt) a.to_opt[pi] = best;
             photo += best;
+#ifndef MVF_ABL_NOSMOOTH
             // ---- edge-aware smoothness (reference: layers.py:231-242 on disp/(mean+1e-7))
             const float *dc = dispP + (row + 1) * LDW + seg * PX + 1 + j;
             const float *t0 = tgtP + (row + 1) * LDW + seg * PX + 1 + j;
@@ -561,6 +662,7 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
                                 fabsf(t0[2 * PLANE] - t0[2 * PLANE + LDW]));
                 sy += gd * expf(-gi);
             }
+#endif
         }
     }
     float *part = a.ws + (size_t)a.B * NMEAN +
@@ -745,8 +847,8 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         f2 P2[12];
         if (FUSED) {
             load_pose_pair(sh, ka, kb, P2);
-            warp_pair_into_lds(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
-                               a.src.p[kb] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0, px0,
+            warp_pair_into_lds<2>(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
+                                  a.src.p[kb] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0, px0,
                                a.min_disp, a.range, a.eps, nullptr, nullptr, 0, 0);
         } else {
             stage_pair3(pairP, a.warped.p[ka] + (size_t)b * 3 * N, a.warped.p[kb] + (size_t)b * 3 * N, N,
@@ -777,7 +879,11 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
                 Row6 yr = load_row6(yp + off + LDW);
 #pragma unroll
                 for (int j = 0; j < PX; ++j) { xq[j] = xr.v[j + 1]; yq[j] = yr.v[j + 1]; }
+#ifdef MVF_ABL_NOSTATS
+            } else if (false) {
+#else
             } else {
+#endif
                 Stats4P s;
                 window_xp(xp + off, yp + off, s);
                 f2 cA[PX], cB[PX], cG[PX];
@@ -813,7 +919,11 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
                             (df.y > 0.0f) ? -1.0f : ((df.y < 0.0f) ? 1.0f : 0.0f));
                 gw[j] = wk[j] * (no_ssim ? 1.0f : 0.15f) * sg / 3.0f;
             }
+#ifdef MVF_ABL_NOGATHER
+            if (false) {
+#else
             if (!no_ssim && row >= 1 && row <= OH) {
+#endif
                 f2 sA[PX], sB[PX], sG[PX];
 #pragma unroll
                 for (int j = 0; j < PX; ++j) sA[j] = sB[j] = sG[j] = f2s(0.0f);
@@ -880,8 +990,14 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
             f2 accP[12];
 #pragma unroll
             for (int q = 0; q < 12; ++q) accP[q] = f2s(0.0f);
-#pragma unroll 1
+#ifndef MVF_CHAIN_UNROLL
+#define MVF_CHAIN_UNROLL 4
+#endif
+#pragma unroll MVF_CHAIN_UNROLL
             for (int j = 0; j < PX; ++j) {
+#ifdef MVF_ABL_NOCHAINB
+                continue;
+#endif
                 const int x = x0 + j, col = seg * PX + j;
                 const bool outp = row_out && (col >= 1) && (col <= OW) && (x >= 0) && (x < W);
                 if (!outp) continue;

@@ -69,9 +69,36 @@ def triplet_images(rng, batch, height, width, shift=2, noise=0.01):
     return tgt, srcs
 
 
+def smooth_field(rng, batch, height, width, cells=(6, 20), lo=0.05, hi=0.95):
+    """Piecewise-smooth field in [lo, hi]: a coarse random grid, bilinearly upsampled, plus a
+    vertical ramp (near ground at the bottom of the image) -- the statistics of a depth
+    network's sigmoid output, for which neighbouring pixels sample neighbouring source
+    positions (coalesced bilinear taps)."""
+    gh, gw = cells
+    coarse = rng.random((batch, gh + 1, gw + 1)).astype(np.float32)
+    ys = np.linspace(0, gh, height, dtype=np.float32)
+    xs = np.linspace(0, gw, width, dtype=np.float32)
+    y0 = np.minimum(ys.astype(np.int64), gh - 1)
+    x0 = np.minimum(xs.astype(np.int64), gw - 1)
+    fy = (ys - y0)[None, :, None]
+    fx = (xs - x0)[None, None, :]
+    c00 = coarse[:, y0][:, :, x0]
+    c01 = coarse[:, y0][:, :, x0 + 1]
+    c10 = coarse[:, y0 + 1][:, :, x0]
+    c11 = coarse[:, y0 + 1][:, :, x0 + 1]
+    f = (c00 * (1 - fy) * (1 - fx) + c01 * (1 - fy) * fx + c10 * fy * (1 - fx) + c11 * fy * fx)
+    ramp = np.linspace(0.0, 1.0, height, dtype=np.float32)[None, :, None]
+    f = 0.6 * f + 0.4 * ramp
+    return (lo + (hi - lo) * f).astype(np.float32)[:, None]
+
+
 def unit_inputs(seed, batch, height, width, num_src=2, pose_scale=0.01,
-                with_mask=False, disp_lo=0.0, disp_hi=1.0):
+                with_mask=False, disp_lo=0.0, disp_hi=1.0, disp_mode="noise"):
     """All tensors one hot-path *unit* consumes (1 target, ``num_src`` sources).
+
+    ``disp_mode``: "noise" = i.i.d. uniform disparity (adversarial for
+    the bilinear gather: neighbouring pixels sample positions up to ~40 px apart), "smooth" =
+    a piecewise-smooth field like a depth network emits.
 
     Keys: disp [B,1,H,W]; tgt [B,3,H,W]; src [S,B,3,H,W]; axisangle,
     translation [S,B,1,3] (PoseDecoder scale 0.01, reference: networks/posenet.py:132);
@@ -86,6 +113,10 @@ def unit_inputs(seed, batch, height, width, num_src=2, pose_scale=0.01,
     srcs = srcs[:num_src]
     disp = (np.float32(disp_lo) + np.float32(disp_hi - disp_lo)
             * rng.random((batch, 1, height, width), dtype=np.float32)).astype(np.float32)
+    if disp_mode == "smooth":     # drawn AFTER the noise field so the other streams are unchanged
+        disp = smooth_field(np.random.default_rng(seed + 7777), batch, height, width)
+    elif disp_mode != "noise":
+        raise ValueError(disp_mode)
     axisangle = (pose_scale * rng.standard_normal((num_src, batch, 1, 3))).astype(np.float32)
     translation = (pose_scale * rng.standard_normal((num_src, batch, 1, 3))).astype(np.float32)
     K, inv_K = kitti_intrinsics(batch, height, width)
