@@ -169,6 +169,21 @@ MVF_API int mvf_pose_fwd(const float *axisangle, const float *translation, float
 MVF_API int mvf_pose_bwd(const float *axisangle, const float *translation, const float *g_M,
                  float *g_axisangle, float *g_translation, int invert, int B, void *stream);
 
+/* ---- f1: flow warp -- IFRNet.warp (networks/IFRNet.py:7-15) and
+ * FusionModule.warp_features (networks/fusion_module.py:80-90).  out[b,c,y,x] = bilinear /
+ * border / align_corners=True sample of img[b,c] at grid = (xs[x] + flow_x/((W-1)/2),
+ * ys[y] + flow_y/((H-1)/2)); xs = linspace(-1,1,W), ys = linspace(-1,1,H) are passed in so
+ * that they are the reference's own fp32 values.  img [B,C,H,W], flow [B,2,H,W] (pixels).
+ * idx_xy nullable int32 [B,H,W,2]; out nullable. */
+MVF_API int mvf_flow_warp_fwd(const float *img, const float *flow, const float *xs, const float *ys,
+                      float *out, int32_t *idx_xy, int B, int C, int H, int W, void *stream);
+/* g_img nullable, zero-initialised by the caller (scatter-add); g_flow nullable [B,2,H,W]
+ * (needs workspace of mvf_flow_warp_workspace_floats floats). */
+MVF_API int mvf_flow_warp_bwd(const float *img, const float *flow, const float *xs, const float *ys,
+                      const float *g_out, float *g_img, float *g_flow, float *workspace, int B, int C,
+                      int H, int W, void *stream);
+MVF_API size_t mvf_flow_warp_workspace_floats(int B, int C, int H, int W);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------
  * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
  * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded

@@ -49,12 +49,16 @@ _SIGNATURES = {
                      _vp, _vp, _i, _i, _i, _vp],
     "mvf_pose_fwd": [_vp, _vp, _vp, _i, _i, _vp],
     "mvf_pose_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "mvf_flow_warp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_flow_warp_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_flow_warp_workspace_floats": [_i, _i, _i, _i],
     "mvf_profile_enable": [_i],
     "mvf_profile_reset": [],
     "mvf_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
 }
 PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD = range(6)
-_RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t}
+_RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t,
+            "mvf_flow_warp_workspace_floats": C.c_size_t}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -267,6 +267,90 @@ __global__ void __launch_bounds__(NT) k_grid_sample_bwd(const float *__restrict_
             make_float2(t.inx ? gx * sx : 0.0f, t.iny ? gy * sy : 0.0f);
 }
 
+// ---------------------------------------------------------------- f1 flow warp
+// IFRNet.warp / FusionModule.warp_features (reference: networks/IFRNet.py:7-15,
+// networks/fusion_module.py:80-90): grid = linspace(-1,1) + flow / ((size-1)/2), then the same
+// bilinear / border / align_corners=True gather as a4.  xs[W], ys[H] are the linspace values
+// (passed in so that they are the reference's own fp32 values).  One lane per pixel, CCH
+// channels per lane: the tap is computed once and reused by every channel of the chunk.
+constexpr int FW_CCH = 8;
+
+MVF_DEV Tap flow_tap(const float *__restrict__ flow, const float *__restrict__ xs,
+                     const float *__restrict__ ys, int b, int i, int x, int y, int H, int W)
+{
+    size_t N = (size_t)H * W;
+    float fx = flow[((size_t)b * 2 + 0) * N + i], fy = flow[((size_t)b * 2 + 1) * N + i];
+    float gx = xs[x] + fx / (((float)W - 1.0f) / 2.0f);
+    float gy = ys[y] + fy / (((float)H - 1.0f) / 2.0f);
+    return tap_of(gx, gy, H, W);
+}
+
+__global__ void __launch_bounds__(NT) k_flow_warp_fwd(const float *__restrict__ img,
+                                                      const float *__restrict__ flow,
+                                                      const float *__restrict__ xs,
+                                                      const float *__restrict__ ys,
+                                                      float *__restrict__ out,
+                                                      int32_t *__restrict__ idx_xy, int C, int H, int W)
+{
+    int N = H * W, b = blockIdx.z;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    int y = i / W, x = i - y * W;
+    Tap t = flow_tap(flow, xs, ys, b, i, x, y, H, W);
+    if (idx_xy && blockIdx.y == 0)
+        reinterpret_cast<int2 *>(idx_xy)[(size_t)b * N + i] = make_int2(t.x0, t.y0);
+    if (!out) return;
+    int c0 = blockIdx.y * FW_CCH, c1 = min(c0 + FW_CCH, C);
+    for (int c = c0; c < c1; ++c)
+        out[((size_t)b * C + c) * N + i] = bilerp(img + ((size_t)b * C + c) * N, W, t);
+}
+
+__global__ void __launch_bounds__(NT) k_flow_warp_bwd(const float *__restrict__ img,
+                                                      const float *__restrict__ flow,
+                                                      const float *__restrict__ xs,
+                                                      const float *__restrict__ ys,
+                                                      const float *__restrict__ g_out,
+                                                      float *__restrict__ g_img,
+                                                      float *__restrict__ g_flow_part, int C, int H,
+                                                      int W)
+{
+    int N = H * W, b = blockIdx.z;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    int y = i / W, x = i - y * W;
+    Tap t = flow_tap(flow, xs, ys, b, i, x, y, H, W);
+    int c0 = blockIdx.y * FW_CCH, c1 = min(c0 + FW_CCH, C);
+    float gx = 0.0f, gy = 0.0f;
+    for (int c = c0; c < c1; ++c) {
+        float go = g_out[((size_t)b * C + c) * N + i];
+        if (g_img) scatter_taps(g_img + ((size_t)b * C + c) * N, W, t, go);
+        if (g_flow_part) {
+            float dx, dy;
+            bilerp_grad(img + ((size_t)b * C + c) * N, W, t, dx, dy);
+            gx += go * dx;
+            gy += go * dy;
+        }
+    }
+    if (g_flow_part) {
+        // d(ix)/d(flow_x) = ((W-1)/2) / ((W-1)/2) = 1 where the coordinate was not clipped;
+        // chunk partials are summed by the caller-visible second pass (k_flow_grad_fold)
+        size_t o = (((size_t)blockIdx.y * gridDim.z + b) * 2) * N + i;
+        g_flow_part[o] = t.inx ? gx : 0.0f;
+        g_flow_part[o + N] = t.iny ? gy : 0.0f;
+    }
+}
+
+// g_flow[b,2,N] = sum over channel chunks of the partials (fixed order)
+__global__ void __launch_bounds__(NT) k_flow_grad_fold(const float *__restrict__ part,
+                                                       float *__restrict__ g_flow, int nchunk, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.0f;
+    for (int k = 0; k < nchunk; ++k) s += part[(size_t)k * n + i];
+    g_flow[i] = s;
+}
+
 // ---------------------------------------------------------------- a5 fused warp
 __global__ void __launch_bounds__(NT) k_warp_fwd(const float *__restrict__ disp,
                                                  const float *__restrict__ invK,
@@ -689,6 +773,38 @@ int mvf_warp_bwd(const float *disp, const float *inv_K, const float *K, const fl
     }
     hipLaunchKernelGGL(k_finish_gT, dim3(B, 1), dim3(NT), 0, (hipStream_t)stream, workspace, K,
                        g_T, (int)grid.x);
+    return hip_check_launch();
+}
+
+int mvf_flow_warp_fwd(const float *img, const float *flow, const float *xs, const float *ys,
+                      float *out, int32_t *idx_xy, int B, int C, int H, int W, void *stream)
+{
+    if (B * C * H * W <= 0) return 0;
+    dim3 grid((unsigned)((H * W + NT - 1) / NT), (unsigned)((C + FW_CCH - 1) / FW_CCH), (unsigned)B);
+    hipLaunchKernelGGL(k_flow_warp_fwd, grid, dim3(NT), 0, (hipStream_t)stream, img, flow, xs, ys, out,
+                       idx_xy, C, H, W);
+    return hip_check_launch();
+}
+
+size_t mvf_flow_warp_workspace_floats(int B, int C, int H, int W)
+{
+    return (size_t)((C + FW_CCH - 1) / FW_CCH) * B * 2 * H * W;
+}
+
+int mvf_flow_warp_bwd(const float *img, const float *flow, const float *xs, const float *ys,
+                      const float *g_out, float *g_img, float *g_flow, float *workspace, int B, int C,
+                      int H, int W, void *stream)
+{
+    if (B * C * H * W <= 0) return 0;
+    const int nchunk = (C + FW_CCH - 1) / FW_CCH;
+    dim3 grid((unsigned)((H * W + NT - 1) / NT), (unsigned)nchunk, (unsigned)B);
+    hipLaunchKernelGGL(k_flow_warp_bwd, grid, dim3(NT), 0, (hipStream_t)stream, img, flow, xs, ys,
+                       g_out, g_img, g_flow ? workspace : nullptr, C, H, W);
+    if (g_flow) {
+        size_t n = (size_t)B * 2 * H * W;
+        hipLaunchKernelGGL(k_flow_grad_fold, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
+                           (hipStream_t)stream, workspace, g_flow, nchunk, n);
+    }
     return hip_check_launch();
 }
 

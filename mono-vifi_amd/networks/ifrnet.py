@@ -11,16 +11,22 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+def _hip_flow_warp(img, flow):
+    from .. import ops
+    return ops.flow_warp(img, flow).to(img.dtype)
+
+
+# The warp implementation is a module attribute so that the CPU-only comparison against the
+# reference's modules (tests/test_networks_vs_reference.py) can inject a torch restatement;
+# the product default is the gfx950 kernel (no CPU fallback).
+WARP_IMPL = _hip_flow_warp
+
+
 def warp(img, flow):
     """Backward-warp ``img`` by a pixel-unit flow field with the same bilinear / border /
-    align_corners=True gather the depth path uses (reference: IFRNet.py:7-15)."""
-    B, _, H, W = flow.shape
-    xs = torch.linspace(-1.0, 1.0, W, device=flow.device, dtype=flow.dtype).view(1, 1, 1, W)
-    ys = torch.linspace(-1.0, 1.0, H, device=flow.device, dtype=flow.dtype).view(1, 1, H, 1)
-    gx = xs + flow[:, 0:1] / ((W - 1.0) / 2.0)
-    gy = ys + flow[:, 1:2] / ((H - 1.0) / 2.0)
-    grid = torch.cat([gx, gy], 1).permute(0, 2, 3, 1)
-    return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
+    align_corners=True gather the depth path uses (reference: IFRNet.py:7-15); runs as the
+    ``mvf_flow_warp`` kernels."""
+    return WARP_IMPL(img, flow)
 
 
 def resize(x, scale_factor):

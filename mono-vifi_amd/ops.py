@@ -444,3 +444,68 @@ class Pose(torch.autograd.Function):
         nat.check(nat.lib().mvf_pose_bwd(nat.ptr(aa), nat.ptr(tr), nat.ptr(gM), nat.ptr(g_aa),
                                          nat.ptr(g_tr), invert, aa.shape[0], _stream()), "pose_bwd")
         return g_aa.reshape(sa), g_tr.reshape(st), None
+
+
+# ------------------------------------------------------------------ f1 flow warp
+_LINSPACE = {}
+
+
+def _linspace(n, device):
+    """torch.linspace(-1, 1, n) evaluated on the CPU (the reference builds its base grid
+    there, networks/IFRNet.py:9-10) and cached per device."""
+    key = (n, str(device))
+    t = _LINSPACE.get(key)
+    if t is None:
+        t = torch.linspace(-1.0, 1.0, n).to(device)
+        _LINSPACE[key] = t
+    return t
+
+
+class FlowWarp(torch.autograd.Function):
+    """IFRNet.warp(img, flow); reference: networks/IFRNet.py:7-15"""
+
+    @staticmethod
+    def forward(ctx, img, flow):
+        nat.require_device(img, flow)
+        img, flow = _c(img), _c(flow)
+        B, Cc, H, W = img.shape
+        if tuple(flow.shape) != (B, 2, H, W):
+            raise RuntimeError(f"flow must be [B,2,H,W] matching img, got {tuple(flow.shape)}")
+        xs, ys = _linspace(W, img.device), _linspace(H, img.device)
+        out = torch.empty_like(img)
+        nat.check(nat.lib().mvf_flow_warp_fwd(nat.ptr(img), nat.ptr(flow), nat.ptr(xs), nat.ptr(ys),
+                                              nat.ptr(out), None, B, Cc, H, W, _stream()), "flow_warp")
+        ctx.save_for_backward(img, flow, xs, ys)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        img, flow, xs, ys = ctx.saved_tensors
+        B, Cc, H, W = img.shape
+        g_out = _c(g_out)
+        g_img = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        g_flow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
+        ws = None
+        if g_flow is not None:
+            n = nat.lib().mvf_flow_warp_workspace_floats(B, Cc, H, W)
+            ws = torch.empty(n, dtype=torch.float32, device=img.device)
+        nat.check(nat.lib().mvf_flow_warp_bwd(nat.ptr(img), nat.ptr(flow), nat.ptr(xs), nat.ptr(ys),
+                                              nat.ptr(g_out), nat.ptr(g_img), nat.ptr(g_flow),
+                                              nat.ptr(ws), B, Cc, H, W, _stream()), "flow_warp_bwd")
+        return g_img, g_flow
+
+
+def flow_warp(img, flow):
+    return FlowWarp.apply(img, flow)
+
+
+def flow_warp_indices(img_shape, flow):
+    """int32 [B,H,W,2] top-left taps of the flow warp (parity tests)."""
+    nat.require_device(flow)
+    B, Cc, H, W = img_shape
+    flow = _c(flow)
+    idx = torch.empty((B, H, W, 2), dtype=torch.int32, device=flow.device)
+    nat.check(nat.lib().mvf_flow_warp_fwd(None, nat.ptr(flow), nat.ptr(_linspace(W, flow.device)),
+                                          nat.ptr(_linspace(H, flow.device)), None, nat.ptr(idx), B, Cc,
+                                          H, W, _stream()), "flow_warp(idx)")
+    return idx

@@ -810,3 +810,72 @@ MVFO_API void mvfo_pose(const float *axisangle, const float *translation, int in
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------
+ * f1: IFRNet.warp / FusionModule.warp_features.  reference: networks/IFRNet.py:7-15
+ * (called from networks/fusion_module.py:80-90 and IFRNet.py:215-250,428-429).
+ * grid = linspace(-1,1) + flow / ((size-1)/2) ; then grid_sample(border, align_corners).
+ * xs[W], ys[H]: the linspace values (torch.linspace on the CPU), passed in.
+ * ---------------------------------------------------------------------------------- */
+static inline tap_t flow_tap(const float *flow, const float *xs, const float *ys, int b, long i,
+                             int x, int y, int H, int W)
+{
+    long N = (long)H * W;
+    float fx = flow[((long)b * 2 + 0) * N + i], fy = flow[((long)b * 2 + 1) * N + i];
+    float gx = xs[x] + fx / (((float)W - 1.0f) / 2.0f);
+    float gy = ys[y] + fy / (((float)H - 1.0f) / 2.0f);
+    return tap_of(gx, gy, H, W);
+}
+
+MVFO_API void mvfo_flow_warp(const float *img, const float *flow, const float *xs, const float *ys,
+                             float *out, int32_t *x0, int32_t *y0, int B, int C, int H, int W)
+{
+    long N = (long)H * W;
+    for (int b = 0; b < B; ++b) {
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                long i = (long)y * W + x;
+                tap_t t = flow_tap(flow, xs, ys, b, i, x, y, H, W);
+                if (x0) x0[b * N + i] = t.x0;
+                if (y0) y0[b * N + i] = t.y0;
+                if (out)
+                    for (int c = 0; c < C; ++c)
+                        out[((long)b * C + c) * N + i] = bilerp(img + ((long)b * C + c) * N, W, &t);
+            }
+    }
+}
+
+/* grads w.r.t. img (scatter-add, g_img zero-initialised by the caller) and flow */
+MVFO_API void mvfo_flow_warp_bwd(const float *img, const float *flow, const float *xs, const float *ys,
+                                 const float *gout, float *g_img, float *g_flow, int B, int C, int H,
+                                 int W)
+{
+    long N = (long)H * W;
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                long i = (long)y * W + x;
+                tap_t t = flow_tap(flow, xs, ys, b, i, x, y, H, W);
+                float w = t.wx, e = 1.0f - w, n = t.wy, s = 1.0f - n;
+                float gx = 0.f, gy = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    float g = gout[((long)b * C + c) * N + i];
+                    if (g_img) {
+                        float *gi = g_img + ((long)b * C + c) * N;
+                        gi[t.y0 * W + t.x0] += g * (s * e);
+                        gi[t.y0 * W + t.x1] += g * (s * w);
+                        gi[t.y1 * W + t.x0] += g * (n * e);
+                        gi[t.y1 * W + t.x1] += g * (n * w);
+                    }
+                    float dx, dy;
+                    bilerp_grad(img + ((long)b * C + c) * N, W, &t, &dx, &dy);
+                    gx += g * dx;
+                    gy += g * dy;
+                }
+                if (g_flow) {
+                    g_flow[((long)b * 2 + 0) * N + i] = t.inx ? gx : 0.0f;
+                    g_flow[((long)b * 2 + 1) * N + i] = t.iny ? gy : 0.0f;
+                }
+            }
+}

@@ -254,3 +254,24 @@ def unit(disp, tgt, src, T, K, inv_K, noise=None, mask_rec=None, flags=0,
         gdisp = smooth_bwd(disp, tgt, gloss * smoothness, True, gdisp)
         out.update(grad_disp=gdisp, grad_T=np.stack(gT, 0), grad_warped=gw)
     return out
+
+
+def flow_warp(img, flow, xs, ys, want_idx=False):
+    """IFRNet.warp (reference networks/IFRNet.py:7-15); xs/ys = torch.linspace(-1,1,size)."""
+    img, flow, xs, ys = _f(img), _f(flow), _f(xs), _f(ys)
+    B, Cc, H, W = img.shape
+    out = np.empty_like(img)
+    x0 = np.empty((B, H, W), np.int32)
+    y0 = np.empty((B, H, W), np.int32)
+    lib().mvfo_flow_warp(_p(img), _p(flow), _p(xs), _p(ys), _p(out), _pi(x0), _pi(y0), B, Cc, H, W)
+    return (out, x0, y0) if want_idx else out
+
+
+def flow_warp_bwd(img, flow, xs, ys, gout):
+    img, flow, xs, ys, gout = _f(img), _f(flow), _f(xs), _f(ys), _f(gout)
+    B, Cc, H, W = img.shape
+    g_img = np.zeros_like(img)
+    g_flow = np.empty_like(flow)
+    lib().mvfo_flow_warp_bwd(_p(img), _p(flow), _p(xs), _p(ys), _p(gout), _p(g_img), _p(g_flow),
+                             B, Cc, H, W)
+    return g_img, g_flow

@@ -59,3 +59,26 @@ def assert_grad_close(a, b, tol=1e-4, what="grad"):
     mx = rel_err(a, b)
     assert l2 <= tol, f"{what}: relative L2 error {l2:.3e} > {tol}"
     assert mx <= 10 * tol, f"{what}: max error {mx:.3e} of tensor max > {10 * tol}"
+
+
+def torch_flow_warp(img, flow):
+    """Test-only torch restatement of the reference's IFRNet.warp (networks/IFRNet.py:7-15),
+    injected into mono_vifi_amd.networks.ifrnet.WARP_IMPL by the CPU tests that compare the
+    network restatements with the reference's modules (the product uses the HIP kernel)."""
+    import torch
+    import torch.nn.functional as F
+    B, _, H, W = flow.shape
+    xs = torch.linspace(-1.0, 1.0, W).view(1, 1, 1, W).to(flow)
+    ys = torch.linspace(-1.0, 1.0, H).view(1, 1, H, 1).to(flow)
+    gx = xs + flow[:, 0:1] / ((W - 1.0) / 2.0)
+    gy = ys + flow[:, 1:2] / ((H - 1.0) / 2.0)
+    grid = torch.cat([gx.expand(B, 1, H, W), gy.expand(B, 1, H, W)], 1).permute(0, 2, 3, 1)
+    return F.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=True)
+
+
+@pytest.fixture
+def cpu_warp(monkeypatch):
+    from mono_vifi_amd.networks import ifrnet
+    monkeypatch.setattr(ifrnet, "WARP_IMPL", torch_flow_warp)
+    import mono_vifi_amd.networks.fusion_module as fm
+    return ifrnet

@@ -396,9 +396,34 @@ def g6_ssim_smooth():
          disp=inp["disp"], smooth=sm, grad_disp=disp.grad)
 
 
+# ----------------------------------------------------------------------------- G7 (flow warp, f1)
+def g7_flow_warp():
+    sys.modules.pop("networks", None)
+    pkg = types.ModuleType("networks")
+    pkg.__path__ = [os.path.join(REF, "networks")]
+    sys.modules["networks"] = pkg
+    import importlib
+    ifr = importlib.import_module("networks.IFRNet")
+    rng = np.random.default_rng(700)
+    for name, (B, C, H, W, scale) in {"a": (2, 5, 24, 40, 3.0), "b": (1, 16, 6, 20, 1.5),
+                                       "big": (2, 3, 48, 64, 40.0)}.items():
+        img = rng.random((B, C, H, W)).astype(np.float32)
+        flow = (scale * rng.standard_normal((B, 2, H, W))).astype(np.float32)
+        wgt = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        ti, tf = t(img).clone().requires_grad_(True), t(flow).clone().requires_grad_(True)
+        out = ifr.warp(ti, tf)
+        (out * t(wgt)).sum().backward()
+        xs, ys = torch.linspace(-1.0, 1.0, W), torch.linspace(-1.0, 1.0, H)
+        gx = xs.view(1, 1, W) + tf.detach()[:, 0] / ((W - 1.0) / 2.0)
+        gy = ys.view(1, H, 1) + tf.detach()[:, 1] / ((H - 1.0) / 2.0)
+        x0, y0 = index_maps(torch.stack([gx, gy], -1), H, W)
+        save("g7_flow_" + name, img=img, flow=flow, weight=wgt, xs=xs, ys=ys, out=out, x0=x0, y0=y0,
+             grad_img=ti.grad, grad_flow=tf.grad)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     fns = dict(g1=g1_geometry, g2=g2_photometric, g3=g3_gradients, g4=g4_fullsize,
-               g5=g5_pose, g6=g6_ssim_smooth)
+               g5=g5_pose, g6=g6_ssim_smooth, g7=g7_flow_warp)
     for w in which:
         fns[w]()

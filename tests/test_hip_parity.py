@@ -343,3 +343,39 @@ def test_error_behaviour(dev):
         bp(torch.rand(3, 1, 8, 8, device=dev), torch.eye(4, device=dev).repeat(3, 1, 1))
     with pytest.raises(RuntimeError):   # no CPU fallback
         layers.SSIM()(torch.rand(1, 3, 8, 8), torch.rand(1, 3, 8, 8))
+
+
+# ------------------------------------------------------------------ f1: flow warp (G7)
+@pytest.mark.parametrize("case", ["a", "b", "big"])
+def test_flow_warp(dev, case):
+    from mono_vifi_amd import ops
+    g = load_golden("g7_flow_" + case)
+    assert np.array_equal(N(ops._linspace(g["img"].shape[3], dev)), g["xs"])
+    img, flow = T(g["img"], dev, True), T(g["flow"], dev, True)
+    out = ops.flow_warp(img, flow)
+    idx = N(ops.flow_warp_indices(g["img"].shape, flow.detach()))
+    assert np.array_equal(idx[..., 0], g["x0"]) and np.array_equal(idx[..., 1], g["y0"])
+    assert np.max(np.abs(N(out) - g["out"])) <= 1e-6
+    (out * T(g["weight"], dev)).sum().backward()
+    assert rel_err(N(img.grad), g["grad_img"]) <= 1e-5
+    assert rel_err(N(flow.grad), g["grad_flow"]) <= 1e-5
+
+
+def test_flow_warp_feature_pyramid_vs_oracle(dev):
+    """Feature-pyramid shapes of the fusion module (64..512 channels, 96x320 .. 6x20)."""
+    from mono_vifi_amd import ops
+    rng = np.random.default_rng(71)
+    for (C, H, W) in ((64, 96, 320), (128, 24, 80), (512, 6, 20), (3, 192, 640)):
+        img = rng.random((2, C, H, W)).astype(np.float32)
+        flow = (4 * rng.standard_normal((2, 2, H, W))).astype(np.float32)
+        wgt = rng.standard_normal((2, C, H, W)).astype(np.float32)
+        xs, ys = N(ops._linspace(W, dev)), N(ops._linspace(H, dev))
+        ref, x0, y0 = O.flow_warp(img, flow, xs, ys, want_idx=True)
+        ti = T(img, dev, True)
+        out = ops.flow_warp(ti, T(flow, dev))
+        idx = N(ops.flow_warp_indices(img.shape, T(flow, dev)))
+        assert np.array_equal(idx[..., 0], x0) and np.array_equal(idx[..., 1], y0)
+        assert np.max(np.abs(N(out) - ref)) <= 1e-6
+        (out * T(wgt, dev)).sum().backward()
+        g_img, _ = O.flow_warp_bwd(img, flow, xs, ys, wgt)
+        assert rel_err(N(ti.grad), g_img) <= 1e-5

@@ -55,7 +55,7 @@ def test_network_state_dict_keys_match_reference_layout():
     assert "decoder4.convblock.1.conv2.0.weight" in IFRNet("small").state_dict()
 
 
-def test_networks_forward_shapes():
+def test_networks_forward_shapes(cpu_warp):
     from types import SimpleNamespace
     from mono_vifi_amd.networks import FusionModule, IFRNet, monodepth2, posenet
     x = torch.rand(2, 3, 64, 96)

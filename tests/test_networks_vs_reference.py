@@ -74,7 +74,7 @@ def test_pose_decoder(ref):
 
 
 @pytest.mark.parametrize("scale", ["small", "large"])
-def test_ifrnet(ref, scale):
+def test_ifrnet(ref, scale, cpu_warp):
     from mono_vifi_amd.networks import IFRNet
     torch.manual_seed(2)
     theirs = ref["IFRNet"].IFRNet(scale).eval()
@@ -93,7 +93,7 @@ def test_ifrnet(ref, scale):
     assert torch.allclose(ref["IFRNet"].warp(f, fl), warp(f, fl), atol=1e-6)
 
 
-def test_fusion_module(ref):
+def test_fusion_module(ref, cpu_warp):
     from types import SimpleNamespace
     from mono_vifi_amd.networks import FusionModule
     ch = np.array([64, 64, 128, 256, 512])

@@ -127,3 +127,15 @@ def test_fullsize_against_reference(cfg):
     assert abs(gnorm - float(g["grad_disp_norm"])) <= 1e-4 * float(g["grad_disp_norm"])
     # the reference reduces grad_P over H*W pixels in fp32 (BLAS); the oracle in fp64
     assert rel_err(out["grad_T"], g["grad_T"]) <= 5e-3
+
+
+@pytest.mark.parametrize("case", ["a", "b", "big"])
+def test_flow_warp(case):
+    """f1: IFRNet.warp -- indices bit-exact, values 1e-6, grads 1e-5 vs the reference."""
+    g = load_golden("g7_flow_" + case)
+    out, x0, y0 = O.flow_warp(g["img"], g["flow"], g["xs"], g["ys"], want_idx=True)
+    assert np.array_equal(x0, g["x0"]) and np.array_equal(y0, g["y0"])
+    assert np.max(np.abs(out - g["out"])) <= 1e-6
+    g_img, g_flow = O.flow_warp_bwd(g["img"], g["flow"], g["xs"], g["ys"], g["weight"])
+    assert rel_err(g_img, g["grad_img"]) <= 1e-5
+    assert rel_err(g_flow, g["grad_flow"]) <= 1e-5
