@@ -363,19 +363,16 @@ MVF_DEV WarpPair warp_point_pair(float disp, const float *__restrict__ iK, const
 }
 
 struct Taps4 {
-    unsigned o00, o01, o10, o11;
+    TapRows q;
     float wnw, wne, wsw, wse;
 };
 MVF_DEV Taps4 taps_of(const Tap &t, int W)
 {
-    Taps4 q;
-    q.o00 = (unsigned)t.y0 * W + t.x0;
-    q.o01 = (unsigned)t.y0 * W + t.x1;
-    q.o10 = (unsigned)t.y1 * W + t.x0;
-    q.o11 = (unsigned)t.y1 * W + t.x1;
+    Taps4 r;
+    r.q = taprows_of(t, W);
     float fw = t.wx, fe = 1.0f - fw, fn = t.wy, fs = 1.0f - fn;
-    q.wnw = fs * fe; q.wne = fs * fw; q.wsw = fn * fe; q.wse = fn * fw;
-    return q;
+    r.wnw = fs * fe; r.wne = fs * fw; r.wsw = fn * fe; r.wse = fn * fw;
+    return r;
 }
 
 // fused warp of a source pair into the pair planes: bilinear samples of src_a / src_b at
@@ -406,12 +403,10 @@ MVF_DEV WarpSlot warp_slot(int idx, const float *__restrict__ dispP, const float
     s.qa = taps_of(w.ta, W);
     s.qb = taps_of(w.tb, W);
 #ifdef MVF_ABL_COALESCED   // ablation: taps at the pixel itself (perfectly coalesced gathers)
-    s.qa.o00 = s.qa.o01 = s.qa.o10 = s.qa.o11 = (unsigned)gy * W + gx;
-    s.qb.o00 = s.qb.o01 = s.qb.o10 = s.qb.o11 = (unsigned)gy * W + gx;
+    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = (unsigned)gy * W + min(gx, W - 2);
 #endif
 #ifdef MVF_ABL_NOCHAIN     // ablation: no projection chain (taps from the disparity bits)
-    s.qa.o00 = s.qa.o01 = s.qa.o10 = s.qa.o11 = (unsigned)gy * W + gx;
-    s.qb.o00 = s.qb.o01 = s.qb.o10 = s.qb.o11 = (unsigned)gy * W + gx;
+    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = (unsigned)gy * W + min(gx, W - 2);
     s.qa.wnw = s.qb.wnw = dispP[s.r * LDW + s.c];
 #endif
     s.x0a = w.ta.x0; s.y0a = w.ta.y0; s.x0b = w.tb.x0; s.y0b = w.tb.y0;
@@ -440,11 +435,8 @@ MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict_
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-                const float *pa = sa + ch * N, *pb = sb + ch * N;
-                a[u][ch][0] = pa[s[u].qa.o00]; a[u][ch][1] = pa[s[u].qa.o01];
-                a[u][ch][2] = pa[s[u].qa.o10]; a[u][ch][3] = pa[s[u].qa.o11];
-                bq[u][ch][0] = pb[s[u].qb.o00]; bq[u][ch][1] = pb[s[u].qb.o01];
-                bq[u][ch][2] = pb[s[u].qb.o10]; bq[u][ch][3] = pb[s[u].qb.o11];
+                load_taps(sa + ch * N, s[u].qa.q, a[u][ch][0], a[u][ch][1], a[u][ch][2], a[u][ch][3]);
+                load_taps(sb + ch * N, s[u].qb.q, bq[u][ch][0], bq[u][ch][1], bq[u][ch][2], bq[u][ch][3]);
             }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
