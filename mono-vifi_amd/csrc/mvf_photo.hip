@@ -435,8 +435,18 @@ MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict_
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
+#ifdef MVF_ABL_LDSGATHER   // ablation: taps from an LDS plane (access-pattern cost of an LDS-staged source)
+                {
+                    int ya = min(max(s[u].y0a - py0, 0), PH - 2), xa = min(max(s[u].x0a - px0, 0), PW - 2);
+                    int yb = min(max(s[u].y0b - py0, 0), PH - 2), xb = min(max(s[u].x0b - px0, 0), PW - 2);
+                    const float *la = dispP + ya * LDW + xa, *lb = dispP + yb * LDW + xb;
+                    a[u][ch][0] = la[0] + ch; a[u][ch][1] = la[1]; a[u][ch][2] = la[LDW]; a[u][ch][3] = la[LDW + 1];
+                    bq[u][ch][0] = lb[0] + ch; bq[u][ch][1] = lb[1]; bq[u][ch][2] = lb[LDW]; bq[u][ch][3] = lb[LDW + 1];
+                }
+#else
                 load_taps(sa + ch * N, s[u].qa.q, a[u][ch][0], a[u][ch][1], a[u][ch][2], a[u][ch][3]);
                 load_taps(sb + ch * N, s[u].qb.q, bq[u][ch][0], bq[u][ch][1], bq[u][ch][2], bq[u][ch][3]);
+#endif
             }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -837,14 +847,24 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         asm volatile("" ::: "memory");
         __syncthreads();
         f2 P2[12];
+#ifdef MVF_ABL_NOWARPB
+        load_pose_pair(sh, ka, kb, P2);
+        if (false) {
+#else
         if (FUSED) {
             load_pose_pair(sh, ka, kb, P2);
+#endif
             warp_pair_into_lds<2>(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
                                   a.src.p[kb] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0, px0,
                                a.min_disp, a.range, a.eps, nullptr, nullptr, 0, 0);
         } else {
+#ifdef MVF_ABL_NOWARPB
+            stage_pair3(pairP, a.src.p[ka] + (size_t)b * 3 * N, a.src.p[kb] + (size_t)b * 3 * N, N,
+                        H, W, py0, px0);
+#else
             stage_pair3(pairP, a.warped.p[ka] + (size_t)b * 3 * N, a.warped.p[kb] + (size_t)b * 3 * N, N,
                         H, W, py0, px0);
+#endif
         }
         __syncthreads();
 
@@ -1000,8 +1020,18 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
                 float dxa[3], dya[3], dxb[3], dyb[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
+#ifdef MVF_ABL_CHAINLDS   // ablation: adjoint taps from an LDS plane instead of global memory
+                    const float *la = tgtP + c * PLANE + (row + 1) * LDW + col;
+                    dxa[c] = (la[1] - la[0]) * w.ta.wy + (la[LDW + 1] - la[LDW]);
+                    dya[c] = (la[LDW] - la[0]) * w.ta.wx + (la[LDW + 1] - la[1]);
+                    dxb[c] = (la[2] - la[1]) * w.tb.wy + (la[LDW + 2] - la[LDW + 1]);
+                    dyb[c] = (la[LDW + 1] - la[1]) * w.tb.wx + (la[LDW + 2] - la[2]);
+#elif defined(MVF_ABL_CHAINNOTAP)
+                    dxa[c] = w.ta.wx; dya[c] = w.ta.wy; dxb[c] = w.tb.wx; dyb[c] = w.tb.wy;
+#else
                     bilerp_grad(sa + c * N, W, w.ta, dxa[c], dya[c]);
                     bilerp_grad(sb + c * N, W, w.tb, dxb[c], dyb[c]);
+#endif
                 }
                 f2 gix = g0 * mk2(dxa[0], dxb[0]) + g1 * mk2(dxa[1], dxb[1]) + g2 * mk2(dxa[2], dxb[2]);
                 f2 giy = g0 * mk2(dya[0], dyb[0]) + g1 * mk2(dya[1], dyb[1]) + g2 * mk2(dya[2], dyb[2]);
@@ -1038,7 +1068,11 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
             float flat[24];
 #pragma unroll
             for (int q = 0; q < 12; ++q) { flat[q] = accP[q].x; flat[12 + q] = accP[q].y; }
+#ifdef MVF_ABL_NOBSUM
+            const float tot = flat[threadIdx.x % 24];
+#else
             const float tot = block_sum_many<NT, 24>(flat, scratch);
+#endif
             if (threadIdx.x < 12) parta[threadIdx.x] = tot;
             else if (threadIdx.x < 24 && hasb) partb[threadIdx.x - 12] = tot;
         }
@@ -1070,10 +1104,12 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
                 return expf(-gi);
             };
             auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
+#ifndef MVF_ABL_NOSMOOTHB
             if (x + 1 < W) gn += cx * wgt(1) * sgn(nd - dc[1] / den);
             if (x - 1 >= 0) gn -= cx * wgt(-1) * sgn(dc[-1] / den - nd);
             if (y + 1 < H) gn += cy * wgt(LDW) * sgn(nd - dc[LDW] / den);
             if (y - 1 >= 0) gn -= cy * wgt(-LDW) * sgn(dc[-LDW] / den - nd);
+#endif
             a.g_disp[(size_t)b * N + (size_t)y * W + x] = gdP[roff + j] + gn / den - corr / den;
         }
     }
