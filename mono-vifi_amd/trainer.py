@@ -35,7 +35,7 @@ from torch.utils.data import DataLoader
 from . import datasets, parallel
 from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
 from .losses import HotPathLosses
-from .networks import FusionModule, IFRNet, monodepth2, posenet
+from .networks import FusionModule, IFRNet, dhrnet, litemono, monodepth2, posenet
 
 
 def setup_logging(log_file=None, filemode="w", rank=0):
@@ -160,9 +160,18 @@ class Trainer(HotPathLosses):
             self.models["encoder"] = monodepth2.DepthEncoder(layers_n, o.weights_init == "pretrained")
             self.models["depth"] = monodepth2.DepthDecoder(self.models["encoder"].num_ch_enc,
                                                            range(o.num_scales))
+        elif o.backbone == "DHRNet":
+            self.models["encoder"] = dhrnet.DepthEncoder(18, o.weights_init == "pretrained")
+            self.models["depth"] = dhrnet.DepthDecoder(self.models["encoder"].num_ch_enc,
+                                                       range(o.num_scales))
+        elif o.backbone == "LiteMono":
+            # reference: train.py:157-167 (lite-mono-pretrain.pth cannot be fetched: random init)
+            self.models["encoder"] = litemono.DepthEncoder(model="lite-mono", drop_path_rate=0.2,
+                                                           width=o.width, height=o.height)
+            self.models["depth"] = litemono.DepthDecoder(self.models["encoder"].num_ch_enc,
+                                                         range(o.num_scales))
         else:
-            raise NotImplementedError(
-                f"backbone {o.backbone}: DHRNet / LiteMono are the next rows (SURVEY.md section 8f)")
+            raise ValueError(f"unknown backbone {o.backbone}")
         if o.fuse_model_type == "shared_all":
             self.models["encoder_mf"] = self.models["encoder"]
             self.models["depth_mf"] = self.models["depth"]

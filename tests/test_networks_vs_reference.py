@@ -110,3 +110,93 @@ def test_fusion_module(ref, cpu_warp):
     b = ours(feats, flows, mask)
     for x, y in zip(a, b):
         assert torch.allclose(x, y, atol=1e-5), float((x - y).abs().max())
+
+
+def _import_ref_dhrnet():
+    """The reference's DHRNet needs yacs (absent): a dict-backed CfgNode stand-in is enough
+    for its read-only config tables.  matplotlib is stubbed if missing."""
+    yacs = types.ModuleType("yacs")
+    cfgmod = types.ModuleType("yacs.config")
+
+    class CfgNode(dict):
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError as e:
+                raise AttributeError(k) from e
+
+        def __setattr__(self, k, v):
+            self[k] = v
+    cfgmod.CfgNode = CfgNode
+    yacs.config = cfgmod
+    sys.modules.setdefault("yacs", yacs)
+    sys.modules.setdefault("yacs.config", cfgmod)
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"] = mpl
+        sys.modules["matplotlib.pyplot"] = mpl.pyplot
+    return importlib.import_module("networks.DHRNet")
+
+
+def test_dhrnet(ref):
+    from mono_vifi_amd.networks import dhrnet
+    theirs_mod = _import_ref_dhrnet()
+    torch.manual_seed(4)
+    their_enc = theirs_mod.DepthEncoder(18, False).eval()
+    their_dec = theirs_mod.DepthDecoder(their_enc.num_ch_enc, range(1)).eval()
+    enc, dec = dhrnet.DepthEncoder(18).eval(), dhrnet.DepthDecoder(their_enc.num_ch_enc, range(1)).eval()
+    _copy(enc, their_enc)
+    _copy(dec, their_dec)
+    x = torch.rand(1, 3, 64, 96)
+    with torch.no_grad():
+        fa, fb = their_enc(x), enc(x)
+        for a, b in zip(fa, fb):
+            assert torch.allclose(a, b, atol=1e-5), float((a - b).abs().max())
+        assert torch.allclose(their_dec(fa)[("disp", 0)], dec(fb)[("disp", 0)], atol=1e-6)
+    assert sum(p.numel() for p in enc.parameters()) == 9562260      # SURVEY.md section 2c
+    assert sum(p.numel() for p in dec.parameters()) == 416589
+
+
+def _import_ref_litemono():
+    """The reference's LiteMono imports DropPath / trunc_normal_ from timm (absent): stub them
+    with the textbook definitions so that the reference module itself can be imported."""
+    timm = types.ModuleType("timm")
+    timm.models = types.ModuleType("timm.models")
+    layers_mod = types.ModuleType("timm.models.layers")
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+            self.p = p
+
+        def forward(self, x):
+            return x      # compared in eval mode only
+    layers_mod.DropPath = DropPath
+    layers_mod.trunc_normal_ = torch.nn.init.trunc_normal_
+    timm.models.layers = layers_mod
+    for name, mod in (("timm", timm), ("timm.models", timm.models), ("timm.models.layers", layers_mod)):
+        sys.modules.setdefault(name, mod)
+    return importlib.import_module("networks.LiteMono")
+
+
+@pytest.mark.parametrize("hw", [(192, 640), (320, 1024)])
+def test_litemono(ref, hw):
+    from mono_vifi_amd.networks import litemono
+    theirs_mod = _import_ref_litemono()
+    H, W = hw
+    torch.manual_seed(5)
+    their_enc = theirs_mod.DepthEncoder(model="lite-mono", drop_path_rate=0.2, width=W, height=H).eval()
+    their_dec = theirs_mod.DepthDecoder(their_enc.num_ch_enc, range(1)).eval()
+    enc = litemono.DepthEncoder(model="lite-mono", drop_path_rate=0.2, width=W, height=H).eval()
+    dec = litemono.DepthDecoder(their_enc.num_ch_enc, range(1)).eval()
+    _copy(enc, their_enc)
+    _copy(dec, their_dec)
+    x = torch.rand(1, 3, 64, 96)
+    with torch.no_grad():
+        fa, fb = their_enc(x), enc(x)
+        for a, b in zip(fa, fb):
+            assert torch.allclose(a, b, atol=2e-5), float((a - b).abs().max())
+        assert torch.allclose(their_dec(fa)[("disp", 0)], dec(fb)[("disp", 0)], atol=1e-6)

@@ -89,3 +89,12 @@ def test_run_epoch_through_dataloader(tmp_path):
     t.run_epoch(max_steps=2)
     assert t.step == 2
     assert os.path.exists(os.path.join(str(tmp_path), "t", "scalars_train.jsonl"))
+
+
+@pytest.mark.parametrize("backbone", ["DHRNet", "LiteMono"])
+def test_other_backbones_step(tmp_path, backbone):
+    """BASELINE.json configs 3-5 use the HRNet18 / Lite-Mono backbones: one optimisation step."""
+    t = make_trainer(tmp_path, backbone=backbone)
+    t.set_train()
+    losses = t.optimisation_step(device_batch(2, 64, 96, t.device))
+    assert all(np.isfinite(float(losses[k].detach())) for k in ("loss", "loss_base", "loss_dc"))
