@@ -184,6 +184,18 @@ MVF_API int mvf_flow_warp_bwd(const float *img, const float *flow, const float *
                       int H, int W, void *stream);
 MVF_API size_t mvf_flow_warp_workspace_floats(int B, int C, int H, int W);
 
+/* ---- f2: Trainer.compute_SI_log_depth_loss (train.py:924-941) ----
+ * pred, target [B,1,H,W] (N = H*W), mask nullable [B,1,H,W]; B <= 64.
+ * loss[0] = mean_b( sum ld^2/n - beta*(sum ld)^2/n^2 ), ld = log(pred+1e-7)*m - log(target+1e-7)*m,
+ * n = sum m + 1e-8.  sums [B,4] = {sum ld, sum ld^2, n, -} saved for the backward.
+ * workspace: B*64*4 floats. */
+MVF_API int mvf_silog_fwd(const float *pred, const float *target, const float *mask, float *loss,
+                  float *sums, float *workspace, int B, int N, float beta, void *stream);
+/* g_pred / g_target nullable; g_loss device scalar */
+MVF_API int mvf_silog_bwd(const float *pred, const float *target, const float *mask, const float *sums,
+                  const float *g_loss, float *g_pred, float *g_target, int B, int N, float beta,
+                  void *stream);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------
  * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
  * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded

@@ -429,6 +429,85 @@ __global__ void __launch_bounds__(NT) k_warp_bwd(const float *__restrict__ disp,
     reduce12_to_ws<NT>(acc, ws + ((size_t)b * gridDim.x + blockIdx.x) * 12, scratch);
 }
 
+// ---------------------------------------------------------------- f2 scale-invariant log loss
+// Trainer.compute_SI_log_depth_loss (reference: train.py:924-941): per image
+//   ld = log(pred+1e-7)*m - log(target+1e-7)*m ; n = sum m + 1e-8
+//   loss_b = sum ld^2 / n - beta * (sum ld)^2 / n^2 ; loss = mean_b loss_b
+// Forward: per-block partials {sum ld, sum ld^2, sum m} -> ws ; finishing kernel (fp64) writes
+// loss[0] and sums[B][4] = {s1, s2, n, -} for the backward.  Backward is element-wise.
+constexpr int SIL_NB = 64;     // blocks per image
+
+__global__ void __launch_bounds__(NT) k_silog_partial(const float *__restrict__ pred,
+                                                      const float *__restrict__ target,
+                                                      const float *__restrict__ mask,
+                                                      float *__restrict__ ws, int N)
+{
+    __shared__ float scratch[3 * (NT / kWave)];
+    int b = blockIdx.y;
+    const float *p = pred + (size_t)b * N, *t = target + (size_t)b * N;
+    const float *m = mask ? mask + (size_t)b * N : nullptr;
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = blockIdx.x * NT + threadIdx.x; i < N; i += SIL_NB * NT) {
+        float mk = m ? m[i] : 1.0f;
+        float ld = logf(p[i] + 1e-7f) * mk - logf(t[i] + 1e-7f) * mk;
+        v[0] += ld;
+        v[1] += ld * ld;
+        v[2] += mk;
+    }
+    float tot = block_sum_many<NT, 3>(v, scratch);
+    if (threadIdx.x < 3) ws[((size_t)b * SIL_NB + blockIdx.x) * 4 + threadIdx.x] = tot;
+}
+
+__global__ void k_silog_finish(const float *__restrict__ ws, float *__restrict__ loss,
+                               float *__restrict__ sums, int B, float beta)
+{
+    __shared__ double acc[64];
+    int b = threadIdx.x;
+    double lb = 0.0;
+    if (b < B) {
+        double s1 = 0.0, s2 = 0.0, n = 0.0;
+        for (int k = 0; k < SIL_NB; ++k) {
+            const float *q = ws + ((size_t)b * SIL_NB + k) * 4;
+            s1 += q[0]; s2 += q[1]; n += q[2];
+        }
+        n += 1e-8;
+        lb = s2 / n - (double)beta * s1 * s1 / (n * n);
+        sums[b * 4 + 0] = (float)s1;
+        sums[b * 4 + 1] = (float)s2;
+        sums[b * 4 + 2] = (float)n;
+        sums[b * 4 + 3] = 0.0f;
+    }
+    acc[threadIdx.x] = lb;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < 64; ++i) tot += acc[i];
+        // batches larger than 64 images: handled by the host wrapper in chunks
+        loss[0] = (float)(tot / (double)B);
+    }
+}
+
+__global__ void __launch_bounds__(NT) k_silog_bwd(const float *__restrict__ pred,
+                                                  const float *__restrict__ target,
+                                                  const float *__restrict__ mask,
+                                                  const float *__restrict__ sums,
+                                                  const float *__restrict__ g_loss,
+                                                  float *__restrict__ g_pred,
+                                                  float *__restrict__ g_target, int B, int N, float beta)
+{
+    int b = blockIdx.y;
+    int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    size_t o = (size_t)b * N + i;
+    float mk = mask ? mask[o] : 1.0f;
+    float lp = pred[o] + 1e-7f, lt = target[o] + 1e-7f;
+    float ld = logf(lp) * mk - logf(lt) * mk;
+    float s1 = sums[b * 4 + 0], n = sums[b * 4 + 2];
+    float g = g_loss[0] / (float)B * (2.0f * ld / n - 2.0f * beta * s1 / (n * n));
+    if (g_pred) g_pred[o] = g * mk / lp;
+    if (g_target) g_target[o] = -g * mk / lt;
+}
+
 // ---------------------------------------------------------------- a10 pose glue
 // reference: layers.py:28-103.  One lane per batch element.
 struct Rot {
@@ -805,6 +884,28 @@ int mvf_flow_warp_bwd(const float *img, const float *flow, const float *xs, cons
         hipLaunchKernelGGL(k_flow_grad_fold, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0,
                            (hipStream_t)stream, workspace, g_flow, nchunk, n);
     }
+    return hip_check_launch();
+}
+
+int mvf_silog_fwd(const float *pred, const float *target, const float *mask, float *loss,
+                  float *sums, float *workspace, int B, int N, float beta, void *stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    if (B > 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_silog_partial, dim3(SIL_NB, B), dim3(NT), 0, (hipStream_t)stream, pred, target,
+                       mask, workspace, N);
+    hipLaunchKernelGGL(k_silog_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, loss, sums,
+                       B, beta);
+    return hip_check_launch();
+}
+
+int mvf_silog_bwd(const float *pred, const float *target, const float *mask, const float *sums,
+                  const float *g_loss, float *g_pred, float *g_target, int B, int N, float beta,
+                  void *stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    hipLaunchKernelGGL(k_silog_bwd, dim3((unsigned)((N + NT - 1) / NT), (unsigned)B), dim3(NT), 0,
+                       (hipStream_t)stream, pred, target, mask, sums, g_loss, g_pred, g_target, B, N, beta);
     return hip_check_launch();
 }
 

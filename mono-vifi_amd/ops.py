@@ -509,3 +509,46 @@ def flow_warp_indices(img_shape, flow):
                                           nat.ptr(_linspace(H, flow.device)), None, nat.ptr(idx), B, Cc,
                                           H, W, _stream()), "flow_warp(idx)")
     return idx
+
+
+# ------------------------------------------------------------------ f2 SI-log depth loss
+class SILog(torch.autograd.Function):
+    """Trainer.compute_SI_log_depth_loss; reference: train.py:924-941"""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask, beta):
+        nat.require_device(pred, target, mask)
+        pred, target, mask = _c(pred), _c(target), _c(mask)
+        B = pred.shape[0]
+        N = pred[0].numel()
+        if pred.shape[1] != 1 or target.shape != pred.shape:
+            raise RuntimeError("compute_SI_log_depth_loss expects pred/target [B,1,H,W]")
+        if B > 64:
+            raise RuntimeError("mvf_silog supports batch sizes up to 64")
+        dev = pred.device
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        sums = torch.empty((B, 4), dtype=torch.float32, device=dev)
+        ws = torch.empty(B * 64 * 4, dtype=torch.float32, device=dev)
+        nat.check(nat.lib().mvf_silog_fwd(nat.ptr(pred), nat.ptr(target), nat.ptr(mask), nat.ptr(loss),
+                                          nat.ptr(sums), nat.ptr(ws), B, N, float(beta), _stream()),
+                  "silog_fwd")
+        ctx.save_for_backward(pred, target, mask, sums)
+        ctx.beta = float(beta)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, mask, sums = ctx.saved_tensors
+        B = pred.shape[0]
+        N = pred[0].numel()
+        g = _c(g).reshape(1)
+        gp = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        gt = torch.empty_like(target) if ctx.needs_input_grad[1] else None
+        nat.check(nat.lib().mvf_silog_bwd(nat.ptr(pred), nat.ptr(target), nat.ptr(mask), nat.ptr(sums),
+                                          nat.ptr(g), nat.ptr(gp), nat.ptr(gt), B, N, ctx.beta,
+                                          _stream()), "silog_bwd")
+        return gp, gt, None, None
+
+
+def silog_loss(pred, target, mask=None, beta=0.5):
+    return SILog.apply(pred, target, mask, beta)

@@ -492,15 +492,10 @@ class Trainer(HotPathLosses):
             self.compute_SI_log_depth_loss(restored, depth, mask)
 
     def compute_SI_log_depth_loss(self, pred, target, mask=None, beta=0.5):
-        """Scale-invariant log loss (reference: train.py:924-941)."""
-        if mask is None:
-            mask = torch.ones_like(pred)
-        mask = mask[:, 0]
-        log_diff = torch.log(pred[:, 0] + 1e-7) * mask - torch.log(target[:, 0] + 1e-7) * mask
-        valid = mask.sum(1).sum(1) + 1e-8
-        sq_sum = (log_diff ** 2).sum(1).sum(1)
-        sum_sq = log_diff.sum(1).sum(1) ** 2
-        return (sq_sum / valid - beta * sum_sq / (valid ** 2)).mean()
+        """Scale-invariant log loss (reference: train.py:924-941): one reduction kernel + one
+        element-wise backward kernel instead of ~30 element-wise / reduction launches."""
+        from . import ops
+        return ops.silog_loss(pred, target, mask, beta)
 
     def predict_poses(self, img_0, img1):
         """Pose between two frames, forward and inverted (reference: train.py:943-954)."""

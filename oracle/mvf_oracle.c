@@ -879,3 +879,35 @@ MVFO_API void mvfo_flow_warp_bwd(const float *img, const float *flow, const floa
                 }
             }
 }
+
+/* ------------------------------------------------------------------------------------
+ * f2: Trainer.compute_SI_log_depth_loss.  reference: train.py:924-941.
+ * returns the loss; g_pred / g_target (nullable) receive gloss * d loss / d pred|target.
+ * ---------------------------------------------------------------------------------- */
+MVFO_API double mvfo_silog(const float *pred, const float *target, const float *mask, float beta,
+                           float gloss, float *g_pred, float *g_target, int B, long N)
+{
+    double total = 0.0;
+    for (int b = 0; b < B; ++b) {
+        const float *p = pred + b * N, *t = target + b * N;
+        const float *m = mask ? mask + b * N : 0;
+        double s1 = 0.0, s2 = 0.0, n = 0.0;
+        for (long i = 0; i < N; ++i) {
+            float mk = m ? m[i] : 1.0f;
+            float ld = logf(p[i] + 1e-7f) * mk - logf(t[i] + 1e-7f) * mk;
+            s1 += ld; s2 += (double)ld * ld; n += mk;
+        }
+        n += 1e-8;
+        total += s2 / n - (double)beta * s1 * s1 / (n * n);
+        if (g_pred || g_target)
+            for (long i = 0; i < N; ++i) {
+                float mk = m ? m[i] : 1.0f;
+                float lp = p[i] + 1e-7f, lt = t[i] + 1e-7f;
+                float ld = logf(lp) * mk - logf(lt) * mk;
+                double g = (double)gloss / B * (2.0 * ld / n - 2.0 * beta * s1 / (n * n));
+                if (g_pred) g_pred[b * N + i] = (float)(g * mk / lp);
+                if (g_target) g_target[b * N + i] = (float)(-g * mk / lt);
+            }
+    }
+    return total / B;
+}

@@ -41,6 +41,7 @@ def lib():
         _lib = C.CDLL(build())
         _lib.mvfo_smooth.restype = C.c_double
         _lib.mvfo_losses_base_fwd.restype = C.c_double
+        _lib.mvfo_silog.restype = C.c_double
     return _lib
 
 
@@ -275,3 +276,16 @@ def flow_warp_bwd(img, flow, xs, ys, gout):
     lib().mvfo_flow_warp_bwd(_p(img), _p(flow), _p(xs), _p(ys), _p(gout), _p(g_img), _p(g_flow),
                              B, Cc, H, W)
     return g_img, g_flow
+
+
+def silog(pred, target, mask=None, beta=0.5, gloss=1.0, want_grads=False):
+    """Trainer.compute_SI_log_depth_loss (reference train.py:924-941)."""
+    pred, target = _f(pred), _f(target)
+    mask = _f(mask) if mask is not None else None
+    B = pred.shape[0]
+    N = pred[0].size
+    gp = np.empty_like(pred) if want_grads else None
+    gt = np.empty_like(target) if want_grads else None
+    v = lib().mvfo_silog(_p(pred), _p(target), _p(mask), C.c_float(beta), C.c_float(gloss), _p(gp),
+                         _p(gt), B, C.c_long(N))
+    return (float(v), gp, gt) if want_grads else float(v)

@@ -421,9 +421,29 @@ def g7_flow_warp():
              grad_img=ti.grad, grad_flow=tf.grad)
 
 
+# ----------------------------------------------------------------------------- G8 (SI-log, f2)
+def g8_silog():
+    rng = np.random.default_rng(800)
+    B, H, W = 3, 24, 40
+    fs = fake_self(B, H, W)
+    pred = (0.1 + 20 * rng.random((B, 1, H, W))).astype(np.float32)
+    target = (pred * (0.7 + 0.6 * rng.random((B, 1, H, W)))).astype(np.float32)
+    mask = (rng.random((B, 1, H, W)) > 0.3).astype(np.float32)
+    mask[1] = 0          # an image with no valid pixel: the 1e-8 guard
+    out = {}
+    for tag, m in (("nomask", None), ("mask", mask)):
+        tp, tt = t(pred).clone().requires_grad_(True), t(target).clone().requires_grad_(True)
+        loss = Trainer.compute_SI_log_depth_loss(fs, tp, tt, t(m) if m is not None else None)
+        (loss * 3.0).backward()
+        out["loss_" + tag] = loss
+        out["grad_pred_" + tag] = tp.grad
+        out["grad_target_" + tag] = tt.grad
+    save("g8_silog", pred=pred, target=target, mask=mask, **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     fns = dict(g1=g1_geometry, g2=g2_photometric, g3=g3_gradients, g4=g4_fullsize,
-               g5=g5_pose, g6=g6_ssim_smooth, g7=g7_flow_warp)
+               g5=g5_pose, g6=g6_ssim_smooth, g7=g7_flow_warp, g8=g8_silog)
     for w in which:
         fns[w]()

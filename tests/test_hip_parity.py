@@ -379,3 +379,27 @@ def test_flow_warp_feature_pyramid_vs_oracle(dev):
         (out * T(wgt, dev)).sum().backward()
         g_img, _ = O.flow_warp_bwd(img, flow, xs, ys, wgt)
         assert rel_err(N(ti.grad), g_img) <= 1e-5
+
+
+# ------------------------------------------------------------------ f2: SI-log loss (G8)
+def test_silog(dev):
+    from mono_vifi_amd import ops
+    g = load_golden("g8_silog")
+    for tag, m in (("nomask", None), ("mask", g["mask"])):
+        p, t = T(g["pred"], dev, True), T(g["target"], dev, True)
+        loss = ops.silog_loss(p, t, T(m, dev) if m is not None else None, 0.5)
+        (loss * 3.0).backward()
+        assert abs(float(loss.detach()) - float(g["loss_" + tag])) <= 2e-6 * abs(float(g["loss_" + tag]))
+        assert rel_err(N(p.grad), g["grad_pred_" + tag]) <= 1e-5
+        assert rel_err(N(t.grad), g["grad_target_" + tag]) <= 1e-5
+    # full size vs the oracle
+    rng = np.random.default_rng(81)
+    pred = (0.1 + 50 * rng.random((12, 1, 192, 640))).astype(np.float32)
+    target = (pred * (0.5 + rng.random(pred.shape))).astype(np.float32)
+    mask = (rng.random(pred.shape) > 0.2).astype(np.float32)
+    ref, gp, gt = O.silog(pred, target, mask, 0.5, want_grads=True)
+    p, t = T(pred, dev, True), T(target, dev, True)
+    loss = ops.silog_loss(p, t, T(mask, dev))
+    loss.backward()
+    assert abs(float(loss.detach()) - ref) <= 1e-5 * abs(ref)
+    assert rel_err(N(p.grad), gp) <= 1e-4 and rel_err(N(t.grad), gt) <= 1e-4

@@ -139,3 +139,13 @@ def test_flow_warp(case):
     g_img, g_flow = O.flow_warp_bwd(g["img"], g["flow"], g["xs"], g["ys"], g["weight"])
     assert rel_err(g_img, g["grad_img"]) <= 1e-5
     assert rel_err(g_flow, g["grad_flow"]) <= 1e-5
+
+
+def test_silog():
+    """f2: compute_SI_log_depth_loss incl. an all-masked image, vs the reference."""
+    g = load_golden("g8_silog")
+    for tag, m in (("nomask", None), ("mask", g["mask"])):
+        loss, gp, gt = O.silog(g["pred"], g["target"], m, 0.5, gloss=3.0, want_grads=True)
+        assert abs(loss - float(g["loss_" + tag])) <= 2e-6 * abs(float(g["loss_" + tag]))
+        assert rel_err(gp, g["grad_pred_" + tag]) <= 1e-5
+        assert rel_err(gt, g["grad_target_" + tag]) <= 1e-5
