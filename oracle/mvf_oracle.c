@@ -27,6 +27,21 @@
 
 #define MVFO_API __attribute__((visibility("default")))
 
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+/* number of OpenMP threads the timing leg of bench.py uses (0 = leave as is) */
+MVFO_API int mvfo_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+    return omp_get_max_threads();
+#else
+    (void)n;
+    return 1;
+#endif
+}
+
 /* ------------------------------------------------------------------------------------
  * disp -> depth.  reference: layers.py:16-25 (called from train.py:961).
  * min_disp = (float)(1/max_depth), range = (float)(1/min_depth - 1/max_depth) are

@@ -289,3 +289,9 @@ def silog(pred, target, mask=None, beta=0.5, gloss=1.0, want_grads=False):
     v = lib().mvfo_silog(_p(pred), _p(target), _p(mask), C.c_float(beta), C.c_float(gloss), _p(gp),
                          _p(gt), B, C.c_long(N))
     return (float(v), gp, gt) if want_grads else float(v)
+
+
+def set_threads(n):
+    """OpenMP threads used by the oracle (bench.py's cpu_baseline calibrates this); returns
+    the count in effect."""
+    return int(lib().mvfo_set_threads(int(n)))
