@@ -168,7 +168,7 @@ def cpu_baseline(args):
         one()
         n += 1
         dt = time.perf_counter() - t0
-        if dt >= args.cpu_seconds or n >= 200:
+        if dt >= args.cpu_seconds or n >= 5000:
             break
     t_unit = dt / n
     # value = images/sec the CPU port sustains on the HOT-PATH part of a step (9 units fwd+bwd);
