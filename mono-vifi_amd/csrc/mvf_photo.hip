@@ -1088,6 +1088,7 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         // d/d disp_j of scale*smooth(disp/den): gn_j/den - (sum_i gn_i d_i)/(den^2 N); the sum is
         // den*scale*smooth_b because the per-image term is positively homogeneous of degree 1
         const float corr = scale * smooth_b / (float)N;
+        const float rden = 1.0f / den, corr_den = corr / den;
 #pragma unroll 1
         for (int j = 0; j < PX; ++j) {
             const int x = x0 + j;
@@ -1096,7 +1097,9 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
             if (!outp) continue;
             const float *dc = dispP + (row + 1) * LDW + col + 1;
             const float *t0 = tgtP + (row + 1) * LDW + col + 1;
-            float nd = dc[0] / den;
+            // only the SIGN of differences of normalised disparities is needed: dividing by
+            // the positive per-image constant cannot change it, so compare the raw values
+            float nd = dc[0];
             float gn = 0.0f;
             auto wgt = [&](int o) {
                 float gi = div3((fabsf(t0[0] - t0[o]) + fabsf(t0[PLANE] - t0[PLANE + o])) +
@@ -1105,12 +1108,12 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
             };
             auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
 #ifndef MVF_ABL_NOSMOOTHB
-            if (x + 1 < W) gn += cx * wgt(1) * sgn(nd - dc[1] / den);
-            if (x - 1 >= 0) gn -= cx * wgt(-1) * sgn(dc[-1] / den - nd);
-            if (y + 1 < H) gn += cy * wgt(LDW) * sgn(nd - dc[LDW] / den);
-            if (y - 1 >= 0) gn -= cy * wgt(-LDW) * sgn(dc[-LDW] / den - nd);
+            if (x + 1 < W) gn += cx * wgt(1) * sgn(nd - dc[1]);
+            if (x - 1 >= 0) gn -= cx * wgt(-1) * sgn(dc[-1] - nd);
+            if (y + 1 < H) gn += cy * wgt(LDW) * sgn(nd - dc[LDW]);
+            if (y - 1 >= 0) gn -= cy * wgt(-LDW) * sgn(dc[-LDW] - nd);
 #endif
-            a.g_disp[(size_t)b * N + (size_t)y * W + x] = gdP[roff + j] + gn / den - corr / den;
+            a.g_disp[(size_t)b * N + (size_t)y * W + x] = gdP[roff + j] + gn * rden - corr_den;
         }
     }
 }
