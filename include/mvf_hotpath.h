@@ -196,6 +196,27 @@ MVF_API int mvf_silog_bwd(const float *pred, const float *target, const float *m
                   const float *g_loss, float *g_pred, float *g_target, int B, int N, float beta,
                   void *stream);
 
+/* ---- f2: the affine-augmentation glue ---------------------------
+ * Trainer.affine_transform (train.py:888-902): per sample rotate(img, angle) (torchvision
+ * functional.rotate, bilinear, zero fill), crop box = (x0, y0, w, h), F.interpolate back to
+ * (H,W) (bilinear, align_corners=False).  The reference loops over the batch with five
+ * .item() host syncs per sample; here angle_deg [B] (degrees), box [B,4] int32 and ratio [B]
+ * are device arrays and one launch covers the batch.  img/out [B,C,H,W].  Forward only
+ * (the trainer applies it to teacher frames, which carry no gradient).  The box must lie
+ * inside the image (the reference's slicing / paste assume it too). */
+MVF_API int mvf_affine_transform_fwd(const float *img, const float *angle_deg, const int32_t *box,
+                             float *out, int B, int C, int H, int W, void *stream);
+/* depth_restore of Trainer.compute_depth_consistency_loss_affine (train.py:909-916):
+ * out = ratio[b] * rotate( zeros(H,W) with F.interpolate(depth -> (h,w)) pasted at (x0,y0),
+ * -angle[b] ).  depth/out [B,C,H,W]. */
+MVF_API int mvf_affine_restore_fwd(const float *depth, const float *angle_deg, const int32_t *box,
+                           const float *ratio, float *out, int B, int C, int H, int W, void *stream);
+/* g_depth = adjoint of the above applied to g_out; deterministic (two gather passes, no
+ * atomics).  workspace: B*C*H*W floats. */
+MVF_API int mvf_affine_restore_bwd(const float *g_out, const float *angle_deg, const int32_t *box,
+                           const float *ratio, float *workspace, float *g_depth, int B, int C,
+                           int H, int W, void *stream);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------
  * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
  * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded

@@ -54,6 +54,9 @@ _SIGNATURES = {
     "mvf_flow_warp_workspace_floats": [_i, _i, _i, _i],
     "mvf_silog_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mvf_silog_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mvf_affine_transform_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_affine_restore_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_affine_restore_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_profile_enable": [_i],
     "mvf_profile_reset": [],
     "mvf_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)],

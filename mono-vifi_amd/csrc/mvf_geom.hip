@@ -657,8 +657,8 @@ void drain(ProfState &p, int id)
             p.acc_ms[id] += ms;
             p.acc_n[id] += 1;
         }
-        hipEventDestroy(pr.first);
-        hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
     }
     p.ev[id].clear();
 }
@@ -672,7 +672,7 @@ void prof_begin(int id, hipStream_t st)
     if (p.ev[id].size() >= kMaxPairs) drain(p, id);
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
-    hipEventRecord(e, st);
+    (void)hipEventRecord(e, st);
     p.open_start[id] = e;
 }
 
@@ -684,7 +684,7 @@ void prof_end(int id, hipStream_t st)
     if (!p.open_start[id]) return;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
-    hipEventRecord(e, st);
+    (void)hipEventRecord(e, st);
     p.ev[id].emplace_back(p.open_start[id], e);
     p.open_start[id] = nullptr;
 }

@@ -552,3 +552,67 @@ class SILog(torch.autograd.Function):
 
 def silog_loss(pred, target, mask=None, beta=0.5):
     return SILog.apply(pred, target, mask, beta)
+
+
+# --------------------------------------------------------------------------- f2 affine glue
+def _affine_meta(angle, box, ratio, B, dev):
+    """angle [B] or [B,1] degrees fp32, box [B,4] (x0,y0,w,h) int32, ratio [B] or [B,1] fp32 --
+    all kept on the device (the reference reads them with .item() per sample)."""
+    angle = angle.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+    box = box.to(device=dev, dtype=torch.int32).contiguous()
+    if angle.numel() != B or tuple(box.shape) != (B, 4):
+        raise RuntimeError("angle must hold B values and box must be [B,4]")
+    if ratio is not None:
+        ratio = ratio.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
+        if ratio.numel() != B:
+            raise RuntimeError("ratio_local must hold B values")
+    return angle, box, ratio
+
+
+def affine_transform(img, angle, box):
+    """Trainer.affine_transform (reference: train.py:888-902): rotate by ``angle`` degrees
+    (bilinear, zero fill), crop ``box`` and resize back to (H,W), for the whole batch in one
+    launch.  Forward only: the trainer applies it to teacher frames."""
+    nat.require_device(img)
+    if img.requires_grad:
+        raise RuntimeError("affine_transform has no backward (inputs are teacher frames)")
+    img = _c(img)
+    B, C, H, W = img.shape
+    angle, box, _ = _affine_meta(angle, box, None, B, img.device)
+    out = torch.empty_like(img)
+    nat.check(nat.lib().mvf_affine_transform_fwd(nat.ptr(img), nat.ptr(angle), nat.ptr(box), nat.ptr(out),
+                                                 B, C, H, W, _stream()), "affine_transform_fwd")
+    return out
+
+
+class AffineRestore(torch.autograd.Function):
+    """depth_restore of Trainer.compute_depth_consistency_loss_affine; reference: train.py:909-916"""
+
+    @staticmethod
+    def forward(ctx, depth, angle, box, ratio):
+        nat.require_device(depth)
+        depth = _c(depth)
+        B, C, H, W = depth.shape
+        angle, box, ratio = _affine_meta(angle, box, ratio, B, depth.device)
+        out = torch.empty_like(depth)
+        nat.check(nat.lib().mvf_affine_restore_fwd(nat.ptr(depth), nat.ptr(angle), nat.ptr(box),
+                                                   nat.ptr(ratio), nat.ptr(out), B, C, H, W, _stream()),
+                  "affine_restore_fwd")
+        ctx.save_for_backward(angle, box, ratio)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        angle, box, ratio = ctx.saved_tensors
+        g = _c(g)
+        B, C, H, W = g.shape
+        ws = torch.empty_like(g)
+        gd = torch.empty_like(g)
+        nat.check(nat.lib().mvf_affine_restore_bwd(nat.ptr(g), nat.ptr(angle), nat.ptr(box), nat.ptr(ratio),
+                                                   nat.ptr(ws), nat.ptr(gd), B, C, H, W, _stream()),
+                  "affine_restore_bwd")
+        return gd, None, None, None
+
+
+def affine_restore(depth, angle, box, ratio):
+    return AffineRestore.apply(depth, angle, box, ratio)

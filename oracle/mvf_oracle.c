@@ -926,3 +926,182 @@ MVFO_API double mvfo_silog(const float *pred, const float *target, const float *
     }
     return total / B;
 }
+
+/* ------------------------------------------------------------------------------------
+ * f2: Trainer.affine_transform (reference: train.py:888-902) and the depth "restore" of
+ * Trainer.compute_depth_consistency_loss_affine (reference: train.py:909-916).
+ *
+ * Both compose torchvision.transforms.functional.rotate(img, angle, interpolation=2)
+ * (bilinear, zero fill: an inverse-mapped pixel-centre grid sampled with
+ * grid_sample(align_corners=False, padding_mode="zeros")) with a box crop / paste and
+ * F.interpolate(mode="bilinear", align_corners=False).  torchvision is absent here, so the
+ * rotate step follows its published algorithm (v0.12, _get_inverse_affine_matrix +
+ * _gen_affine_grid): PARITY UNPINNED for that step; the interpolate / crop / paste steps are
+ * checked against torch itself (tests/test_oracle_golden.py).
+ *
+ * rot_pos(): source position in pixels of output pixel (y,x) for a rotation by `deg`:
+ *   c,s = cos,sin(deg*pi/180) evaluated in double and rounded to fp32 (torchvision builds the
+ *   matrix with python floats); grid g = (c*xs - s*ys)/(0.5*W) with xs = x + 0.5 - W/2;
+ *   pixel = ((g + 1)*W - 1)/2  (ATen grid_sampler_unnormalize, align_corners=False).
+ * ---------------------------------------------------------------------------------- */
+typedef struct { float c, s; } trig_t;
+static inline trig_t trig_of(float deg)
+{
+    double a = (double)deg * 3.14159265358979323846 / 180.0;
+    trig_t t = {(float)cos(a), (float)sin(a)};
+    return t;
+}
+static inline void rot_pos(trig_t t, int y, int x, int H, int W, float *px, float *py)
+{
+    float xs = (float)x + 0.5f - (float)W / 2.0f, ys = (float)y + 0.5f - (float)H / 2.0f;
+    float gx = (t.c * xs - t.s * ys) / (0.5f * (float)W);
+    float gy = (t.s * xs + t.c * ys) / (0.5f * (float)H);
+    *px = ((gx + 1.0f) * (float)W - 1.0f) / 2.0f;
+    *py = ((gy + 1.0f) * (float)H - 1.0f) / 2.0f;
+}
+/* bilinear, zero padding, of one plane at a real position */
+static inline float sample_zeros(const float *im, int H, int W, float px, float py)
+{
+    float fx = floorf(px), fy = floorf(py);
+    int x0 = (int)fx, y0 = (int)fy;
+    float lx = px - fx, ly = py - fy, v = 0.0f;
+    if (y0 >= 0 && y0 < H) {
+        if (x0 >= 0 && x0 < W) v += im[(long)y0 * W + x0] * ((1.0f - lx) * (1.0f - ly));
+        if (x0 + 1 >= 0 && x0 + 1 < W) v += im[(long)y0 * W + x0 + 1] * (lx * (1.0f - ly));
+    }
+    if (y0 + 1 >= 0 && y0 + 1 < H) {
+        if (x0 >= 0 && x0 < W) v += im[(long)(y0 + 1) * W + x0] * ((1.0f - lx) * ly);
+        if (x0 + 1 >= 0 && x0 + 1 < W) v += im[(long)(y0 + 1) * W + x0 + 1] * (lx * ly);
+    }
+    return v;
+}
+/* F.interpolate(bilinear, align_corners=False) source index of output index `o`:
+ * in_size/out_size scale, clamp at 0, upper tap clamped (ATen area_pixel_compute_source_index) */
+typedef struct { int i0, i1; float l; } rs_t;
+static inline rs_t resize_src(int o, int in_size, int out_size)
+{
+    float sc = (float)in_size / (float)out_size;
+    float t = ((float)o + 0.5f) * sc - 0.5f;
+    if (t < 0.0f) t = 0.0f;
+    rs_t r;
+    r.i0 = (int)t;
+    if (r.i0 > in_size - 1) r.i0 = in_size - 1;
+    r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
+    r.l = t - (float)r.i0;
+    if (r.l < 0.0f) r.l = 0.0f;
+    if (r.l > 1.0f) r.l = 1.0f;
+    return r;
+}
+
+/* out[b,c] = resize( rotate(img[b,c], angle[b]) [y0:y0+h, x0:x0+w] -> (H,W) ) */
+MVFO_API void mvfo_affine_transform(const float *img, const float *angle, const int32_t *box,
+                                    float *out, int B, int C, int H, int W)
+{
+    long N = (long)H * W;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y) {
+            trig_t t = trig_of(angle[b]);
+            int x0 = box[b * 4], y0 = box[b * 4 + 1], w = box[b * 4 + 2], h = box[b * 4 + 3];
+            rs_t ry = resize_src(y, h, H);
+            for (int x = 0; x < W; ++x) {
+                rs_t rx = resize_src(x, w, W);
+                float p[4][2];
+                rot_pos(t, y0 + ry.i0, x0 + rx.i0, H, W, &p[0][0], &p[0][1]);
+                rot_pos(t, y0 + ry.i0, x0 + rx.i1, H, W, &p[1][0], &p[1][1]);
+                rot_pos(t, y0 + ry.i1, x0 + rx.i0, H, W, &p[2][0], &p[2][1]);
+                rot_pos(t, y0 + ry.i1, x0 + rx.i1, H, W, &p[3][0], &p[3][1]);
+                for (int c = 0; c < C; ++c) {
+                    const float *im = img + ((long)b * C + c) * N;
+                    float v00 = sample_zeros(im, H, W, p[0][0], p[0][1]);
+                    float v01 = sample_zeros(im, H, W, p[1][0], p[1][1]);
+                    float v10 = sample_zeros(im, H, W, p[2][0], p[2][1]);
+                    float v11 = sample_zeros(im, H, W, p[3][0], p[3][1]);
+                    /* ATen upsample_bilinear2d: h0lambda*(w0lambda*a + w1lambda*b) + h1lambda*(...) */
+                    out[((long)b * C + c) * N + (long)y * W + x] =
+                        (1.0f - ry.l) * ((1.0f - rx.l) * v00 + rx.l * v01) +
+                        ry.l * ((1.0f - rx.l) * v10 + rx.l * v11);
+                }
+            }
+        }
+}
+
+/* canvas value at (Y,X): inside the box the (H,W)->(h,w) bilinear resize of depth, else 0 */
+static inline float canvas_at(const float *d, int H, int W, int x0, int y0, int w, int h, int Y, int X)
+{
+    if (X < x0 || X >= x0 + w || Y < y0 || Y >= y0 + h) return 0.0f;
+    rs_t ry = resize_src(Y - y0, H, h), rx = resize_src(X - x0, W, w);
+    const float *r0 = d + (long)ry.i0 * W, *r1 = d + (long)ry.i1 * W;
+    return (1.0f - ry.l) * ((1.0f - rx.l) * r0[rx.i0] + rx.l * r0[rx.i1]) +
+           ry.l * ((1.0f - rx.l) * r1[rx.i0] + rx.l * r1[rx.i1]);
+}
+
+/* out[b,c] = ratio[b] * rotate( paste( resize(depth[b,c] -> (h,w)) at (x0,y0) on zeros ), -angle[b] ) */
+MVFO_API void mvfo_affine_restore(const float *depth, const float *angle, const int32_t *box,
+                                  const float *ratio, float *out, int B, int C, int H, int W)
+{
+    long N = (long)H * W;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < B; ++b)
+        for (int y = 0; y < H; ++y) {
+            trig_t t = trig_of(-angle[b]);
+            int x0 = box[b * 4], y0 = box[b * 4 + 1], w = box[b * 4 + 2], h = box[b * 4 + 3];
+            for (int x = 0; x < W; ++x) {
+                float px, py;
+                rot_pos(t, y, x, H, W, &px, &py);
+                float fx = floorf(px), fy = floorf(py);
+                int X = (int)fx, Y = (int)fy;
+                float lx = px - fx, ly = py - fy;
+                for (int c = 0; c < C; ++c) {
+                    const float *d = depth + ((long)b * C + c) * N;
+                    float v = 0.0f;
+                    if (Y >= 0 && Y < H) {
+                        if (X >= 0 && X < W) v += canvas_at(d, H, W, x0, y0, w, h, Y, X) * ((1.0f - lx) * (1.0f - ly));
+                        if (X + 1 >= 0 && X + 1 < W) v += canvas_at(d, H, W, x0, y0, w, h, Y, X + 1) * (lx * (1.0f - ly));
+                    }
+                    if (Y + 1 >= 0 && Y + 1 < H) {
+                        if (X >= 0 && X < W) v += canvas_at(d, H, W, x0, y0, w, h, Y + 1, X) * ((1.0f - lx) * ly);
+                        if (X + 1 >= 0 && X + 1 < W) v += canvas_at(d, H, W, x0, y0, w, h, Y + 1, X + 1) * (lx * ly);
+                    }
+                    out[((long)b * C + c) * N + (long)y * W + x] = v * ratio[b];
+                }
+            }
+        }
+}
+
+/* adjoint of mvfo_affine_restore w.r.t. depth: plain scatter in double (single thread per
+ * plane), g_depth [B,C,H,W] */
+MVFO_API void mvfo_affine_restore_bwd(const float *g_out, const float *angle, const int32_t *box,
+                                      const float *ratio, float *g_depth, int B, int C, int H, int W)
+{
+    long N = (long)H * W;
+#pragma omp parallel for collapse(2)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            double *acc = (double *)calloc((size_t)N, sizeof(double));
+            trig_t t = trig_of(-angle[b]);
+            int x0 = box[b * 4], y0 = box[b * 4 + 1], w = box[b * 4 + 2], h = box[b * 4 + 3];
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    float px, py;
+                    rot_pos(t, y, x, H, W, &px, &py);
+                    float fx = floorf(px), fy = floorf(py);
+                    int X = (int)fx, Y = (int)fy;
+                    float lx = px - fx, ly = py - fy;
+                    double g = (double)g_out[((long)b * C + c) * N + (long)y * W + x] * ratio[b];
+                    for (int k = 0; k < 4; ++k) {
+                        int YY = Y + (k >> 1), XX = X + (k & 1);
+                        if (YY < 0 || YY >= H || XX < 0 || XX >= W) continue;
+                        if (XX < x0 || XX >= x0 + w || YY < y0 || YY >= y0 + h) continue;
+                        double wr = (double)((k & 1) ? lx : 1.0f - lx) * (double)((k >> 1) ? ly : 1.0f - ly);
+                        rs_t ry = resize_src(YY - y0, H, h), rx = resize_src(XX - x0, W, w);
+                        acc[(long)ry.i0 * W + rx.i0] += g * wr * (1.0 - ry.l) * (1.0 - rx.l);
+                        acc[(long)ry.i0 * W + rx.i1] += g * wr * (1.0 - ry.l) * rx.l;
+                        acc[(long)ry.i1 * W + rx.i0] += g * wr * ry.l * (1.0 - rx.l);
+                        acc[(long)ry.i1 * W + rx.i1] += g * wr * ry.l * rx.l;
+                    }
+                }
+            for (long i = 0; i < N; ++i) g_depth[((long)b * C + c) * N + i] = (float)acc[i];
+            free(acc);
+        }
+}

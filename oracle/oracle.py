@@ -291,6 +291,36 @@ def silog(pred, target, mask=None, beta=0.5, gloss=1.0, want_grads=False):
     return (float(v), gp, gt) if want_grads else float(v)
 
 
+def _box(box):
+    return np.ascontiguousarray(box, dtype=np.int32)
+
+
+def affine_transform(img, angle, box):
+    """Trainer.affine_transform (reference train.py:888-902): rotate, crop the box, resize back."""
+    img, angle, box = _f(img), _f(angle).reshape(-1), _box(box)
+    B, Cc, H, W = img.shape
+    out = np.empty_like(img)
+    lib().mvfo_affine_transform(_p(img), _p(angle), _pi(box), _p(out), B, Cc, H, W)
+    return out
+
+
+def affine_restore(depth, angle, box, ratio):
+    """depth_restore of compute_depth_consistency_loss_affine (reference train.py:909-916)."""
+    depth, angle, box, ratio = _f(depth), _f(angle).reshape(-1), _box(box), _f(ratio).reshape(-1)
+    B, Cc, H, W = depth.shape
+    out = np.empty_like(depth)
+    lib().mvfo_affine_restore(_p(depth), _p(angle), _pi(box), _p(ratio), _p(out), B, Cc, H, W)
+    return out
+
+
+def affine_restore_bwd(gout, angle, box, ratio):
+    gout, angle, box, ratio = _f(gout), _f(angle).reshape(-1), _box(box), _f(ratio).reshape(-1)
+    B, Cc, H, W = gout.shape
+    g = np.empty_like(gout)
+    lib().mvfo_affine_restore_bwd(_p(gout), _p(angle), _pi(box), _p(ratio), _p(g), B, Cc, H, W)
+    return g
+
+
 def set_threads(n):
     """OpenMP threads used by the oracle (bench.py's cpu_baseline calibrates this); returns
     the count in effect."""

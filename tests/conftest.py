@@ -82,3 +82,19 @@ def cpu_warp(monkeypatch):
     monkeypatch.setattr(ifrnet, "WARP_IMPL", torch_flow_warp)
     import mono_vifi_amd.networks.fusion_module as fm
     return ifrnet
+
+
+def affine_case(seed, B, C, H, W, lo=0.0, hi=1.0):
+    rng = np.random.default_rng(seed)
+    x = (lo + (hi - lo) * rng.random((B, C, H, W))).astype(np.float32)
+    ratio = rng.uniform(1.2, 2.0, size=(B,)).astype(np.float32)
+    angle = rng.uniform(-5.0, 5.0, size=(B,)).astype(np.float32)
+    box = np.zeros((B, 4), np.int32)
+    for b in range(B):                      # datasets/mono_dataset.py:110-149
+        r = float(ratio[b])
+        h_re, w_re = int(H * r), int(W * r)
+        w0 = int((w_re - W) * rng.random())
+        h0 = int((h_re - H) * rng.random())
+        box[b] = (round(w0 / r), round(h0 / r), min(round(W / r), W - round(w0 / r)),
+                  min(round(H / r), H - round(h0 / r)))
+    return x, angle, box, ratio

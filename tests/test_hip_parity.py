@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import assert_grad_close, load_golden, rel_err
+from conftest import affine_case, assert_grad_close, load_golden, rel_err
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -403,3 +403,70 @@ def test_silog(dev):
     loss.backward()
     assert abs(float(loss.detach()) - ref) <= 1e-5 * abs(ref)
     assert rel_err(N(p.grad), gp) <= 1e-4 and rel_err(N(t.grad), gt) <= 1e-4
+
+
+# ------------------------------------------------------------------ f2: affine glue
+AFFINE_SHAPES = [(2, 3, 32, 64), (3, 1, 37, 101), (2, 2, 5, 7), (12, 3, 192, 640), (8, 1, 320, 1024)]
+
+
+@pytest.mark.parametrize("shape", AFFINE_SHAPES)
+def test_affine_transform_vs_oracle(dev, shape):
+    """Trainer.affine_transform (train.py:888-902): one launch vs the oracle's per-pixel
+    restatement; positions are fp32 values up to W, so values agree to ~1e-4 px of the data's
+    slope (i.i.d. data: the value range)."""
+    from mono_vifi_amd import ops
+    x, angle, box, _ = affine_case(21, *shape)
+    want = O.affine_transform(x, angle, box)
+    got = ops.affine_transform(T(x, dev), T(angle, dev), T(box, dev))
+    assert np.max(np.abs(N(got) - want)) <= 1e-5
+    with pytest.raises(RuntimeError):     # forward only
+        ops.affine_transform(T(x, dev, True), T(angle, dev), T(box, dev))
+
+
+@pytest.mark.parametrize("shape", AFFINE_SHAPES)
+def test_affine_restore_vs_oracle(dev, shape):
+    """depth_restore of compute_depth_consistency_loss_affine (train.py:909-916), forward and
+    the deterministic two-pass adjoint."""
+    from mono_vifi_amd import ops
+    x, angle, box, ratio = affine_case(22, *shape, lo=0.1, hi=100.0)
+    d = T(x, dev, True)
+    out = ops.affine_restore(d, T(angle, dev), T(box, dev), T(ratio, dev))
+    want = O.affine_restore(x, angle, box, ratio)
+    assert np.max(np.abs(N(out) - want)) <= 1e-5 * 200.0
+    g = np.random.default_rng(23).standard_normal(x.shape).astype(np.float32)
+    out.backward(T(g, dev))
+    gd = O.affine_restore_bwd(g, angle, box, ratio)
+    assert rel_err(N(d.grad), gd) <= 1e-5
+    # deterministic: a second backward gives the same bits
+    d2 = T(x, dev, True)
+    ops.affine_restore(d2, T(angle, dev), T(box, dev), T(ratio, dev)).backward(T(g, dev))
+    assert np.array_equal(N(d.grad), N(d2.grad))
+
+
+def test_affine_vs_torch_formulation(dev):
+    """The same maths as batched torch ops on the GPU (tests/torch_affine.py: rotate / crop /
+    paste as grid_sample calls), values and autograd gradient; plus degenerate boxes."""
+    import torch_affine as ta
+    from mono_vifi_amd import ops
+    x, angle, box, ratio = affine_case(24, 4, 3, 96, 160, lo=0.1, hi=10.0)
+    a, b, r = T(angle, dev), T(box, dev), T(ratio, dev)
+    got = ops.affine_transform(T(x, dev), a, b)
+    want = ta.crop_resize_bilinear(ta.rotate_bilinear(T(x, dev), a), b.long())
+    assert float((got - want).abs().max()) <= 2e-4 * 10.0
+    d1, d2 = T(x, dev, True), T(x, dev, True)
+    o1 = ops.affine_restore(d1, a, b, r)
+    o2 = ta.rotate_bilinear(ta.paste_resized(d2, b.long()), -a) * r.view(-1, 1, 1, 1)
+    assert float((o1 - o2).abs().max()) <= 2e-4 * 20.0
+    w = torch.randn_like(o1)
+    (o1 * w).sum().backward()
+    (o2 * w).sum().backward()
+    assert float((d1.grad - d2.grad).abs().max()) <= 2e-4 * float(d2.grad.abs().max())
+    # identity: angle 0, full box, ratio 1
+    z = torch.zeros(4, device=dev)
+    full = torch.tensor([[0, 0, 160, 96]] * 4, dtype=torch.int32, device=dev)
+    one = torch.ones(4, device=dev)
+    assert float((ops.affine_transform(T(x, dev), z, full) - T(x, dev)).abs().max()) <= 1e-5
+    assert float((ops.affine_restore(T(x, dev), z, full, one) - T(x, dev)).abs().max()) <= 1e-5
+    with pytest.raises(RuntimeError):
+        ops.affine_restore(T(x, dev), z[:2], full, one)
+

@@ -89,10 +89,11 @@ def test_synthetic_batch_contract():
 
 
 def test_batched_affine_helpers_match_per_sample_loops():
-    """The batched rotate / crop-resize / paste replace the reference's per-sample Python
-    loops (train.py:888-922); check them against those loops written with torch ops."""
+    """tests/torch_affine.py (the batched torch statement the GPU tests compare the affine
+    kernels with) against the reference's per-sample loops (train.py:888-922) written with
+    torch ops, and against the oracle."""
     import torch.nn.functional as F
-    from mono_vifi_amd import trainer as tr
+    import torch_affine as tr
     torch.manual_seed(0)
     img = torch.rand(3, 2, 32, 48)
     box = torch.tensor([[3, 2, 30, 20], [0, 0, 48, 32], [10, 5, 24, 16]])
@@ -121,3 +122,13 @@ def test_batched_affine_helpers_match_per_sample_loops():
     # +90 deg (counter-clockwise) of a square image == torch.rot90 with k=1
     sq = torch.rand(1, 1, 16, 16)
     assert torch.allclose(tr.rotate_bilinear(sq, torch.tensor([[90.0]])), torch.rot90(sq, 1, (2, 3)), atol=1e-4)
+    # the composed forms against the oracle
+    from oracle import oracle as O
+    angle = torch.tensor([[3.0], [-4.5], [0.7]])
+    ratio = torch.tensor([[1.6], [1.0], [2.0]])
+    want = O.affine_transform(img.numpy(), angle.numpy(), box.numpy())
+    got = tr.crop_resize_bilinear(tr.rotate_bilinear(img, angle), box)
+    assert np.max(np.abs(got.numpy() - want)) <= 2e-5
+    want = O.affine_restore(img.numpy(), angle.numpy(), box.numpy(), ratio.numpy())
+    got = tr.rotate_bilinear(tr.paste_resized(img, box), -angle) * ratio.view(-1, 1, 1, 1)
+    assert np.max(np.abs(got.numpy() - want)) <= 2e-5
