@@ -461,12 +461,12 @@ def test_affine_vs_torch_formulation(dev):
     (o1 * w).sum().backward()
     (o2 * w).sum().backward()
     assert float((d1.grad - d2.grad).abs().max()) <= 2e-4 * float(d2.grad.abs().max())
-    # identity: angle 0, full box, ratio 1
+    # identity: angle 0, full box, ratio 1 (positions carry ~1e-5 px of rounding; data spans 10)
     z = torch.zeros(4, device=dev)
     full = torch.tensor([[0, 0, 160, 96]] * 4, dtype=torch.int32, device=dev)
     one = torch.ones(4, device=dev)
-    assert float((ops.affine_transform(T(x, dev), z, full) - T(x, dev)).abs().max()) <= 1e-5
-    assert float((ops.affine_restore(T(x, dev), z, full, one) - T(x, dev)).abs().max()) <= 1e-5
+    assert float((ops.affine_transform(T(x, dev), z, full) - T(x, dev)).abs().max()) <= 1e-5 * 10.0
+    assert float((ops.affine_restore(T(x, dev), z, full, one) - T(x, dev)).abs().max()) <= 1e-5 * 10.0
     with pytest.raises(RuntimeError):
         ops.affine_restore(T(x, dev), z[:2], full, one)
 
