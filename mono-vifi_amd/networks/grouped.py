@@ -1,0 +1,172 @@
+"""Grouped invocation of a BatchNorm network.
+
+One optimisation step of the reference calls the depth encoder 8 times and the pose
+encoder 6 times on mutually independent inputs (reference: train.py:724-731, 745-747,
+788-797, 830-868), each call normalising with *its own* batch statistics and -- under
+SyncBatchNorm -- issuing its own collectives per layer (280 per direction per step).
+
+Here the G independent inputs are interleaved along the batch dimension
+(sample ``n = b*G + g``), so that a contiguous activation ``[B*G, C, H, W]`` is, without any
+copy, also the tensor ``[B, G*C, H, W]``: batch normalisation over that folded view with the
+affine parameters repeated G times computes exactly the per-call statistics of every call
+in ONE fused batch-norm launch, and under SyncBatchNorm one collective per layer carries
+the statistics of all G calls.  Convolutions, pooling and activations are per-sample and do
+not care about the interleaving.  Running statistics are advanced as the G sequential
+momentum updates the per-call form would perform, in group order.
+
+State-dict keys and shapes are those of ``nn.BatchNorm2d`` (checkpoints interchange with the
+reference's ``.pth`` files).
+"""
+from __future__ import annotations
+
+import contextlib
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def merge_groups(tensors):
+    """G tensors [B, ...] -> [B*G, ...] interleaved (sample n = b*G + g)."""
+    return torch.stack(list(tensors), 1).flatten(0, 1)
+
+
+def split_groups(t, groups):
+    """[B*G, ...] interleaved -> tuple of G views [B, ...] (one autograd node: the backward is
+    a single stack of the group gradients)."""
+    return torch.unbind(t.view(t.shape[0] // groups, groups, *t.shape[1:]), 1)
+
+
+class _AllReduceSyncBN(torch.autograd.Function):
+    """Synchronised batch norm with plain tensor ops and ONE all-reduce per direction
+    (device-agnostic: this is what the gloo tests run; on a HIP device the native fused
+    SyncBatchNorm kernels are used instead, see GroupedBatchNorm2d._sync_bn)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        C = x.shape[1]
+        red = [0] + list(range(2, x.dim()))
+        n_local = x.numel() // C
+        xd = x.double()              # E[x^2] - mean^2 cancels: accumulate the moments in fp64
+        stats = torch.cat([xd.sum(red), (xd * xd).sum(red), xd.new_full((1,), float(n_local))])
+        dist.all_reduce(stats, group=group)
+        n = stats[-1]
+        mean = stats[:C] / n
+        var = (stats[C:2 * C] / n - mean * mean).clamp_min(0.0)
+        invstd = torch.rsqrt(var + eps).to(x.dtype)
+        mean, var, n = mean.to(x.dtype), var.to(x.dtype), n.to(x.dtype)
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = (x - mean.view(shape)) * invstd.view(shape)
+        ctx.save_for_backward(xhat, weight, invstd, n)
+        ctx.group = group
+        ctx.mark_non_differentiable(mean, var, n)
+        return xhat * weight.view(shape) + bias.view(shape), mean, var, n
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv, _gn):
+        xhat, weight, invstd, n = ctx.saved_tensors
+        C = xhat.shape[1]
+        red = [0] + list(range(2, xhat.dim()))
+        shape = [1, C] + [1] * (xhat.dim() - 2)
+        s_gy, s_gyx = gy.sum(red), (gy * xhat).sum(red)
+        both = torch.cat([s_gy, s_gyx])
+        dist.all_reduce(both, group=ctx.group)
+        m_gy, m_gyx = both[:C] / n, both[C:] / n
+        gx = (gy - m_gy.view(shape) - xhat * m_gyx.view(shape)) * (weight * invstd).view(shape)
+        return gx, s_gyx, s_gy, None, None
+
+
+class GroupedBatchNorm2d(nn.BatchNorm2d):
+    """``nn.BatchNorm2d`` whose input may hold ``groups`` interleaved independent calls."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.groups = 1
+        self.sync = False            # synchronise statistics across ranks (SyncBatchNorm semantics)
+        self.process_group = None
+
+    def _sync_bn(self, xv, w, b, rm, rv, world):
+        """SyncBatchNorm over the folded view; updates rm/rv in place."""
+        if xv.is_cuda:
+            from torch.nn.modules._functions import SyncBatchNorm as sync_fn
+            group = self.process_group or dist.group.WORLD
+            return sync_fn.apply(xv, w, b, rm, rv, self.eps, self.momentum, group, world)
+        y, mean, var, n = _AllReduceSyncBN.apply(xv, w, b, self.eps, self.process_group)
+        with torch.no_grad():
+            rm.mul_(1 - self.momentum).add_(mean, alpha=self.momentum)
+            rv.mul_(1 - self.momentum).add_(var * (n / (n - 1)), alpha=self.momentum)
+        return y
+
+    def forward(self, x):
+        G = self.groups
+        world = dist.get_world_size(self.process_group) if (self.sync and dist.is_initialized()) else 1
+        sync = self.sync and world > 1 and self.training
+        if not self.training or (G == 1 and not sync):
+            return super().forward(x)       # eval: running statistics are the same for every call
+        if self.momentum is None or not self.track_running_stats:
+            raise RuntimeError("GroupedBatchNorm2d needs momentum-tracked running statistics")
+        N, C = x.shape[0], x.shape[1]
+        if N % G:
+            raise RuntimeError(f"batch {N} is not a multiple of the group count {G}")
+        if not x.is_contiguous():
+            x = x.contiguous()
+        xv = x.view(N // G, G * C, *x.shape[2:])
+        w, b = self.weight.repeat(G), self.bias.repeat(G)
+        rm, rv = self.running_mean.repeat(G), self.running_var.repeat(G)
+        if sync:
+            y = self._sync_bn(xv, w, b, rm, rv, world)
+        else:
+            y = F.batch_norm(xv, rm, rv, w, b, True, self.momentum, self.eps)
+        self._fold_running(rm, rv, G, C)
+        return y.view_as(x)
+
+    @torch.no_grad()
+    def _fold_running(self, rm, rv, G, C):
+        """rm/rv hold, per group, ONE momentum update from the common starting value:
+        r_g = (1-m) r + m s_g.  The per-call form would apply the G updates in sequence:
+        r <- (1-m)^G r + sum_g m (1-m)^(G-1-g) s_g."""
+        m = self.momentum
+        coef = torch.tensor([(1 - m) ** (G - 1 - g) for g in range(G)], dtype=rm.dtype,
+                            device=rm.device).view(G, 1)
+        for run, upd in ((self.running_mean, rm), (self.running_var, rv)):
+            s_times_m = upd.view(G, C) - (1 - m) * run          # m * s_g
+            run.mul_((1 - m) ** G).add_((coef * s_times_m).sum(0))
+        self.num_batches_tracked += G
+
+
+def convert_grouped_batchnorm(module, sync=False, process_group=None):
+    """Replace every ``nn.BatchNorm2d`` (or SyncBatchNorm) under ``module`` by a
+    ``GroupedBatchNorm2d`` sharing its parameters and buffers; returns the module."""
+    out = module
+    if isinstance(module, (nn.BatchNorm2d, nn.SyncBatchNorm)) and not isinstance(module, GroupedBatchNorm2d):
+        out = GroupedBatchNorm2d(module.num_features, module.eps, module.momentum, module.affine,
+                                 module.track_running_stats)
+        if module.affine:
+            out.weight, out.bias = module.weight, module.bias
+        out.running_mean, out.running_var = module.running_mean, module.running_var
+        out.num_batches_tracked = module.num_batches_tracked
+        out.training = module.training
+    if isinstance(out, GroupedBatchNorm2d):
+        out.sync, out.process_group = bool(sync), process_group
+    for name, child in module.named_children():
+        new = convert_grouped_batchnorm(child, sync, process_group)
+        if new is not child:
+            out.add_module(name, new)
+    return out
+
+
+@contextlib.contextmanager
+def grouped(module, groups):
+    """Within the block, the BatchNorm layers of ``module`` treat their input as ``groups``
+    interleaved independent calls."""
+    bns = [m for m in module.modules() if isinstance(m, GroupedBatchNorm2d)]
+    if groups > 1 and not bns and any(isinstance(m, nn.modules.batchnorm._BatchNorm) for m in module.modules()):
+        raise RuntimeError("grouped(): convert the module with convert_grouped_batchnorm() first")
+    for m in bns:
+        m.groups = groups
+    try:
+        yield module
+    finally:
+        for m in bns:
+            m.groups = 1

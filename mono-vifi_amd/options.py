@@ -99,6 +99,10 @@ def build_parser():
                    help="IFRNet_{L,S}_{KITTI,CS}.pth; random-init teacher when absent")
     p.add_argument("--sync_bn", type=_str2bool, default=True,
                    help="SyncBatchNorm under world_size > 1 (reference: train.py:207)")
+    p.add_argument("--group_calls", type=_str2bool, default=True,
+                   help="run the mutually independent encoder / decoder / pose / fusion invocations "
+                        "of a step as one interleaved batch each, with per-call BatchNorm statistics "
+                        "(networks/grouped.py); False = one call at a time like the reference")
     p.add_argument("--fused_units", type=_str2bool, default=True,
                    help="fused unit kernels (warped images in LDS) instead of the staged "
                         "generate_images_pred + compute_losses_base pair")

@@ -35,7 +35,7 @@ from torch.utils.data import DataLoader
 from . import datasets, parallel
 from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
 from .losses import HotPathLosses
-from .networks import FusionModule, IFRNet, dhrnet, litemono, monodepth2, posenet
+from .networks import FusionModule, IFRNet, dhrnet, grouped, litemono, monodepth2, posenet
 
 
 def setup_logging(log_file=None, filemode="w", rank=0):
@@ -49,6 +49,10 @@ def setup_logging(log_file=None, filemode="w", rank=0):
 def sec_to_hm_str(t):
     t = int(t)
     return "{:02d}h{:02d}m{:02d}s".format(t // 3600, (t % 3600) // 60, t % 60)
+
+
+def split_g(t, groups):
+    return grouped.split_groups(t, groups)
 
 
 class Trainer(HotPathLosses):
@@ -149,8 +153,13 @@ class Trainer(HotPathLosses):
 
         checkpoint = self.load_ckpt() if o.resume else None
 
+        if o.group_calls:
+            # per-call BatchNorm statistics for interleaved grouped calls; with sync_bn one
+            # collective per layer carries the statistics of every call
+            for m in self._modules_unique.values():
+                grouped.convert_grouped_batchnorm(m, sync=o.world_size > 1 and o.sync_bn)
         if o.world_size > 1:
-            if o.sync_bn and self.device.type == "cuda":
+            if o.sync_bn and self.device.type == "cuda" and not o.group_calls:
                 for k in list(self._modules_unique):
                     conv = nn.SyncBatchNorm.convert_sync_batchnorm(self._modules_unique[k])
                     for name, m in self.models.items():
@@ -321,9 +330,63 @@ class Trainer(HotPathLosses):
         out[:, :3, 3:4] = torch.matmul(Rc, pose[:, :3, 3:4])
         return out
 
+    # ---- the independent invocations of a step, one interleaved batch each (networks/grouped.py)
+    def _encode_many(self, name, imgs):
+        """Encoder on G independent inputs -> per input, its feature pyramid.  Grouped: one call
+        on the interleaved batch with per-call BatchNorm statistics."""
+        if not self.opt.group_calls or len(imgs) == 1:
+            return [self._encode(name, im) for im in imgs]
+        G = len(imgs)
+        with grouped.grouped(self.models[name], G):
+            feats = self._encode(name, grouped.merge_groups(imgs))
+        per_level = [grouped.split_groups(f, G) for f in feats]
+        return [[lvl[g] for lvl in per_level] for g in range(G)]
+
+    def _depth_many(self, decoder, feats_list):
+        """Depth decoder on G feature pyramids -> per input {("disp", s): fp32 disparity}."""
+        if not self.opt.group_calls or len(feats_list) == 1:
+            return [self._depth(decoder, f) for f in feats_list]
+        G = len(feats_list)
+        merged = [grouped.merge_groups([f[l] for f in feats_list]) for l in range(len(feats_list[0]))]
+        out = self._depth(decoder, merged)
+        split = {k: grouped.split_groups(v, G) for k, v in out.items()}
+        return [{k: split[k][g] for k in out} for g in range(G)]
+
+    def _fuse_many(self, jobs):
+        """jobs: (three feature pyramids, two flows, merge mask) per fused frame
+        (reference: train.py:788-812) -> per job {("disp", s)} of the multi-frame decoder."""
+        def one(feats, fl, mask):
+            f = self._nets(lambda: self.models["fusion_module"](
+                [[t.float() for t in lvl] for lvl in feats], fl, mask))
+            return self._depth("depth_mf", f)
+        if not self.opt.group_calls or len(jobs) == 1:
+            return [one(*j) for j in jobs]
+        G, L = len(jobs), len(jobs[0][0][0])
+        feats = [[grouped.merge_groups([j[0][pos][l] for j in jobs]) for l in range(L)] for pos in range(3)]
+        flows = [grouped.merge_groups([j[1][k] for j in jobs]) for k in range(2)]
+        mask = grouped.merge_groups([j[2] for j in jobs])
+        out = one(feats, flows, mask)
+        split = {k: grouped.split_groups(v, G) for k, v in out.items()}
+        return [{k: split[k][g] for k in out} for g in range(G)]
+
+    def predict_poses_many(self, pairs):
+        """[(img_a, img_b), ...] -> [(pose a->b, inverted), ...] (reference: train.py:724-731)."""
+        if not self.opt.group_calls or len(pairs) == 1:
+            return [self.predict_poses(a, b) for a, b in pairs]
+        G = len(pairs)
+        x = grouped.merge_groups([torch.cat([a, b], 1) for a, b in pairs])
+        with grouped.grouped(self.models["pose_encoder"], G):
+            feats = [self._encode("pose_encoder", x)]
+        axisangle, translation = self._nets(lambda: self.models["pose"]([[f.float() for f in feats[0]]]))
+        axisangle, translation = axisangle.float(), translation.float()
+        pose = split_g(transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=False), G)
+        pose_inv = split_g(transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=True), G)
+        return list(zip(pose, pose_inv))
+
     def process_batch(self, inputs):
         """Pass a minibatch through the networks and the 9 hot-path units
-        (reference: train.py:698-886)."""
+        (reference: train.py:698-886).  The data flow is the reference's; mutually independent
+        network invocations are issued as one interleaved batch each (`--group_calls`)."""
         o = self.opt
         for key, ipt in inputs.items():
             if torch.is_tensor(ipt):
@@ -350,21 +413,28 @@ class Trainer(HotPathLosses):
                   "loss_dc": torch.zeros((), device=self.device)}
 
         aug = lambda f: inputs[("color_aug", f, 0)]  # noqa: E731
-        pose_n1_0, pose_0_n1 = self.predict_poses(aug(-1), aug(0))
-        pose_0_p1, pose_p1_0 = self.predict_poses(aug(0), aug(1))
-        pose_n1_nt, pose_nt_n1 = self.predict_poses(img_n1, img_nt)
-        pose_nt_p1, pose_p1_nt = self.predict_poses(img_nt, img_p1)
-        pose_n1_pt, pose_pt_n1 = self.predict_poses(img_n1, img_pt)
-        pose_pt_p1, pose_p1_pt = self.predict_poses(img_pt, img_p1)
+        ((pose_n1_0, pose_0_n1), (pose_0_p1, pose_p1_0), (pose_n1_nt, pose_nt_n1), (pose_nt_p1, pose_p1_nt),
+         (pose_n1_pt, pose_pt_n1), (pose_pt_p1, pose_p1_pt)) = self.predict_poses_many(
+            [(aug(-1), aug(0)), (aug(0), aug(1)), (img_n1, img_nt), (img_nt, img_p1), (img_n1, img_pt),
+             (img_pt, img_p1)])
 
-        # ---- single-frame depths
-        feats_0 = self._encode("encoder", aug(0))
-        feats_nt = self._encode("encoder", img_nt)
-        feats_pt = self._encode("encoder", img_pt)
-        disp_0, disp_pt, disp_nt = (self._depth("depth", f) for f in (feats_0, feats_pt, feats_nt))
-        _, depth_0 = disp_to_depth(disp_0[("disp", 0)], o.min_depth, o.max_depth)
-        _, depth_pt = disp_to_depth(disp_pt[("disp", 0)], o.min_depth, o.max_depth)
-        _, depth_nt = disp_to_depth(disp_nt[("disp", 0)], o.min_depth, o.max_depth)
+        # ---- encoder invocations, in the reference's call order (train.py:745-747, 788-797, 830-868)
+        enc_in = [aug(0), img_nt, img_pt]
+        if o.fuse_model_type != "separate_all":
+            enc_in += [aug(-1), aug(1)]
+        if o.use_affine:
+            tgts_a = [inputs[("color_affine", 0, 0)], self.affine_transform(img_nt, inputs),
+                      self.affine_transform(img_pt, inputs)]
+            enc_in += [inputs[("color_affine_aug", 0, 0)], tgts_a[1], tgts_a[2]]
+        enc = self._encode_many("encoder", enc_in)
+        feats_0, feats_nt, feats_pt = enc[0], enc[1], enc[2]
+        feats_aff = enc[-3:] if o.use_affine else []
+
+        # ---- single-frame depths (plain and affine views share the decoder)
+        dec = self._depth_many("depth", [feats_0, feats_pt, feats_nt] + feats_aff)
+        disp_0, disp_pt, disp_nt = dec[0], dec[1], dec[2]
+        to_depth = lambda d: disp_to_depth(d[("disp", 0)], o.min_depth, o.max_depth)[1]  # noqa: E731
+        depth_0, depth_pt, depth_nt = to_depth(disp_0), to_depth(disp_pt), to_depth(disp_nt)
 
         srcs = [img_n1, img_p1]
         losses["loss_base"] = losses["loss_base"] + self._unit(disp_0, img_0, [pose_0_n1, pose_0_p1], srcs, K, inv_K)
@@ -373,24 +443,16 @@ class Trainer(HotPathLosses):
 
         # ---- multi-frame depths
         if o.fuse_model_type == "separate_all":
-            feats_0 = self._encode("encoder_mf", aug(0))
-            feats_nt = self._encode("encoder_mf", img_nt)
-            feats_pt = self._encode("encoder_mf", img_pt)
-            feats_n1 = self._encode("encoder_mf", aug(-1))
-            feats_p1 = self._encode("encoder_mf", aug(1))
+            feats_0, feats_nt, feats_pt, feats_n1, feats_p1 = self._encode_many(
+                "encoder_mf", [aug(0), img_nt, img_pt, aug(-1), aug(1)])
         else:
-            feats_n1 = self._encode("encoder", aug(-1))
-            feats_p1 = self._encode("encoder", aug(1))
-
-        def fuse(feats, fl, mask):
-            f = self._nets(lambda: self.models["fusion_module"](
-                [[t.float() for t in lvl] for lvl in feats], fl, mask))
-            d = self._depth("depth_mf", f)
-            return d, disp_to_depth(d[("disp", 0)], o.min_depth, o.max_depth)[1]
-
-        disp_0_fuse, depth_0_fuse = fuse([feats_n1, feats_0, feats_p1], [flow_0_n1, flow_0_p1], merge_mask_01)
-        disp_nt_fuse, depth_nt_fuse = fuse([feats_n1, feats_nt, feats_0], [flow_nt_n1, flow_nt_0], merge_mask_nt)
-        disp_pt_fuse, depth_pt_fuse = fuse([feats_0, feats_pt, feats_p1], [flow_pt_0, flow_pt_p1], merge_mask_pt)
+            feats_n1, feats_p1 = enc[3], enc[4]
+        fused = self._fuse_many([
+            ([feats_n1, feats_0, feats_p1], [flow_0_n1, flow_0_p1], merge_mask_01),
+            ([feats_n1, feats_nt, feats_0], [flow_nt_n1, flow_nt_0], merge_mask_nt),
+            ([feats_0, feats_pt, feats_p1], [flow_pt_0, flow_pt_p1], merge_mask_pt)])
+        disp_0_fuse, disp_nt_fuse, disp_pt_fuse = fused
+        depth_0_fuse, depth_nt_fuse, depth_pt_fuse = (to_depth(d) for d in fused)
 
         losses["loss_base"] = losses["loss_base"] + self._unit(disp_0_fuse, img_0, [pose_0_n1, pose_0_p1], srcs, K, inv_K)
         losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_0, depth_0_fuse)
@@ -405,18 +467,10 @@ class Trainer(HotPathLosses):
             Rc_inv = torch.inverse(Rc)
             srcs_a = [inputs[("color_affine", -1, 0)], inputs[("color_affine", 1, 0)]]
             mask_rec = inputs["valid_mask_rec"]
-            todo = (
-                (inputs[("color_affine_aug", 0, 0)], inputs[("color_affine", 0, 0)], pose_0_n1, pose_0_p1,
-                 depth_0, depth_0_fuse),
-                (None, img_nt, pose_nt_n1, pose_nt_p1, depth_nt, depth_nt_fuse),
-                (None, img_pt, pose_pt_n1, pose_pt_p1, depth_pt, depth_pt_fuse),
-            )
-            for net_in, tgt, pa, pb, depth_s, depth_f in todo:
-                if net_in is None:
-                    tgt = self.affine_transform(tgt, inputs)
-                    net_in = tgt
-                disp_a = self._depth("depth", self._encode("encoder", net_in))
-                _, depth_a = disp_to_depth(disp_a[("disp", 0)], o.min_depth, o.max_depth)
+            todo = ((pose_0_n1, pose_0_p1, depth_0, depth_0_fuse), (pose_nt_n1, pose_nt_p1, depth_nt, depth_nt_fuse),
+                    (pose_pt_n1, pose_pt_p1, depth_pt, depth_pt_fuse))
+            for (pa, pb, depth_s, depth_f), tgt, disp_a in zip(todo, tgts_a, dec[3:]):
+                depth_a = to_depth(disp_a)
                 poses_a = [self._affine_pose(pa, Rc, Rc_inv), self._affine_pose(pb, Rc, Rc_inv)]
                 losses["loss_base"] = losses["loss_base"] + self._unit(disp_a, tgt, poses_a, srcs_a, K, inv_K, mask_rec)
                 losses["loss_dc"] = losses["loss_dc"] + self.compute_depth_consistency_loss_affine(

@@ -1,0 +1,137 @@
+"""CPU: grouped invocation of a BatchNorm network is the same
+function as the reference's sequence of independent calls (train.py:745-747, 788-797,
+830-868): outputs, parameter gradients and running statistics; under SyncBatchNorm
+semantics with 2 ranks over gloo, one collective per layer carries all groups."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _nets():
+    from mono_vifi_amd.networks import grouped, monodepth2
+    torch.manual_seed(3)
+    ref = monodepth2.DepthEncoder(18, False)
+    # non-trivial affine parameters and running statistics
+    for m in ref.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.weight.data.uniform_(0.5, 1.5)
+            m.bias.data.uniform_(-0.2, 0.2)
+            m.running_mean.uniform_(-0.1, 0.1)
+            m.running_var.uniform_(0.8, 1.2)
+    grp = grouped.convert_grouped_batchnorm(copy.deepcopy(ref))
+    return ref, grp, grouped
+
+
+def _loss(feats, wts):
+    return sum((f * w).sum() for f, w in zip(feats, wts))
+
+
+def test_grouped_equals_sequential_calls():
+    ref, grp, grouped = _nets()
+    assert list(ref.state_dict()) == list(grp.state_dict())      # checkpoint-compatible
+    G, B = 3, 2
+    torch.manual_seed(5)
+    xs = [torch.rand(B, 3, 32, 64) for _ in range(G)]
+    # reference: G independent calls, in order
+    outs = [ref(x) for x in xs]
+    wts = [[torch.randn_like(f) for f in o] for o in outs]
+    sum(_loss(o, w) for o, w in zip(outs, wts)).backward()
+    # grouped: one call
+    with grouped.grouped(grp, G):
+        feats = grp(grouped.merge_groups(xs))
+    per_group = list(zip(*[grouped.split_groups(f, G) for f in feats]))
+    sum(_loss(o, w) for o, w in zip(per_group, wts)).backward()
+    for o, p in zip(outs, per_group):
+        for a, b in zip(o, p):
+            assert torch.allclose(a, b, atol=2e-5, rtol=1e-4)
+    for (n, a), (_, b) in zip(ref.named_parameters(), grp.named_parameters()):
+        assert torch.allclose(a.grad, b.grad, atol=1e-4 * float(a.grad.abs().max()) + 1e-7), n
+    for (n, a), (_, b) in zip(ref.named_buffers(), grp.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), atol=1e-6, rtol=1e-5), n
+    # groups == 1 and eval mode fall through to the plain layer
+    assert all(m.groups == 1 for m in grp.modules() if isinstance(m, grouped.GroupedBatchNorm2d))
+    ref.eval(), grp.eval()
+    with grouped.grouped(grp, G):
+        e = grp(grouped.merge_groups(xs))
+    for lvl, f in enumerate(e):
+        for g, v in enumerate(grouped.split_groups(f, G)):
+            assert torch.allclose(v, ref(xs[g])[lvl], atol=2e-5, rtol=1e-4)
+
+
+def test_grouped_requires_conversion_and_divisible_batch():
+    from mono_vifi_amd.networks import grouped, monodepth2
+    net = monodepth2.DepthEncoder(18, False)
+    with pytest.raises(RuntimeError):
+        with grouped.grouped(net, 2):
+            pass
+    net = grouped.convert_grouped_batchnorm(net)
+    with pytest.raises(RuntimeError):
+        with grouped.grouped(net, 2):
+            net(torch.rand(3, 3, 32, 64))
+
+
+def _sync_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    ref, grp, grouped = _nets()
+    grouped.convert_grouped_batchnorm(grp, sync=True)
+    G, B = 3, 2
+    torch.manual_seed(7)
+    xs_all = [torch.rand(world * B, 3, 32, 64) for _ in range(G)]     # global batch of every call
+    xs = [x[rank * B:(rank + 1) * B] for x in xs_all]
+    calls = {"n": 0}
+    orig = dist.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    dist.all_reduce = counting
+    with grouped.grouped(grp, G):
+        feats = grp(grouped.merge_groups(xs))
+    n_fwd = calls["n"]
+    per_group = list(zip(*[grouped.split_groups(f, G) for f in feats]))
+    torch.manual_seed(9)
+    wts_all = [[torch.randn(world * B, *f.shape[1:]) for f in o] for o in per_group]
+    wts = [[w[rank * B:(rank + 1) * B] for w in ws] for ws in wts_all]
+    sum(_loss(o, w) for o, w in zip(per_group, wts)).backward()
+    dist.all_reduce = orig
+    n_bn = sum(isinstance(m, grouped.GroupedBatchNorm2d) for m in grp.modules())
+    # gradient all-reduce of the trainer (sum over ranks == gradient of the global-batch loss)
+    for p in grp.parameters():
+        dist.all_reduce(p.grad)
+    if rank == 0:
+        outs = [ref(x) for x in xs_all]                      # the global batch, per call
+        sum(_loss(o, w) for o, w in zip(outs, wts_all)).backward()
+        ok = n_fwd == n_bn and calls["n"] == 2 * n_bn          # ONE collective per layer per direction
+        for o, p in zip(outs, per_group):
+            for a, b in zip(o, p):
+                ok = ok and torch.allclose(a[:B], b, atol=5e-5, rtol=1e-4)
+        for (n, a), (_, b) in zip(ref.named_parameters(), grp.named_parameters()):
+            ok = ok and torch.allclose(a.grad, b.grad, atol=2e-4 * float(a.grad.abs().max()) + 1e-7)
+        for (n, a), (_, b) in zip(ref.named_buffers(), grp.named_buffers()):
+            ok = ok and torch.allclose(a.float(), b.float(), atol=1e-5, rtol=1e-4)
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_grouped_sync_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert q.get(timeout=10) is True

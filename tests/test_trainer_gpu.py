@@ -98,3 +98,31 @@ def test_other_backbones_step(tmp_path, backbone):
     t.set_train()
     losses = t.optimisation_step(device_batch(2, 64, 96, t.device))
     assert all(np.isfinite(float(losses[k].detach())) for k in ("loss", "loss_base", "loss_dc"))
+
+
+def test_grouped_calls_equal_one_call_at_a_time(tmp_path):
+    """--group_calls (interleaved grouped invocations, per-call BatchNorm statistics) is the
+    same function as the reference's one-call-at-a-time step: losses, gradients, running
+    statistics."""
+    t = make_trainer(tmp_path)
+    t.set_train()
+    batch = device_batch(2, 64, 96, t.device)
+    g = torch.Generator(device=t.device).manual_seed(3)
+    t.tie_break_noise = torch.randn((2, 2, 64, 96), device=t.device, generator=g)
+    state0 = {k: {n: v.clone() for n, v in m.state_dict().items()} for k, m in t.models.items()}
+    out = {}
+    for grp in (True, False):
+        for k, m in t.models.items():
+            m.load_state_dict(state0[k])
+        t.opt.group_calls = grp
+        _, losses = t.process_batch(dict(batch))
+        t.reducer.zero_grad()
+        losses["loss"].backward()
+        t.reducer.finish()
+        bufs = torch.cat([b.flatten().float() for m in t._modules_unique.values() for b in m.buffers()])
+        out[grp] = (float(losses["loss"]), float(losses["loss_dc"]),
+                    torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone(), bufs.clone())
+    assert abs(out[True][0] - out[False][0]) <= 1e-5 * abs(out[False][0])
+    assert abs(out[True][1] - out[False][1]) <= 1e-5 * abs(out[False][1]) + 1e-7
+    assert float((out[True][2] - out[False][2]).norm() / out[False][2].norm()) <= 2e-3
+    assert torch.allclose(out[True][3], out[False][3], rtol=1e-4, atol=1e-5)
