@@ -396,12 +396,24 @@ class Trainer(HotPathLosses):
         img_n1, img_p1, img_0 = inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("color", 0, 0)]
 
         with torch.no_grad():
-            img_nt, flow_nt_n1, flow_nt_0, merge_mask_nt = self._nets(
-                lambda: self.model_vfi_train(img_n1, img_0, embt))
-            img_pt, flow_pt_0, flow_pt_p1, merge_mask_pt = self._nets(
-                lambda: self.model_vfi_train(img_0, img_p1, embt))
-            flow_0_n1, flow_0_p1, merge_mask_01 = self._nets(
-                lambda: self.model_vfi_train(img_n1, img_p1, embt, onlyFlow=True))
+            if o.group_calls:
+                # the three teacher passes (train.py:715-722) as one batch: IFRNet has no batch
+                # statistics, so plain concatenation is exact; the synthesised frame of the
+                # third (flow-only) pair is simply not used
+                e3 = torch.cat([embt, embt, embt], 0)
+                im, f_a, f_b, mk = self._nets(lambda: self.model_vfi_train(
+                    torch.cat([img_n1, img_0, img_n1], 0), torch.cat([img_0, img_p1, img_p1], 0), e3))
+                img_nt, img_pt, _ = im.chunk(3)
+                flow_nt_n1, flow_pt_0, flow_0_n1 = f_a.chunk(3)
+                flow_nt_0, flow_pt_p1, flow_0_p1 = f_b.chunk(3)
+                merge_mask_nt, merge_mask_pt, merge_mask_01 = mk.chunk(3)
+            else:
+                img_nt, flow_nt_n1, flow_nt_0, merge_mask_nt = self._nets(
+                    lambda: self.model_vfi_train(img_n1, img_0, embt))
+                img_pt, flow_pt_0, flow_pt_p1, merge_mask_pt = self._nets(
+                    lambda: self.model_vfi_train(img_0, img_p1, embt))
+                flow_0_n1, flow_0_p1, merge_mask_01 = self._nets(
+                    lambda: self.model_vfi_train(img_n1, img_p1, embt, onlyFlow=True))
             img_nt, img_pt = img_nt.float(), img_pt.float()
             flows = [t.float() for t in (flow_nt_n1, flow_nt_0, flow_pt_0, flow_pt_p1, flow_0_n1,
                                          flow_0_p1, merge_mask_nt, merge_mask_pt, merge_mask_01)]
