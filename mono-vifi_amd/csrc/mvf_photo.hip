@@ -324,6 +324,41 @@ MVF_DEV void stage_pair3(f2 *__restrict__ pairP, const float *__restrict__ im0,
     stage_lane3(pairP, 1, im1, N, H, W, py0, px0);
 }
 
+// Kernel prologue: target (3 planes), disparity and a first candidate pair taken straight
+// from global planes, with ALL 35 loads of a lane in flight before the first LDS store -- one
+// exposed memory latency for what would otherwise be three staging phases.
+MVF_DEV void stage_first(float *__restrict__ tgtP, float *__restrict__ dispP, f2 *__restrict__ pairP,
+                         const float *__restrict__ tgt, const float *__restrict__ disp,
+                         const float *__restrict__ im0, const float *__restrict__ im1, size_t N, int H,
+                         int W, int py0, int px0)
+{
+    float vt[NSTAGE][3], vd[NSTAGE], va[NSTAGE][3], vb[NSTAGE][3];
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
+        int r = idx / PW, c = idx - r * PW;
+        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
+        unsigned o = (unsigned)gy * W + gx;
+        vt[it][0] = tgt[o]; vt[it][1] = tgt[N + o]; vt[it][2] = tgt[2 * N + o];
+        vd[it] = disp[o];
+        va[it][0] = im0[o]; va[it][1] = im0[N + o]; va[it][2] = im0[2 * N + o];
+        vb[it][0] = im1[o]; vb[it][1] = im1[N + o]; vb[it][2] = im1[2 * N + o];
+    }
+#pragma unroll
+    for (int it = 0; it < NSTAGE; ++it) {
+        int idx = threadIdx.x + it * NT;
+        int r = idx / PW, c = idx - r * PW;
+        if (idx < PH * PW) {
+            const int e = r * LDW + c;
+            tgtP[e] = vt[it][0]; tgtP[PLANE + e] = vt[it][1]; tgtP[2 * PLANE + e] = vt[it][2];
+            dispP[e] = vd[it];
+            pairP[e] = mk2(va[it][0], vb[it][0]);
+            pairP[PPLANE + e] = mk2(va[it][1], vb[it][1]);
+            pairP[2 * PPLANE + e] = mk2(va[it][2], vb[it][2]);
+        }
+    }
+}
+
 // generate_images_pred for TWO sources at one pixel: the ray, depth and camera point are
 // shared, the projection runs packed (lane 0 = source a, lane 1 = source b).
 struct WarpPair {
@@ -522,16 +557,10 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
         int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
         sh.P[k][e] = proj_entry(a.K + b * 16, a.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
     }
-    stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
-    stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
-    __syncthreads();
-
-    const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
-    const int off = row * LDW + seg * PX;   // plane element of the window's top-left
-    const int y = ty0 + row, x0 = tx0 + seg * PX;
-
-    // candidates in evaluation order: S warped sources, then (auto-masking) S identity
-    // sources; evaluated two at a time
+    // candidates: S warped sources, then (auto-masking) S identity sources; evaluated two at
+    // a time, LAST pair first: a pair that comes straight from global planes (identity
+    // sources; every pair of the staged kernel) is fetched together with the target and the
+    // disparity in the prologue, and the fused warp (which needs the staged disparity) follows
     constexpr int NC = 2 * S;
     float val[NC][PX];
     const int ncand = automask ? 2 * S : S;
@@ -540,17 +569,47 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
 #else
     const int npair = (ncand + 1) >> 1;
 #endif
+    bool prologue_pair = false;
+    {
+        const int ca = 2 * (npair - 1), cb = (ca + 1 < ncand) ? ca + 1 : ca;
+        const bool wa = ca < S, wb = cb < S;
+        const int ka = wa ? ca : ca - S, kb = wb ? cb : cb - S;
+#ifdef MVF_ABL_NOWARP
+        prologue_pair = true;
+        const float *ima = a.src.p[ka], *imb = a.src.p[kb];
+#else
+        prologue_pair = !(FUSED && wa);
+        const float *ima = FUSED ? a.src.p[ka] : (wa ? a.warped.p[ka] : a.src.p[ka]);
+        const float *imb = FUSED ? a.src.p[kb] : (wb ? a.warped.p[kb] : a.src.p[kb]);
+#endif
+        if (prologue_pair) {
+            stage_first(tgtP, dispP, pairP, a.tgt + (size_t)b * 3 * N, a.disp + (size_t)b * N,
+                        ima + (size_t)b * 3 * N, imb + (size_t)b * 3 * N, N, H, W, py0, px0);
+        } else {
+            stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
+            stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
+        }
+    }
+    __syncthreads();
+
+    const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
+    const int off = row * LDW + seg * PX;   // plane element of the window's top-left
+    const int y = ty0 + row, x0 = tx0 + seg * PX;
+
 #pragma unroll 1
-    for (int pr = 0; pr < npair; ++pr) {
+    for (int pr = npair - 1; pr >= 0; --pr) {
         const int ca = 2 * pr, cb = (2 * pr + 1 < ncand) ? 2 * pr + 1 : 2 * pr;
         const bool wa = ca < S, wb = cb < S;              // warped (vs identity) candidates
         const int ka = wa ? ca : ca - S, kb = wb ? cb : cb - S;
-        __syncthreads();   // previous pair fully consumed
+        const bool staged = prologue_pair && pr == npair - 1;
+        if (!staged && pr != npair - 1) __syncthreads();   // previous pair fully consumed
 #ifdef MVF_ABL_NOWARP
-        if (false) {
+        if (staged) {
+        } else if (false) {
             if (wa) {
 #else
-        if (FUSED) {
+        if (staged) {
+        } else if (FUSED) {
             if (wa) {
 #endif
                 // lane 0 (and lane 1 when it is a warped source too) by the fused warp
@@ -577,7 +636,7 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
 #endif
             stage_pair3(pairP, ima, imb, N, H, W, py0, px0);
         }
-        __syncthreads();
+        if (!staged) __syncthreads();
         f2 out[PX];
 #ifdef MVF_ABL_NOREPROJ
         {
@@ -1002,10 +1061,7 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
             f2 accP[12];
 #pragma unroll
             for (int q = 0; q < 12; ++q) accP[q] = f2s(0.0f);
-#ifndef MVF_CHAIN_UNROLL
-#define MVF_CHAIN_UNROLL 4
-#endif
-#pragma unroll MVF_CHAIN_UNROLL
+#pragma unroll 4
             for (int j = 0; j < PX; ++j) {
 #ifdef MVF_ABL_NOCHAINB
                 continue;
