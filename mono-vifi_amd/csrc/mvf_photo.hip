@@ -870,11 +870,6 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
         sh.P[k][e] = proj_entry(a.K + b * 16, a.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
     }
-    stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
-    stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
-    for (int i = threadIdx.x; i < RPLANE; i += NT) gdP[i] = 0.0f;
-    __syncthreads();
-
     const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
     const int off = row * LDW + seg * PX;
     const int roff = row * LDW + seg * PX;   // region-plane element of this lane's first pixel
@@ -882,7 +877,8 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
     const bool rowin = (y >= 0) && (y < H);
     const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
 
-    // base weight of every region pixel: gpix * mask (0 outside the image), and its argmin
+    // argmin and mask of every region pixel: issued with the prologue's plane loads (one
+    // memory phase), weighted after the barrier
     float wbase[PX];
     int sel[PX];
 #pragma unroll
@@ -892,8 +888,15 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         const size_t pi = (size_t)b * N + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
         sel[j] = in ? (int)a.argmin[pi] : 254;
         float m = (in && a.mask) ? a.mask[pi] : 1.0f;
-        wbase[j] = in ? sh.gpix * m : 0.0f;
+        wbase[j] = in ? m : 0.0f;
     }
+    stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
+    stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
+    for (int i = threadIdx.x; i < RPLANE; i += NT) gdP[i] = 0.0f;
+    __syncthreads();
+    // base weight of every region pixel: gpix * mask (0 outside the image)
+#pragma unroll
+    for (int j = 0; j < PX; ++j) wbase[j] = sh.gpix * wbase[j];
 
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
 
