@@ -305,6 +305,48 @@ __global__ void __launch_bounds__(NT) k_flow_warp_fwd(const float *__restrict__ 
         out[((size_t)b * C + c) * N + i] = bilerp(img + ((size_t)b * C + c) * N, W, t);
 }
 
+// The L2 executes fp32 atomics at about one dword per clock per channel, so the scatter is
+// bound by the NUMBER of atomics (4 per element), not by bytes.  Lanes of a wavefront walk
+// consecutive x; for a locally uniform integer displacement the east tap of lane l is the
+// west tap of lane l+1 (same rows): lane l+1 then takes that contribution over with a
+// cross-lane move and ONE atomic serves both -- 2 atomics per element instead of 4.  The
+// hand-over is decided per lane pair from the integer taps, so any flow field is handled
+// (lanes that do not line up keep their own atomics).
+struct ScatterLinks {
+    bool from_left;    // my west column == left neighbour's east column, same rows: I add its east values
+    bool to_right;     // ... and the right neighbour takes my east values
+};
+MVF_DEV ScatterLinks scatter_links(const Tap &t, bool active)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int act = active ? 1 : 0;
+    const int lx1 = __shfl_up(t.x1, 1), ly0 = __shfl_up(t.y0, 1), ly1 = __shfl_up(t.y1, 1),
+              la = __shfl_up(act, 1);
+    const int rx0 = __shfl_down(t.x0, 1), ry0 = __shfl_down(t.y0, 1), ry1 = __shfl_down(t.y1, 1),
+              ra = __shfl_down(act, 1);
+    ScatterLinks k;
+    k.from_left = active && lane > 0 && la && lx1 == t.x0 && ly0 == t.y0 && ly1 == t.y1;
+    k.to_right = active && lane < kWave - 1 && ra && rx0 == t.x1 && ry0 == t.y0 && ry1 == t.y1;
+    return k;
+}
+// all lanes of the wavefront must call this (cross-lane moves); inactive lanes pass g = 0
+MVF_DEV void scatter_taps_linked(float *__restrict__ gi, int W, const Tap &t, float g, bool active,
+                                 const ScatterLinks &k)
+{
+    float w = t.wx, e = 1.0f - w, n = t.wy, s = 1.0f - n;
+    float nw = g * (s * e), ne = g * (s * w), sw = g * (n * e), se = g * (n * w);
+    const float lne = __shfl_up(ne, 1), lse = __shfl_up(se, 1);
+    if (k.from_left) { nw += lne; sw += lse; }
+    if (active) {
+        atomicAdd(gi + t.y0 * W + t.x0, nw);
+        atomicAdd(gi + t.y1 * W + t.x0, sw);
+        if (!k.to_right) {
+            atomicAdd(gi + t.y0 * W + t.x1, ne);
+            atomicAdd(gi + t.y1 * W + t.x1, se);
+        }
+    }
+}
+
 __global__ void __launch_bounds__(NT) k_flow_warp_bwd(const float *__restrict__ img,
                                                       const float *__restrict__ flow,
                                                       const float *__restrict__ xs,
@@ -315,23 +357,25 @@ __global__ void __launch_bounds__(NT) k_flow_warp_bwd(const float *__restrict__ 
                                                       int W)
 {
     int N = H * W, b = blockIdx.z;
-    int i = blockIdx.x * NT + threadIdx.x;
-    if (i >= N) return;
+    const int i_raw = blockIdx.x * NT + threadIdx.x;
+    const bool active = i_raw < N;
+    const int i = active ? i_raw : N - 1;
     int y = i / W, x = i - y * W;
     Tap t = flow_tap(flow, xs, ys, b, i, x, y, H, W);
+    const ScatterLinks links = scatter_links(t, active);
     int c0 = blockIdx.y * FW_CCH, c1 = min(c0 + FW_CCH, C);
     float gx = 0.0f, gy = 0.0f;
     for (int c = c0; c < c1; ++c) {
-        float go = g_out[((size_t)b * C + c) * N + i];
-        if (g_img) scatter_taps(g_img + ((size_t)b * C + c) * N, W, t, go);
-        if (g_flow_part) {
+        float go = active ? g_out[((size_t)b * C + c) * N + i] : 0.0f;
+        if (g_img) scatter_taps_linked(g_img + ((size_t)b * C + c) * N, W, t, go, active, links);
+        if (g_flow_part && active) {
             float dx, dy;
             bilerp_grad(img + ((size_t)b * C + c) * N, W, t, dx, dy);
             gx += go * dx;
             gy += go * dy;
         }
     }
-    if (g_flow_part) {
+    if (g_flow_part && active) {
         // d(ix)/d(flow_x) = ((W-1)/2) / ((W-1)/2) = 1 where the coordinate was not clipped;
         // chunk partials are summed by the caller-visible second pass (k_flow_grad_fold)
         size_t o = (((size_t)blockIdx.y * gridDim.z + b) * 2) * N + i;
