@@ -180,15 +180,25 @@ def cpu_baseline(args):
                       f"{cores} of {host_cores} host cores (fastest of a thread-count sweep)"}
 
 
-def traffic_from_profiles(kernel):
-    """HBM bytes per launch measured offline with rocprofv3 --pmc (separate passes,
-    FETCH_SIZE doubled per the gfx950 note); committed under profiles/."""
+def _profiles_json():
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(kernel)
+            return json.load(f)
     except (OSError, ValueError):
-        return None
+        return {}
+
+
+def traffic_from_profiles(kernel):
+    """HBM bytes per launch measured offline with rocprofv3 --pmc (separate passes,
+    FETCH_SIZE doubled per the gfx950 note); committed under profiles/."""
+    return _profiles_json().get(kernel)
+
+
+def valu_from_profiles(kernel):
+    """VALU-pipe utilisation of the kernel from the committed PMC pass (what actually bounds
+    a kernel whose HBM fraction is low): {"valu_busy": ..., "valu_instr_per_px": ...} or None."""
+    return _profiles_json().get("_valu", {}).get(kernel)
 
 
 def main():
@@ -235,7 +245,8 @@ def main():
         ach = bytes_px * px / avg_s / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": traffic_from_profiles(name), "avg_us": round(avg_s * 1e6, 2),
+                "traffic": traffic_from_profiles(name), "valu": valu_from_profiles(name),
+                "avg_us": round(avg_s * 1e6, 2),
                 "launches": n, "algorithmic_bytes_per_launch": bytes_px * px}
 
     r_fwd = roof(fwd_ms, fwd_n, FWD_BYTES_PER_PX, "k_photo_fwd<fused>")
