@@ -269,6 +269,49 @@ MVF_DEV f2 div3(f2 x)
     return pk_fma(r, c, q);
 }
 
+// ---- correctly rounded fp32 division without the range guards --------------------------
+// The compiler lowers `n / d` to v_div_scale x2, v_rcp, Newton step, quotient, two residual
+// corrections, v_div_fmas, v_div_fixup (11 instructions).  The scale / fixup instructions
+// only act when an exponent is extreme (|d| or |n| outside ~[2^-96, 2^96], denormals, 0,
+// inf, NaN); everywhere else they are the identity and the result is that of the core
+// below -- the same operations in the same order, so the same bits.  Used where the operand
+// range is known by construction or checked by the caller (div_safe), it (a) drops the three
+// guard instructions, (b) runs packed for a candidate pair, and (c) lets several quotients
+// over the same denominator share the refined reciprocal.
+MVF_DEV float recip_refined(float d)
+{
+    float r = __builtin_amdgcn_rcpf(d);
+    float e = fmaf(-d, r, 1.0f);
+    return fmaf(e, r, r);
+}
+MVF_DEV float div_core(float n, float d, float r1)
+{
+    float q = n * r1;
+    float rem = fmaf(-d, q, n);
+    float q1 = fmaf(rem, r1, q);
+    float rem1 = fmaf(-d, q1, n);
+    return fmaf(rem1, r1, q1);
+}
+MVF_DEV f2 recip_refined(f2 d)
+{
+    f2 r = mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+    f2 e = pk_fma(-d, r, f2s(1.0f));
+    return pk_fma(e, r, r);
+}
+MVF_DEV f2 div_core(f2 n, f2 d, f2 r1)
+{
+    f2 q = n * r1;
+    f2 rem = pk_fma(-d, q, n);
+    f2 q1 = pk_fma(rem, r1, q);
+    f2 rem1 = pk_fma(-d, q1, n);
+    return pk_fma(rem1, r1, q1);
+}
+// exponent of |x| within [-60, 60] (finite, normal, far from over/underflow in the core)
+MVF_DEV bool div_safe(float x)
+{
+    return (unsigned)(__builtin_amdgcn_frexp_expf(x) + 60) <= 121u;
+}
+
 // ------------------------------------------------------------------------------- SSIM
 MVF_DEV int refl(int j, int n)
 {
