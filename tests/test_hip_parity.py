@@ -280,6 +280,58 @@ def test_ragged_shapes_vs_oracle(dev, shape, flags):
     assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
 
 
+# ------------------------------------------------------------------ other source counts
+@pytest.mark.parametrize("S", [1, 3, 4])
+@pytest.mark.parametrize("flags", [0, 2, 4])
+@pytest.mark.parametrize("path", ["fused", "staged"])
+def test_source_counts_vs_oracle(dev, S, flags, path):
+    """1, 3 and 4 source frames (odd counts exercise the mixed warped/identity candidate pair
+    of the tile engine; the reference's loops are generic in len(frame_ids))."""
+    from mono_vifi_amd import ops, synthetic
+    B, H, W = 2, 33, 70
+    inp = synthetic.unit_inputs(300 + 10 * S + flags, B, H, W, num_src=S, pose_scale=0.03, with_mask=True)
+    T_np = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k % 2 == 1))
+                     for k in range(S)], 0)
+    noise_np = np.ascontiguousarray(inp["noise"][:, :1] if flags & 2 else inp["noise"])
+    ref = O.unit(inp["disp"], inp["tgt"], inp["src"], T_np, inp["K"], inp["inv_K"], noise_np,
+                 inp["mask_rec"], flags, want_grads=True)
+    noise = None if flags & 4 else T(noise_np, dev)
+    disp = T(inp["disp"], dev, True)
+    Tt = T(T_np, dev, True)
+    srcs = [T(inp["src"][k], dev) for k in range(S)]
+    if path == "fused":
+        cfgt = (S, flags, 1e-3, 0.1, 100.0, 1e-7, True, True)
+        loss, _, argmin, idx, _ = ops.Unit.apply(disp, T(inp["tgt"], dev), Tt, T(inp["K"], dev),
+                                                 T(inp["inv_K"], dev), T(inp["mask_rec"], dev), noise,
+                                                 cfgt, *srcs)
+        idx = N(idx)
+        for k in range(S):
+            assert np.array_equal(idx[k, ..., 0], ref["x0"][k])
+            assert np.array_equal(idx[k, ..., 1], ref["y0"][k])
+    else:
+        s = make_self([flags & 1, (flags >> 1) & 1, (flags >> 2) & 1], noise)
+        ws = [s.generate_images_pred({("disp", 0): disp}, Tt[k], srcs[k], T(inp["K"], dev),
+                                     T(inp["inv_K"], dev)) for k in range(S)]
+        if S == 1 and flags & 4:
+            # single candidate + mask_rec: the reference's in-place `to_optimise *= mask_rec[:,0]`
+            # cannot broadcast (train.py:1030-1036); the mirror raises the same error
+            with pytest.raises(RuntimeError):
+                s.compute_losses_base({("disp", 0): disp}, T(inp["tgt"], dev), ws, srcs,
+                                      T(inp["mask_rec"], dev))
+            return
+        loss, _ = s.compute_losses_base({("disp", 0): disp}, T(inp["tgt"], dev), ws, srcs,
+                                        T(inp["mask_rec"], dev))
+        argmin = None
+    loss.backward()
+    if argmin is not None:
+        am = N(argmin).astype(np.int32)
+        am[am == 255] = -1
+        assert np.array_equal(am.reshape(ref["idx"].shape), ref["idx"])
+    assert abs(float(loss) - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    assert_grad_close(N(disp.grad), ref["grad_disp"], TOL, "grad_disp vs oracle")
+    assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
+
+
 # ------------------------------------------------------------------ properties at full size
 def test_properties_fullsize(dev):
     """Size-independent properties at the benchmark shape (B12 640x192): determinism of the
