@@ -217,6 +217,12 @@ MVF_API int mvf_affine_restore_bwd(const float *g_out, const float *angle_deg, c
                            const float *ratio, float *workspace, float *g_depth, int B, int C,
                            int H, int W, void *stream);
 
+/* ---- Conv3x3's ReflectionPad2d(1) (layers.py:121-138) -------------------------------------
+ * in [planes,H,W] -> out [planes,H+2,W+2] (planes = B*C); backward is a deterministic gather.
+ * H, W >= 2 (ATen's reflection_pad2d requires pad < size). */
+MVF_API int mvf_reflect_pad1_fwd(const float *in, float *out, int planes, int H, int W, void *stream);
+MVF_API int mvf_reflect_pad1_bwd(const float *g_out, float *g_in, int planes, int H, int W, void *stream);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------
  * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
  * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded

@@ -55,6 +55,8 @@ _SIGNATURES = {
     "mvf_silog_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mvf_silog_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mvf_affine_transform_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_reflect_pad1_fwd": [_vp, _vp, _i, _i, _i, _vp],
+    "mvf_reflect_pad1_bwd": [_vp, _vp, _i, _i, _i, _vp],
     "mvf_affine_restore_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_affine_restore_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_profile_enable": [_i],

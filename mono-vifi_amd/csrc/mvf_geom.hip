@@ -552,6 +552,92 @@ __global__ void __launch_bounds__(NT) k_silog_bwd(const float *__restrict__ pred
     if (g_target) g_target[o] = -g * mk / lt;
 }
 
+// ---------------------------------------------------------------- Conv3x3's ReflectionPad2d(1)
+// reference: layers.py:121-138 (every 3x3 convolution of the decoders pads by reflection
+// first; the tensors are the largest of the step, up to [72,16,192,640]).  Forward: one lane
+// per output element of the padded plane, lanes walk x (coalesced stores, near-coalesced
+// loads).  Backward: a gather -- each input element sums its own copy and the reflected
+// copies that land on it (rows 1 and H-2, columns 1 and W-2) -- so no atomics.
+// Bound: HBM (read N, write N + border).
+constexpr int RP_PL = 8;     // planes per lane: index math once, 8 independent loads in flight
+
+__global__ void __launch_bounds__(NT) k_reflect_pad1_fwd(const float *__restrict__ in,
+                                                         float *__restrict__ out, int planes, int H,
+                                                         int W)
+{
+    const int Wp = W + 2, Hp = H + 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= Hp * Wp) return;
+    const int Y = i / Wp, X = i - Y * Wp;
+    int y = Y - 1, x = X - 1;
+    y = (y < 0) ? -y : ((y >= H) ? 2 * (H - 1) - y : y);
+    x = (x < 0) ? -x : ((x >= W) ? 2 * (W - 1) - x : x);
+    const size_t p0 = (size_t)blockIdx.y * RP_PL;
+    const int np = min(RP_PL, planes - (int)p0);
+    const float *src = in + p0 * H * W + (size_t)y * W + x;
+    float *dst = out + p0 * Hp * Wp + i;
+    float v[RP_PL];
+#pragma unroll
+    for (int k = 0; k < RP_PL; ++k) v[k] = (k < np) ? src[(size_t)k * H * W] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < RP_PL; ++k)
+        if (k < np) dst[(size_t)k * Hp * Wp] = v[k];
+}
+
+__global__ void __launch_bounds__(NT) k_reflect_pad1_bwd(const float *__restrict__ g_out,
+                                                         float *__restrict__ g_in, int planes, int H,
+                                                         int W)
+{
+    const int Wp = W + 2;
+    const size_t PP = (size_t)(H + 2) * Wp;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    // padded rows / columns that map onto (y, x): its own, plus the reflected border ones
+    int rows[3], cols[3], nr = 1, nc = 1;
+    rows[0] = y + 1;
+    cols[0] = x + 1;
+    if (y == 1) rows[nr++] = 0;
+    if (y == H - 2) rows[nr++] = H + 1;
+    if (x == 1) cols[nc++] = 0;
+    if (x == W - 2) cols[nc++] = W + 1;
+    const size_t p0 = (size_t)blockIdx.y * RP_PL;
+    const int np = min(RP_PL, planes - (int)p0);
+    const float *g = g_out + p0 * PP;
+    float *dst = g_in + p0 * H * W + i;
+    if (nr <= 2 && nc <= 2) {
+        // own copy for every lane, with all plane loads in flight; the (few) border lanes add
+        // the reflected copies afterwards
+        const size_t o = (size_t)(y + 1) * Wp + x + 1;
+        float v[RP_PL];
+#pragma unroll
+        for (int k = 0; k < RP_PL; ++k) v[k] = (k < np) ? g[(size_t)k * PP + o] : 0.0f;
+        if (nr > 1 || nc > 1) {
+            const size_t oc = (size_t)(y + 1) * Wp + cols[nc - 1];
+            const size_t orw = (size_t)rows[nr - 1] * Wp + x + 1;
+            const size_t orc = (size_t)rows[nr - 1] * Wp + cols[nc - 1];
+#pragma unroll
+            for (int k = 0; k < RP_PL; ++k) {
+                if (k >= np) continue;
+                const float *gk = g + (size_t)k * PP;
+                if (nc > 1) v[k] += gk[oc];
+                if (nr > 1) v[k] += gk[orw];
+                if (nr > 1 && nc > 1) v[k] += gk[orc];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < RP_PL; ++k)
+            if (k < np) dst[(size_t)k * H * W] = v[k];
+        return;
+    }
+    for (int k = 0; k < np; ++k) {      // H or W == 3: a row / column is the image of both borders
+        float acc = 0.0f;
+        for (int a = 0; a < nr; ++a)
+            for (int c = 0; c < nc; ++c) acc += g[(size_t)k * PP + (size_t)rows[a] * Wp + cols[c]];
+        dst[(size_t)k * H * W] = acc;
+    }
+}
+
 // ---------------------------------------------------------------- a10 pose glue
 // reference: layers.py:28-103.  One lane per batch element.
 struct Rot {
@@ -950,6 +1036,26 @@ int mvf_silog_bwd(const float *pred, const float *target, const float *mask, con
     if (B <= 0 || N <= 0) return 0;
     hipLaunchKernelGGL(k_silog_bwd, dim3((unsigned)((N + NT - 1) / NT), (unsigned)B), dim3(NT), 0,
                        (hipStream_t)stream, pred, target, mask, sums, g_loss, g_pred, g_target, B, N, beta);
+    return hip_check_launch();
+}
+
+int mvf_reflect_pad1_fwd(const float *in, float *out, int planes, int H, int W, void *stream)
+{
+    if (planes <= 0) return 0;
+    if (!in || !out || H < 2 || W < 2 || planes > 65535 * RP_PL) return (int)hipErrorInvalidValue;
+    const int n = (H + 2) * (W + 2);
+    hipLaunchKernelGGL(k_reflect_pad1_fwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((planes + RP_PL - 1) / RP_PL)),
+                       dim3(NT), 0, (hipStream_t)stream, in, out, planes, H, W);
+    return hip_check_launch();
+}
+
+int mvf_reflect_pad1_bwd(const float *g_out, float *g_in, int planes, int H, int W, void *stream)
+{
+    if (planes <= 0) return 0;
+    if (!g_out || !g_in || H < 2 || W < 2 || planes > 65535 * RP_PL) return (int)hipErrorInvalidValue;
+    const int n = H * W;
+    hipLaunchKernelGGL(k_reflect_pad1_bwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((planes + RP_PL - 1) / RP_PL)),
+                       dim3(NT), 0, (hipStream_t)stream, g_out, g_in, planes, H, W);
     return hip_check_launch();
 }
 

@@ -146,10 +146,15 @@ class Conv3x3(nn.Module):
 
     def __init__(self, in_channels, out_channels, use_refl=True):
         super().__init__()
+        self.use_refl = bool(use_refl)
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
     def forward(self, x):
+        if self.use_refl and x.is_cuda and x.dtype == torch.float32:
+            # fp32 on the HIP device: gather kernels (deterministic backward, no atomics);
+            # other dtypes / hosts keep the stock module (the networks are plain PyTorch)
+            return self.conv(ops.reflect_pad1(x))
         return self.conv(self.pad(x))
 
 

@@ -616,3 +616,34 @@ class AffineRestore(torch.autograd.Function):
 
 def affine_restore(depth, angle, box, ratio):
     return AffineRestore.apply(depth, angle, box, ratio)
+
+
+# --------------------------------------------------------------------------- Conv3x3 glue
+class ReflectPad1(torch.autograd.Function):
+    """nn.ReflectionPad2d(1) of Conv3x3; reference: layers.py:121-138"""
+
+    @staticmethod
+    def forward(ctx, x):
+        nat.require_device(x)
+        x = _c(x)
+        B, C, H, W = x.shape
+        if H < 2 or W < 2:
+            raise RuntimeError("ReflectionPad2d(1) needs H, W >= 2")
+        out = torch.empty((B, C, H + 2, W + 2), dtype=torch.float32, device=x.device)
+        nat.check(nat.lib().mvf_reflect_pad1_fwd(nat.ptr(x), nat.ptr(out), B * C, H, W, _stream()),
+                  "reflect_pad1_fwd")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        B, C, Hp, Wp = g.shape
+        gi = torch.empty((B, C, Hp - 2, Wp - 2), dtype=torch.float32, device=g.device)
+        nat.check(nat.lib().mvf_reflect_pad1_bwd(nat.ptr(g), nat.ptr(gi), B * C, Hp - 2, Wp - 2, _stream()),
+                  "reflect_pad1_bwd")
+        return gi
+
+
+def reflect_pad1(x):
+    return ReflectPad1.apply(x)
+

@@ -522,3 +522,23 @@ def test_affine_vs_torch_formulation(dev):
     with pytest.raises(RuntimeError):
         ops.affine_restore(T(x, dev), z[:2], full, one)
 
+
+# ------------------------------------------------------------------ Conv3x3's reflection pad
+@pytest.mark.parametrize("shape", [(1, 1, 2, 2), (2, 3, 3, 5), (3, 16, 24, 40), (12, 16, 192, 640)])
+def test_reflect_pad1(dev, shape):
+    """layers.Conv3x3 pads by reflection (layers.py:121-138): bit-identical copy forward,
+    deterministic gather backward, against ATen on the same device."""
+    import torch.nn.functional as F
+    from mono_vifi_amd import layers, ops
+    x = torch.randn(*shape, device=dev)
+    a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    pa, pb = ops.reflect_pad1(a), F.pad(b, (1, 1, 1, 1), mode="reflect")
+    assert torch.equal(pa, pb)
+    w = torch.randn_like(pa)
+    (pa * w).sum().backward()
+    (pb * w).sum().backward()
+    assert float((a.grad - b.grad).abs().max()) <= 1e-5 * float(b.grad.abs().max())
+    conv = layers.Conv3x3(shape[1], 4).to(dev)
+    ref = conv.conv(conv.pad(x))
+    assert torch.allclose(conv(x), ref, atol=1e-6)
+
