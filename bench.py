@@ -19,7 +19,7 @@ Workloads (config.workload in the JSON names the one that ran):
 * ``train`` -- the whole optimisation step of the drop-in trainer (networks + hot path +
   backward + clip + AdamW), see mono-vifi_amd/trainer.py.
 
-``roofline`` is for the dominant hot-path kernel (fused unit backward), from HIP events the
+``roofline`` is for the dominant hot-path kernel (the unit's forward+backward tile kernel), from HIP events the
 library records around every launch of it inside the timed region.  ``cpu_baseline`` times
 the CPU oracle (a port of the reference's algorithm, checked bit-exact against it) on the
 host cores on a bounded sample of the same workload (rank 0, N = 1 only).
@@ -258,7 +258,12 @@ def main():
 
     r_fwd = roof(fwd_ms, fwd_n, FWD_BYTES_PER_PX, "k_photo_fwd<fused>")
     r_bwd = roof(bwd_ms, bwd_n, BWD_BYTES_PER_PX, "k_photo_bwd<fused>")
-    dominant = r_bwd if (r_bwd and (not r_fwd or bwd_ms >= fwd_ms)) else r_fwd
+    # forward+backward of a unit in one tile kernel (the training path): its algorithmic bytes
+    # are those of the forward and the backward it replaces
+    fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
+    r_fb = roof(fb_ms, fb_n, FWD_BYTES_PER_PX + BWD_BYTES_PER_PX, "k_photo_fwdbwd<fused>")
+    cands = [(ms, r) for ms, r in ((fwd_ms, r_fwd), (bwd_ms, r_bwd), (fb_ms, r_fb)) if r]
+    dominant = max(cands, key=lambda t: t[0])[1] if cands else None
 
     if rank == 0:
         images = step.images_per_step * world * args.steps
@@ -275,7 +280,7 @@ def main():
                 f"{args.width}x{args.height}, 2 sources/unit, exact mode, {args.disp} disparity"))(),
                 "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": dominant,
-            "kernels": {"unit_fwd": r_fwd, "unit_bwd": r_bwd},
+            "kernels": {"unit_fwd": r_fwd, "unit_bwd": r_bwd, "unit_fwdbwd": r_fb},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)

@@ -161,6 +161,18 @@ MVF_API int mvf_unit_bwd(const float *disp, const float *tgt, const float *const
                  const float *stats, const float *g_loss, int S, int flags, float smoothness,
                  float min_disp, float range, float eps, float *g_disp, float *g_T,
                  float *workspace, int B, int H, int W, void *stream);
+/* Forward AND backward of a unit in one tile kernel (S <= 2: one source pair), for the
+ * training step, where both always run: loss[3], stats[B,4] as mvf_unit_fwd, plus
+ * g_disp [B,1,H,W] and g_T [S,B,4,4] for an upstream gradient of 1 (the backward is linear in
+ * it: the caller scales).  The warp, the staging and the target statistics are done once
+ * instead of once per direction.  argmin / auto_mask / to_opt nullable.
+ * workspace: mvf_workspace_floats(B,H,W) floats. */
+MVF_API int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
+                    const float *K, const float *inv_K, const float *noise, const float *mask_rec,
+                    int S, int flags, float smoothness, float min_disp, float range, float eps,
+                    float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
+                    float *g_disp, float *g_T, float *workspace, int B, int H, int W, void *stream);
+
 
 /* ---- a10: layers.transformation_from_parameters (layers.py:28-103) --------------------
  * axisangle, translation [B,3] -> M [B,4,4]; M = T*R, or R^T*T(-t) when invert != 0 */
@@ -234,7 +246,8 @@ MVF_API int mvf_reflect_pad1_bwd(const float *g_out, float *g_in, int planes, in
 #define MVF_PROF_PHOTO_BWD 3
 #define MVF_PROF_WARP_FWD 4  /* staged generate_images_pred */
 #define MVF_PROF_WARP_BWD 5
-#define MVF_PROF_COUNT 6
+#define MVF_PROF_UNIT_FWDBWD 6 /* forward+backward of a unit in one tile kernel */
+#define MVF_PROF_COUNT 7
 MVF_API int mvf_profile_enable(int on);
 MVF_API int mvf_profile_reset(void);
 MVF_API int mvf_profile_read(int kernel_id, double *total_ms, int64_t *launches);

@@ -45,6 +45,10 @@ _SIGNATURES = {
     "mvf_photo_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp, _i, _i, _i, _vp],
     "mvf_unit_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
                      _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    # disp,tgt,src**,T,K,invK,noise,mask, S,flags, smooth,min_disp,range,eps, loss,argmin,auto_mask,
+    # to_opt,stats,g_disp,g_T,ws, B,H,W, stream
+    "mvf_unit_fwdbwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
+                        _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mvf_unit_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp,
                      _vp, _vp, _i, _i, _i, _vp],
     "mvf_pose_fwd": [_vp, _vp, _vp, _i, _i, _vp],
@@ -63,7 +67,8 @@ _SIGNATURES = {
     "mvf_profile_reset": [],
     "mvf_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
 }
-PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD = range(6)
+(PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD,
+ PROF_UNIT_FWDBWD) = range(7)
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t}
 

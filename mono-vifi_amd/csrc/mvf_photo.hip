@@ -833,6 +833,11 @@ struct BwdArgs {
     float *g_disp, *ws;
     int S, flags, B, H, W, tiles_x, tiles_y;
     float smoothness, min_disp, range, eps;
+    // forward+backward in one pass (FB): the forward's inputs and outputs
+    const float *noise, *mean_ws;   // tie-break noise; [B*NMEAN] mean partials of k_disp_mean
+    float *part;                    // [B*ntiles*NPART] loss partials of this tiling
+    uint8_t *argmin_out;
+    float *auto_mask_out, *to_opt_out;
 };
 
 constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a backward region
@@ -842,9 +847,19 @@ constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a backward regio
 constexpr int BWD_TGT = 0, BWD_PAIR = 3 * PLANE, BWD_DISP = BWD_PAIR + 6 * PLANE,
               BWD_COEF = BWD_DISP + PLANE, BWD_GD = BWD_COEF + 6 * RPLANE, BWD_POSE = BWD_GD + RPLANE;
 
-template <bool FUSED, int S>
+// FB = forward AND backward of the unit in one pass.  Everything the backward needs from the
+// forward is per-pixel local (the candidates, their min/argmin, the mask) except two per-image
+// scalars: the mean disparity (k_disp_mean runs first, as for the forward) and the smoothness
+// sum of the mean-normalisation term, which enters grad_disp as a per-image constant and is
+// subtracted by k_gdisp_shift afterwards.  The upstream gradient is taken as 1 (the caller
+// scales: the backward is linear in it).  The region evaluates the candidates of all its
+// 64x16 pixels (the 3x3 adjoint gather needs the argmin of the halo ring), so compared with
+// forward + backward kernels the warp, the staging and the target statistics happen once.
+// Only for a single source pair (S <= 2): more pairs would have to be warped twice.
+template <bool FUSED, int S, bool FB = false>
 __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
 {
+    static_assert(!FB || (FUSED && S <= 2), "FB needs the fused warp and a single source pair");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *tgtP = smem + BWD_TGT;
     f2 *pairP = reinterpret_cast<f2 *>(smem + BWD_PAIR);
@@ -864,10 +879,16 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
     const int n_id = automask ? (avg ? 1 : S) : 0;
 
     if (threadIdx.x == 0) {
-        float g = a.g_loss[0];
+        float g = FB ? 1.0f : a.g_loss[0];
         sh.gloss = g;
         sh.gpix = g / (float)((double)a.B * (double)N);
-        sh.den = a.stats[b * 4 + 1];
+        if (FB) {
+            float m = 0.0f;
+            for (int i = 0; i < NMEAN; ++i) m += a.mean_ws[b * NMEAN + i];
+            sh.den = m / (float)N + 1e-7f;
+        } else {
+            sh.den = a.stats[b * 4 + 1];
+        }
     }
     if (FUSED && threadIdx.x < 12 * S) {
         int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
@@ -889,17 +910,30 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         const int x = x0 + j;
         const bool in = rowin && (x >= 0) && (x < W);
         const size_t pi = (size_t)b * N + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-        sel[j] = in ? (int)a.argmin[pi] : 254;
+        sel[j] = (in && !FB) ? (int)a.argmin[pi] : 254;
         float m = (in && a.mask) ? a.mask[pi] : 1.0f;
         wbase[j] = in ? m : 0.0f;
     }
-    stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
-    stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
+    // FB: identity candidates of every region pixel, fetched with the target and the disparity
+    f2 vid[PX];
+    float mraw[PX];      // mask value (1 without a mask), 0 outside the image
+#pragma unroll
+    for (int j = 0; j < PX; ++j) { vid[j] = f2s(0.0f); mraw[j] = wbase[j]; }
+    if (FB && automask) {
+        const int kb0 = (S > 1) ? 1 : 0;
+        stage_first(tgtP, dispP, pairP, a.tgt + (size_t)b * 3 * N, a.disp + (size_t)b * N,
+                    a.src.p[0] + (size_t)b * 3 * N, a.src.p[kb0] + (size_t)b * 3 * N, N, H, W, py0, px0);
+    } else {
+        stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
+        stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
+    }
     for (int i = threadIdx.x; i < RPLANE; i += NT) gdP[i] = 0.0f;
     __syncthreads();
+    if (FB && automask) reproj4p(pairP, tgtP, off, no_ssim, vid);
     // base weight of every region pixel: gpix * mask (0 outside the image)
 #pragma unroll
     for (int j = 0; j < PX; ++j) wbase[j] = sh.gpix * wbase[j];
+    float fb_photo = 0.0f;
 
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
 
@@ -932,6 +966,61 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
 #endif
         }
         __syncthreads();
+
+        if (FB) {
+            // ---- the forward's candidates, min / argmin, mask (reference: train.py:1010-1043)
+            f2 vw[PX];
+            reproj4p(pairP, tgtP, off, no_ssim, vw);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const int x = x0 + j, col = seg * PX + j;
+                const bool in = rowin && (x >= 0) && (x < W);
+                const size_t pix = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+                const size_t pi = (size_t)b * N + pix;
+                float best = 0.0f;
+                int bi = 0, nc = 0;
+                if (automask) {
+                    if (avg) {
+                        float m = vid[j].x;
+                        if (S > 1) m = m + vid[j].y;
+                        m = m / (float)S;
+                        best = m + (in ? a.noise[pi] : 0.0f) * 0.00001f;
+                        nc = 1;
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < S; ++k) {
+                            float v = (k == 0 ? vid[j].x : vid[j].y) +
+                                      (in ? a.noise[((size_t)b * S + k) * N + pix] : 0.0f) * 0.00001f;
+                            if (nc == 0 || v < best) { best = v; bi = nc; }
+                            ++nc;
+                        }
+                    }
+                }
+                if (avg) {
+                    float m = vw[j].x;
+                    if (S > 1) m = m + vw[j].y;
+                    m = m / (float)S;
+                    if (nc == 0 || m < best) { best = m; bi = nc; }
+                    ++nc;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < S; ++k) {
+                        float v = (k == 0) ? vw[j].x : vw[j].y;
+                        if (nc == 0 || v < best) { best = v; bi = nc; }
+                        ++nc;
+                    }
+                }
+                if (a.mask) best = best * mraw[j];
+                sel[j] = in ? ((nc > 1) ? bi : 255) : 254;
+                const bool outp = row_out && (col >= 1) && (col <= OW) && in;
+                if (outp) {
+                    if (a.argmin_out) a.argmin_out[pi] = (nc > 1) ? (uint8_t)bi : (uint8_t)255;
+                    if (a.auto_mask_out) a.auto_mask_out[pi] = (bi > n_id - 1) ? 1.0f : 0.0f;
+                    if (a.to_opt_out) a.to_opt_out[pi] = best;
+                    fb_photo += best;
+                }
+            }
+        }
 
         // selection weights of the two sources: the argmin picked it (or the averaged channel)
         f2 wk[PX];
@@ -1146,11 +1235,14 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         const float scale = sh.gloss * a.smoothness;
         const float cx = scale / (float)((double)a.B * H * (W - 1));
         const float cy = scale / (float)((double)a.B * (H - 1) * W);
-        const float smooth_b = a.stats[b * 4 + 2] + a.stats[b * 4 + 3];
+        // FB: the per-image smoothness sum is not known yet; its (per-image constant) term is
+        // subtracted afterwards by k_gdisp_shift -- x - 0 is exact, so the bits are the same
+        const float smooth_b = FB ? 0.0f : a.stats[b * 4 + 2] + a.stats[b * 4 + 3];
         // d/d disp_j of scale*smooth(disp/den): gn_j/den - (sum_i gn_i d_i)/(den^2 N); the sum is
         // den*scale*smooth_b because the per-image term is positively homogeneous of degree 1
         const float corr = scale * smooth_b / (float)N;
         const float rden = 1.0f / den, corr_den = corr / den;
+        float fb_sx = 0.0f, fb_sy = 0.0f;
 #pragma unroll 1
         for (int j = 0; j < PX; ++j) {
             const int x = x0 + j;
@@ -1170,14 +1262,43 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
             };
             auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
 #ifndef MVF_ABL_NOSMOOTHB
-            if (x + 1 < W) gn += cx * wgt(1) * sgn(nd - dc[1]);
+            if (x + 1 < W) {
+                const float w1 = wgt(1);
+                gn += cx * w1 * sgn(nd - dc[1]);
+                // FB: the forward's edge-aware smoothness sums (reference: layers.py:231-242)
+                if (FB) fb_sx += fabsf(dc[0] / den - dc[1] / den) * w1;
+            }
             if (x - 1 >= 0) gn -= cx * wgt(-1) * sgn(dc[-1] - nd);
-            if (y + 1 < H) gn += cy * wgt(LDW) * sgn(nd - dc[LDW]);
+            if (y + 1 < H) {
+                const float wl = wgt(LDW);
+                gn += cy * wl * sgn(nd - dc[LDW]);
+                if (FB) fb_sy += fabsf(dc[0] / den - dc[LDW] / den) * wl;
+            }
             if (y - 1 >= 0) gn -= cy * wgt(-LDW) * sgn(dc[-LDW] - nd);
 #endif
             a.g_disp[(size_t)b * N + (size_t)y * W + x] = gdP[roff + j] + gn * rden - corr_den;
         }
+        if (FB) {
+            float *part = a.part + (((size_t)b * a.tiles_y + tid.by) * a.tiles_x + tid.bx) * NPART;
+            const float sums[4] = {fb_photo, fb_sx, fb_sy, 0.0f};
+            const float tot = block_sum_many<NT, 4>(sums, scratch);
+            if (threadIdx.x < 4) part[threadIdx.x] = tot;
+        }
     }
+}
+
+// FB epilogue: grad_disp[b, :] -= (smoothness * smooth_b / N) / den_b  (see k_photo_bwd<.., FB>)
+__global__ void __launch_bounds__(256) k_gdisp_shift(float *__restrict__ g_disp,
+                                                     const float *__restrict__ stats,
+                                                     float smoothness, int N)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const float den = stats[b * 4 + 1];
+    const float smooth_b = stats[b * 4 + 2] + stats[b * 4 + 3];
+    const float corr = smoothness * smooth_b / (float)N;
+    g_disp[(size_t)b * N + i] -= corr / den;
 }
 
 // =============================================================================== standalone
@@ -1454,6 +1575,12 @@ void launch_bwd_kernel(const BwdArgs &a, dim3 grid, hipStream_t st)
     }
 }
 
+void launch_fb_kernel(const BwdArgs &a, dim3 grid, hipStream_t st)
+{
+    if (a.S == 1) hipLaunchKernelGGL((k_photo_bwd<true, 1, true>), grid, dim3(NT), bwd_smem(), st, a);
+    else hipLaunchKernelGGL((k_photo_bwd<true, 2, true>), grid, dim3(NT), bwd_smem(), st, a);
+}
+
 int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *stats, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -1622,6 +1749,42 @@ int mvf_unit_bwd(const float *disp, const float *tgt, const float *const *src, c
         launch_bwd_kernel<true>(a, dim3((unsigned)(a.tiles_x * a.tiles_y * B)), (hipStream_t)stream);
     }
     return mvf_geom::finish_gT(workspace, K, g_T, B, S, a.tiles_x * a.tiles_y, stream);
+}
+
+int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
+                    const float *K, const float *inv_K, const float *noise, const float *mask_rec,
+                    int S, int flags, float smoothness, float min_disp, float range, float eps,
+                    float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
+                    float *g_disp, float *g_T, float *workspace, int B, int H, int W, void *stream)
+{
+    if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
+    if (!g_disp || !g_T || !loss || !stats || !workspace) return (int)hipErrorInvalidValue;
+    if (B * H * W <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = H * W;
+    BwdArgs a = {};
+    a.disp = disp; a.tgt = tgt; a.mask = mask_rec; a.T = T; a.K = K; a.invK = inv_K;
+    for (int k = 0; k < S; ++k) a.src.p[k] = src[k];
+    a.S = S; a.flags = flags; a.B = B; a.H = H; a.W = W;
+    a.tiles_x = (W + OW - 1) / OW; a.tiles_y = (H + OH - 1) / OH;
+    a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
+    const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
+    // workspace: [B*NMEAN] mean partials | [B*ntiles*NPART] loss partials | [S*B*ntiles*12] grad_P
+    a.mean_ws = workspace;
+    a.part = workspace + (size_t)B * NMEAN;
+    a.ws = a.part + (size_t)B * ntiles * NPART;
+    a.noise = noise; a.argmin_out = argmin; a.auto_mask_out = auto_mask; a.to_opt_out = to_opt;
+    a.g_disp = g_disp;
+    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, workspace, N);
+    {
+        ProfScope ps(MVF_PROF_UNIT_FWDBWD, st);
+        launch_fb_kernel(a, dim3((unsigned)(ntiles * B)), st);
+    }
+    hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(1024), 0, st, workspace, loss, stats, B, H, W,
+                       (int)ntiles, smoothness, 1);
+    hipLaunchKernelGGL(k_gdisp_shift, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st,
+                       g_disp, stats, smoothness, N);
+    return mvf_geom::finish_gT(a.ws, K, g_T, B, S, (int)ntiles, stream);
 }
 
 }  // extern "C"

@@ -365,6 +365,13 @@ class LossesBase(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ fused unit
+# When a gradient will be asked for (training), a unit with one source pair runs its forward
+# and backward as ONE tile kernel (mvf_unit_fwdbwd): the gradients for an upstream gradient of
+# 1 are produced alongside the loss and only scaled in backward().  Set to False to force the
+# separate forward / backward kernels (the tests compare both).
+UNIT_FWDBWD = True
+
+
 class Unit(torch.autograd.Function):
     """One hot-path unit: S x generate_images_pred + compute_losses_base with the warped
     images kept in LDS (reference: train.py:956-1051).
@@ -388,6 +395,22 @@ class Unit(torch.autograd.Function):
         stats = torch.empty((B, 4), dtype=torch.float32, device=dev)
         ws = _ws(disp, B, H, W)
         sp, skeep = nat.ptr_array(src)
+        ctx.fwdbwd = bool(UNIT_FWDBWD and S <= 2 and not want_idx and
+                          (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]))
+        if ctx.fwdbwd:
+            g_disp = torch.empty_like(disp)
+            g_T = torch.empty_like(T)
+            nat.check(nat.lib().mvf_unit_fwdbwd(
+                nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K), nat.ptr(inv_K), nat.ptr(noise),
+                nat.ptr(mask_rec), S, flags, smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
+                nat.ptr(auto_mask), None, nat.ptr(stats), nat.ptr(g_disp), nat.ptr(g_T), nat.ptr(ws),
+                B, H, W, _stream()), "unit_fwdbwd")
+            ctx.save_for_backward(g_disp, g_T)
+            ctx.n_src = S
+            outs = [loss[0], auto_mask if want_mask else torch.empty(0, device=dev), argmin,
+                    torch.empty(0, device=dev), loss[1:]]
+            ctx.mark_non_differentiable(*outs[1:])
+            return tuple(outs)
         nat.check(nat.lib().mvf_unit_fwd(nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K),
                                          nat.ptr(inv_K), nat.ptr(noise), nat.ptr(mask_rec), S, flags,
                                          smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
@@ -402,6 +425,10 @@ class Unit(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
+        if ctx.fwdbwd:
+            g_disp, g_T = ctx.saved_tensors      # for an upstream gradient of 1; linear in it
+            return (g_disp * g_loss, None, g_T * g_loss, None, None, None, None, None,
+                    *([None] * ctx.n_src))
         disp, tgt, T, K, inv_K, mask_rec, argmin, stats, *src = ctx.saved_tensors
         S, flags, smoothness, md, rg, eps = ctx.cfg
         B, _, H, W = disp.shape

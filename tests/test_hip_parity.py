@@ -332,6 +332,69 @@ def test_source_counts_vs_oracle(dev, S, flags, path):
     assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
 
 
+# ------------------------------------------------------------------ forward+backward in one kernel
+@pytest.mark.parametrize("shape", RAGGED + [(12, 192, 640)])
+@pytest.mark.parametrize("flags", [0, 1, 2, 4, 6])
+@pytest.mark.parametrize("S", [1, 2])
+def test_unit_fwdbwd_equals_separate_kernels(dev, shape, flags, S):
+    """mvf_unit_fwdbwd (what the training step runs: loss and gradients from one tile kernel)
+    against mvf_unit_fwd + mvf_unit_bwd: same argmin and auto-mask, grad_disp / grad_T and
+    loss equal up to the order of the tile partial sums (1e-6), also under a non-unit upstream
+    gradient; and against the oracle at the small shapes."""
+    from mono_vifi_amd import ops, synthetic
+    B, H, W = shape
+    inp = synthetic.unit_inputs(1300 + H * W + flags + S, B, H, W, num_src=S, pose_scale=0.03,
+                                with_mask=True, disp_mode="smooth" if H * W > 10000 else "noise")
+    use_mask = not (flags & 4 and (flags & 2 or S == 1))
+    mask_np = inp["mask_rec"] if use_mask else None
+    T_np = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
+                     for k in range(S)], 0)
+    noise_np = np.ascontiguousarray(inp["noise"][:, :1] if flags & 2 else inp["noise"])
+    noise = None if flags & 4 else T(noise_np, dev)
+    mask = T(mask_np, dev) if use_mask else None
+    srcs = [T(inp["src"][k], dev) for k in range(S)]
+    cfgt = (S, flags, 1e-3, 0.1, 100.0, 1e-7, True, False)
+    res = {}
+    for mode in (True, False):
+        ops.UNIT_FWDBWD = mode
+        try:
+            disp, Tt = T(inp["disp"], dev, True), T(T_np, dev, True)
+            loss, auto_mask, argmin, _, parts = ops.Unit.apply(
+                disp, T(inp["tgt"], dev), Tt, T(inp["K"], dev), T(inp["inv_K"], dev), mask, noise,
+                cfgt, *srcs)
+            (loss * 1.0).backward()
+            d1, t1 = N(disp.grad).copy(), N(Tt.grad).copy()
+            disp.grad = None
+            Tt.grad = None
+            # a second graph with a non-unit upstream gradient
+            disp2, Tt2 = T(inp["disp"], dev, True), T(T_np, dev, True)
+            loss2 = ops.Unit.apply(disp2, T(inp["tgt"], dev), Tt2, T(inp["K"], dev), T(inp["inv_K"], dev),
+                                   mask, noise, cfgt, *srcs)[0]
+            (loss2 * 4.0).backward()
+            res[mode] = (float(loss.detach()), N(argmin), N(auto_mask), d1, t1, N(disp2.grad), N(parts))
+        finally:
+            ops.UNIT_FWDBWD = True
+    fb, sep = res[True], res[False]
+    assert abs(fb[0] - sep[0]) <= 2e-6 * abs(sep[0])
+    assert np.array_equal(fb[1], sep[1]) and np.array_equal(fb[2], sep[2])
+    # grad_disp: same arithmetic; the per-image smoothness sum is folded from a different tiling
+    assert rel_err(fb[3], sep[3]) <= 1e-6
+    assert rel_err(fb[4], sep[4]) <= 1e-6                      # grad_T: tile partials differ in count
+    # upstream gradient 4 (a power of two commutes with every rounding): scaled afterwards (FB)
+    # == scaled inside (separate kernels)
+    assert rel_err(fb[5], sep[5]) <= 1e-6
+    assert np.allclose(fb[6], sep[6], rtol=2e-6, atol=1e-9)
+    if H * W <= 20000:
+        ref = O.unit(inp["disp"], inp["tgt"], inp["src"], T_np, inp["K"], inp["inv_K"], noise_np,
+                     mask_np, flags, want_grads=True)
+        am = fb[1].astype(np.int32)
+        am[am == 255] = -1
+        assert np.array_equal(am, ref["idx"])
+        assert abs(fb[0] - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+        assert_grad_close(fb[3], ref["grad_disp"], TOL, "grad_disp vs oracle")
+        assert rel_err(fb[4], ref["grad_T"]) <= TOL
+
+
 # ------------------------------------------------------------------ properties at full size
 def test_properties_fullsize(dev):
     """Size-independent properties at the benchmark shape (B12 640x192): determinism of the
