@@ -262,6 +262,11 @@ def main():
     # are those of the forward and the backward it replaces
     fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
     r_fb = roof(fb_ms, fb_n, FWD_BYTES_PER_PX + BWD_BYTES_PER_PX, "k_photo_fwdbwd<fused>")
+    if r_fb:
+        r_fb["bytes_note"] = (
+            "algorithmic bytes = SURVEY 8d per-unit figures for the forward (44 B/px) and the "
+            "backward (45 B/px) this one launch performs; the fused kernel reads its inputs once, so "
+            "its own minimum is 45 B/px (66.4 MB) and the measured HBM traffic lies between the two")
     cands = [(ms, r) for ms, r in ((fwd_ms, r_fwd), (bwd_ms, r_bwd), (fb_ms, r_fb)) if r]
     dominant = max(cands, key=lambda t: t[0])[1] if cands else None
 
