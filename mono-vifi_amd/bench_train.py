@@ -37,7 +37,9 @@ class TrainStep:
         o = self.opts
         return (f"full optimisation step, {o.backbone} {o.width}x{o.height} 3-frame, batch "
                 f"{o.batch_size}/GPU, use_affine, {o.fuse_model_type}, IFRNet-L teacher, 9 fused "
-                f"hot-path units, AdamW, random-init weights, device-resident synthetic batch "
+                f"hot-path units (forward+backward tile kernel), "
+                f"{'grouped' if o.group_calls else 'one-at-a-time'} network calls with per-call "
+                f"BatchNorm statistics, AdamW, random-init weights, device-resident synthetic batch "
                 f"(data loading excluded), nets {'bf16 autocast' if o.amp_bf16 else 'fp32'}")
 
     def __call__(self):
