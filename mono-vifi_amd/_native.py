@@ -91,6 +91,10 @@ def lib():
             f"{LIB_PATH} not found: the MI355X hot-path library is not built. Run "
             "`python __graft_entry__.py` (or `make -C mono-vifi_amd/csrc`). "
             "There is no CPU fallback.")
+    # PyTorch must have loaded ITS HIP runtime first: the library links libamdhip64 by soname,
+    # and if it is dlopen'ed before torch the loader binds /opt/rocm's copy and torch then runs
+    # on a second runtime (kernel launches fail with hipErrorNoDevice)
+    import torch  # noqa: F401
     handle = C.CDLL(LIB_PATH)
     for name, args in _SIGNATURES.items():
         fn = getattr(handle, name)   # AttributeError if the ABI lost a symbol
