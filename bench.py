@@ -47,7 +47,14 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 FWD_BYTES_PER_PX = 44          # disp 4 + tgt 12 + 2 src 24 read, 4 written
 BWD_BYTES_PER_PX = 45          # same reads + argmin 1, grad_disp 4 written
+# the forward+backward tile kernel reads its inputs ONCE: disp 4 + tgt 12 + 2 src 24 read,
+# argmin 1 + grad_disp 4 written = 45 B/px; + 8 B/px when the tie-break noise is supplied as a
+# tensor (2 identity candidates), + 4 B/px when a mask_rec plane is supplied
+FB_BYTES_PER_PX = 45
+NOISE_BYTES_PER_PX = 8
+MASK_BYTES_PER_PX = 4
 UNITS_PER_STEP = 9             # reference train.py:747-883 with use_affine
+MASKED_UNITS_PER_STEP = 3      # the three affine units carry valid_mask_rec (train.py:830-868)
 
 
 def parse():
@@ -65,6 +72,11 @@ def parse():
                     help="hotpath workload: disparity statistics (smooth = like a depth network's "
                          "output; noise = i.i.d. uniform, worst case for gather locality)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hotpath-leg", dest="no_hotpath_leg", action="store_true",
+                    help="train workload: skip the extra hot-path-only measurement")
+    ap.add_argument("--inkernel-noise", dest="inkernel_noise", action="store_true",
+                    help="hotpath workload: tie-break noise generated in the tile kernel (counter-based) "
+                         "instead of a torch.randn tensor per unit")
     ap.add_argument("--amp-bf16", dest="amp_bf16", action="store_true",
                     help="bf16 autocast for the conv networks (reduced precision: not the default)")
     ap.add_argument("--channels-last", dest="channels_last", action="store_true")
@@ -187,6 +199,55 @@ def cpu_baseline(args):
                       f"{cores} of {host_cores} host cores (fastest of a thread-count sweep)"}
 
 
+def cpu_baseline_unfused(args):
+    """Second CPU baseline: the SAME unit as ~130 separate ATen operators
+    under autograd (oracle/torch_unfused.py: bmm, grid_sample, reflection pad + avg_pool2d SSIM,
+    cat/min, ...), i.e. the operator stream the reference's own code issues on its CPU path,
+    on all host cores.  Checked against the reference's golden vectors in
+    tests/test_oracle_golden.py; the reference's Python itself cannot travel to this box."""
+    from mono_vifi_amd import synthetic
+    from oracle import oracle as O
+    from oracle import torch_unfused as U
+    Bs = 2
+    inp = synthetic.unit_inputs(4321, Bs, args.height, args.width, with_mask=True)
+    T = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
+                  for k in range(2)], 0)
+    host_cores = os.cpu_count() or 1
+    tens = [torch.from_numpy(np.ascontiguousarray(a)) for a in
+            (inp["disp"], inp["tgt"], T, inp["K"], inp["inv_K"], inp["noise"], inp["mask_rec"])]
+    srcs = [torch.from_numpy(np.ascontiguousarray(a)) for a in inp["src"]]
+
+    def one():
+        U.unit(tens[0], tens[1], srcs, tens[2], tens[3], tens[4], tens[5], tens[6], 0)
+    old = torch.get_num_threads()
+    best = (float("inf"), 1)
+    try:
+        for nt in sorted({c for c in (8, 16, 32, 64, host_cores) if c <= host_cores}):
+            torch.set_num_threads(nt)
+            one()
+            t0 = time.perf_counter()
+            one()
+            best = min(best, (time.perf_counter() - t0, nt))
+        torch.set_num_threads(best[1])
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one()
+            n += 1
+            dt = time.perf_counter() - t0
+            if dt >= args.cpu_seconds or n >= 5000:
+                break
+    finally:
+        torch.set_num_threads(old)
+    t_unit = dt / n
+    return {"value": round(Bs / (UNITS_PER_STEP * t_unit), 3), "unit": "images/sec",
+            "cores": best[1], "kind": "port",
+            "sample": f"{n} x (1 unit fwd+bwd, batch {Bs}, {args.width}x{args.height}) in {dt:.1f} s; "
+                      f"value = hot-path part of a step ({UNITS_PER_STEP} units); "
+                      f"oracle/torch_unfused.py: the unit as ~130 separate ATen ops under autograd "
+                      f"(the operator stream of the reference's CPU path), torch intra-op threads "
+                      f"{best[1]} of {host_cores} host cores (fastest of a sweep)"}
+
+
 def _profiles_json():
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
@@ -197,15 +258,85 @@ def _profiles_json():
 
 
 def traffic_from_profiles(kernel):
-    """HBM bytes per launch measured offline with rocprofv3 --pmc (separate passes,
-    FETCH_SIZE doubled per the gfx950 note); committed under profiles/."""
+    """HBM bytes per launch measured OFFLINE with rocprofv3 --pmc (separate passes,
+    FETCH_SIZE doubled per the gfx950 note) and committed under profiles/ -- a static value,
+    not measured by this run (PMC counters need rocprofv3 around the process)."""
     return _profiles_json().get(kernel)
 
 
 def valu_from_profiles(kernel):
     """VALU-pipe utilisation of the kernel from the committed PMC pass (what actually bounds
-    a kernel whose HBM fraction is low): {"valu_busy": ..., "valu_instr_per_px": ...} or None."""
+    a kernel whose HBM fraction is low): {"valu_busy": ..., "valu_instr_per_px": ...} or None.
+    Static, like traffic_from_profiles."""
     return _profiles_json().get("_valu", {}).get(kernel)
+
+
+def profiles_source():
+    j = _profiles_json()
+    return {"file": "profiles/hbm_traffic.json", "captured": j.get("_captured", "round 1"),
+            "note": "traffic / valu are read from this committed rocprofv3 --pmc summary, "
+                    "not measured in this run"}
+
+
+def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n):
+    px = args.batch * args.height * args.width
+
+    def roof(ms, n, bytes_px, name):
+        if n == 0:
+            return None
+        avg_s = ms / n / 1e3
+        ach = bytes_px * px / avg_s / 1e9
+        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic_from_profiles(name), "valu": valu_from_profiles(name),
+                "static_source": profiles_source(),
+                "avg_us": round(avg_s * 1e6, 2),
+                "launches": n, "algorithmic_bytes_per_launch": round(bytes_px * px),
+                "algorithmic_bytes_per_px": round(bytes_px, 2)}
+
+    r_fwd = roof(fwd_ms, fwd_n, FWD_BYTES_PER_PX, "k_photo_fwd<fused>")
+    r_bwd = roof(bwd_ms, bwd_n, BWD_BYTES_PER_PX, "k_photo_bwd<fused>")
+    # forward+backward of a unit in one tile kernel (the training path): priced on ITS OWN
+    # minimum traffic (inputs read once), plus the optional planes the launches were given
+    noise_px = 0 if args.inkernel_noise else NOISE_BYTES_PER_PX
+    fb_px = FB_BYTES_PER_PX + noise_px + MASK_BYTES_PER_PX * MASKED_UNITS_PER_STEP / UNITS_PER_STEP
+    r_fb = roof(fb_ms, fb_n, fb_px, "k_photo_fwdbwd<fused>")
+    if r_fb:
+        survey = (FWD_BYTES_PER_PX + BWD_BYTES_PER_PX) * px / (fb_ms / fb_n / 1e3) / 1e9
+        r_fb["frac_survey_8d"] = round(survey / HBM_PEAK_GBS, 4)
+        r_fb["bytes_note"] = (
+            f"algorithmic bytes = {FB_BYTES_PER_PX} B/px (disp 4 + target 12 + 2 sources 24 read once; "
+            f"argmin 1 + grad_disp 4 written) + {noise_px} B/px tie-break noise tensor + "
+            f"{MASK_BYTES_PER_PX} B/px mask_rec on {MASKED_UNITS_PER_STEP} of {UNITS_PER_STEP} units; "
+            "frac_survey_8d prices the same launch at SURVEY 8d's forward 44 + backward 45 B/px "
+            "(the two kernels it replaces) for comparison with round 1")
+    cands = [(ms, r) for ms, r in ((fwd_ms, r_fwd), (bwd_ms, r_bwd), (fb_ms, r_fb)) if r]
+    dominant = max(cands, key=lambda t: t[0])[1] if cands else None
+    return {"unit_fwd": r_fwd, "unit_bwd": r_bwd, "unit_fwdbwd": r_fb}, dominant
+
+
+def hotpath_leg(args, rank, dev, nat, steps=20, warmup=5):
+    """The hot path alone on the GPU (9 units fwd+bwd per batch, inputs resident in HBM): the
+    quantity the two cpu_baseline legs measure, in the same unit."""
+    step = HotPathStep(args, rank, dev)
+    for _ in range(warmup):
+        step()
+    nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
+    nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nat.lib().mvf_profile_enable(0)
+    fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
+    kernels, dom = kernel_rooflines(args, 0.0, 0, 0.0, 0, fb_ms, fb_n)
+    return {"value": round(step.images_per_step * steps / dt, 1), "unit": "images/sec",
+            "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+            "workload": f"hot path only: {UNITS_PER_STEP} units fwd+bwd, batch {args.batch}, "
+                        f"{args.width}x{args.height}, {args.disp} disparity",
+            "roofline": dom}
 
 
 def main():
@@ -243,32 +374,13 @@ def main():
 
     fwd_ms, fwd_n = nat.profile_read(nat.PROF_UNIT_FWD)
     bwd_ms, bwd_n = nat.profile_read(nat.PROF_UNIT_BWD)
-    px = args.batch * args.height * args.width
-
-    def roof(ms, n, bytes_px, name):
-        if n == 0:
-            return None
-        avg_s = ms / n / 1e3
-        ach = bytes_px * px / avg_s / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": traffic_from_profiles(name), "valu": valu_from_profiles(name),
-                "avg_us": round(avg_s * 1e6, 2),
-                "launches": n, "algorithmic_bytes_per_launch": bytes_px * px}
-
-    r_fwd = roof(fwd_ms, fwd_n, FWD_BYTES_PER_PX, "k_photo_fwd<fused>")
-    r_bwd = roof(bwd_ms, bwd_n, BWD_BYTES_PER_PX, "k_photo_bwd<fused>")
-    # forward+backward of a unit in one tile kernel (the training path): its algorithmic bytes
-    # are those of the forward and the backward it replaces
     fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
-    r_fb = roof(fb_ms, fb_n, FWD_BYTES_PER_PX + BWD_BYTES_PER_PX, "k_photo_fwdbwd<fused>")
-    if r_fb:
-        r_fb["bytes_note"] = (
-            "algorithmic bytes = SURVEY 8d per-unit figures for the forward (44 B/px) and the "
-            "backward (45 B/px) this one launch performs; the fused kernel reads its inputs once, so "
-            "its own minimum is 45 B/px (66.4 MB) and the measured HBM traffic lies between the two")
-    cands = [(ms, r) for ms, r in ((fwd_ms, r_fwd), (bwd_ms, r_bwd), (fb_ms, r_fb)) if r]
-    dominant = max(cands, key=lambda t: t[0])[1] if cands else None
+    kernels, dominant = kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n)
+
+    # like-for-like figure for the CPU baselines: the hot path alone on the GPU, same units
+    hotpath_only = None
+    if workload == "train" and rank == 0 and world == 1 and not args.no_hotpath_leg:
+        hotpath_only = hotpath_leg(args, rank, dev, nat)
 
     if rank == 0:
         images = step.images_per_step * world * args.steps
@@ -285,10 +397,19 @@ def main():
                 f"{args.width}x{args.height}, 2 sources/unit, exact mode, {args.disp} disparity"))(),
                 "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": dominant,
-            "kernels": {"unit_fwd": r_fwd, "unit_bwd": r_bwd, "unit_fwdbwd": r_fb},
+            "kernels": kernels,
         }
+        if hotpath_only:
+            out["hotpath_only"] = hotpath_only
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline_unfused"] = cpu_baseline_unfused(args)
+            gpu_hp = hotpath_only["value"] if hotpath_only else (out["value"] if workload == "hotpath" else None)
+            out["like_for_like"] = {
+                "unit": "images/sec on the hot-path part of a step (9 units fwd+bwd)",
+                "gpu_hotpath_only": gpu_hp,
+                "cpu_port_openmp": out["cpu_baseline"]["value"],
+                "cpu_unfused_torch_ops": out["cpu_baseline_unfused"]["value"]}
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 1
+#define MVF_ABI_VERSION 2
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -165,13 +165,15 @@ MVF_API int mvf_unit_bwd(const float *disp, const float *tgt, const float *const
  * training step, where both always run: loss[3], stats[B,4] as mvf_unit_fwd, plus
  * g_disp [B,1,H,W] and g_T [S,B,4,4] for an upstream gradient of 1 (the backward is linear in
  * it: the caller scales).  The warp, the staging and the target statistics are done once
- * instead of once per direction.  argmin / auto_mask / to_opt nullable.
- * workspace: mvf_workspace_floats(B,H,W) floats. */
+ * instead of once per direction.  argmin / auto_mask / to_opt nullable; idx_xy nullable
+ * int32 [S,B,H,W,2] as for mvf_unit_fwd (the parity tests read the sampling indices of the
+ * kernel that trains).  workspace: mvf_workspace_floats(B,H,W) floats. */
 MVF_API int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
                     const float *K, const float *inv_K, const float *noise, const float *mask_rec,
                     int S, int flags, float smoothness, float min_disp, float range, float eps,
                     float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
-                    float *g_disp, float *g_T, float *workspace, int B, int H, int W, void *stream);
+                    int32_t *idx_xy, float *g_disp, float *g_T, float *workspace, int B, int H, int W,
+                    void *stream);
 
 
 /* ---- a10: layers.transformation_from_parameters (layers.py:28-103) --------------------
@@ -197,7 +199,7 @@ MVF_API int mvf_flow_warp_bwd(const float *img, const float *flow, const float *
 MVF_API size_t mvf_flow_warp_workspace_floats(int B, int C, int H, int W);
 
 /* ---- f2: Trainer.compute_SI_log_depth_loss (train.py:924-941) ----
- * pred, target [B,1,H,W] (N = H*W), mask nullable [B,1,H,W]; B <= 64.
+ * pred, target [B,1,H,W] (N = H*W), mask nullable [B,1,H,W] (same shape; any batch size).
  * loss[0] = mean_b( sum ld^2/n - beta*(sum ld)^2/n^2 ), ld = log(pred+1e-7)*m - log(target+1e-7)*m,
  * n = sum m + 1e-8.  sums [B,4] = {sum ld, sum ld^2, n, -} saved for the backward.
  * workspace: B*64*4 floats. */

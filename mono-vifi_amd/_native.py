@@ -11,7 +11,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -46,9 +46,9 @@ _SIGNATURES = {
     "mvf_unit_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
                      _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     # disp,tgt,src**,T,K,invK,noise,mask, S,flags, smooth,min_disp,range,eps, loss,argmin,auto_mask,
-    # to_opt,stats,g_disp,g_T,ws, B,H,W, stream
+    # to_opt,stats,idx_xy,g_disp,g_T,ws, B,H,W, stream
     "mvf_unit_fwdbwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
-                        _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+                        _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "mvf_unit_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp,
                      _vp, _vp, _i, _i, _i, _vp],
     "mvf_pose_fwd": [_vp, _vp, _vp, _i, _i, _vp],
@@ -125,6 +125,11 @@ def ptr_array(tensors):
 
 
 def require_device(*tensors):
+    """All tensors on ONE HIP device, and that device is torch's current device: the kernels
+    are enqueued on torch.cuda.current_stream() of the current device and take raw pointers,
+    so a tensor of another GPU would be accessed across devices, unordered against the work
+    that produced it (one process per GPU: Trainer / bench.py call torch.cuda.set_device)."""
+    dev = None
     for t in tensors:
         if t is None:
             continue
@@ -132,6 +137,18 @@ def require_device(*tensors):
             raise RuntimeError(
                 "mono_vifi_amd hot-path ops run on a HIP device (MI355X) only; got a "
                 f"{t.device} tensor. There is no CPU fallback.")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError(f"hot-path op got tensors on different devices: {dev} and {t.device}")
+    if dev is not None:
+        import torch
+        cur = torch.cuda.current_device()
+        if dev.index is not None and dev.index != cur:
+            raise RuntimeError(
+                f"hot-path op got {dev} tensors while the current device is cuda:{cur}; call "
+                "torch.cuda.set_device(local_rank) (or use `with torch.cuda.device(t.device)`) "
+                "so that the kernels are enqueued on the stream of the GPU that owns the data")
 
 
 def profile_read(kernel_id):

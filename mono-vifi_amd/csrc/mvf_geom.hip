@@ -505,30 +505,32 @@ __global__ void __launch_bounds__(NT) k_silog_partial(const float *__restrict__ 
 __global__ void k_silog_finish(const float *__restrict__ ws, float *__restrict__ loss,
                                float *__restrict__ sums, int B, float beta)
 {
+    // one lane per image, 64 images per pass, any batch size (images folded in index order)
     __shared__ double acc[64];
-    int b = threadIdx.x;
-    double lb = 0.0;
-    if (b < B) {
-        double s1 = 0.0, s2 = 0.0, n = 0.0;
-        for (int k = 0; k < SIL_NB; ++k) {
-            const float *q = ws + ((size_t)b * SIL_NB + k) * 4;
-            s1 += q[0]; s2 += q[1]; n += q[2];
+    double tot = 0.0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + threadIdx.x;
+        double lb = 0.0;
+        if (b < B) {
+            double s1 = 0.0, s2 = 0.0, n = 0.0;
+            for (int k = 0; k < SIL_NB; ++k) {
+                const float *q = ws + ((size_t)b * SIL_NB + k) * 4;
+                s1 += q[0]; s2 += q[1]; n += q[2];
+            }
+            n += 1e-8;
+            lb = s2 / n - (double)beta * s1 * s1 / (n * n);
+            sums[b * 4 + 0] = (float)s1;
+            sums[b * 4 + 1] = (float)s2;
+            sums[b * 4 + 2] = (float)n;
+            sums[b * 4 + 3] = 0.0f;
         }
-        n += 1e-8;
-        lb = s2 / n - (double)beta * s1 * s1 / (n * n);
-        sums[b * 4 + 0] = (float)s1;
-        sums[b * 4 + 1] = (float)s2;
-        sums[b * 4 + 2] = (float)n;
-        sums[b * 4 + 3] = 0.0f;
+        acc[threadIdx.x] = lb;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 64; ++i) tot += acc[i];
+        __syncthreads();
     }
-    acc[threadIdx.x] = lb;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int i = 0; i < 64; ++i) tot += acc[i];
-        // batches larger than 64 images: handled by the host wrapper in chunks
-        loss[0] = (float)(tot / (double)B);
-    }
+    if (threadIdx.x == 0) loss[0] = (float)(tot / (double)B);
 }
 
 __global__ void __launch_bounds__(NT) k_silog_bwd(const float *__restrict__ pred,
@@ -1021,7 +1023,7 @@ int mvf_silog_fwd(const float *pred, const float *target, const float *mask, flo
                   float *sums, float *workspace, int B, int N, float beta, void *stream)
 {
     if (B <= 0 || N <= 0) return 0;
-    if (B > 64) return (int)hipErrorInvalidValue;
+    if (B > 65535) return (int)hipErrorInvalidValue;   // grid.y
     hipLaunchKernelGGL(k_silog_partial, dim3(SIL_NB, B), dim3(NT), 0, (hipStream_t)stream, pred, target,
                        mask, workspace, N);
     hipLaunchKernelGGL(k_silog_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, loss, sums,

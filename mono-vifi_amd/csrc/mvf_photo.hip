@@ -457,7 +457,7 @@ MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict_
                                 const float *__restrict__ iK, const f2 P2[12], int H, int W, int py0,
                                 int px0, float min_disp, float range, float eps,
                                 int32_t *__restrict__ idx_a, int32_t *__restrict__ idx_b, int ty0,
-                                int tx0)
+                                int tx0, int oh = TH, int ow = TW)
 {
     const size_t N = (size_t)H * W;
     constexpr int NIT = (NSTAGE + U - 1) / U;
@@ -501,7 +501,7 @@ MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict_
             if (idx_a) {
                 // the un-reflected pixels of this tile own their index entry
                 int y = py0 + s[u].r, x = px0 + s[u].c;
-                if (y >= ty0 && y < min(ty0 + TH, H) && x >= tx0 && x < min(tx0 + TW, W)) {
+                if (y >= ty0 && y < min(ty0 + oh, H) && x >= tx0 && x < min(tx0 + ow, W)) {
                     reinterpret_cast<int2 *>(idx_a)[(size_t)y * W + x] = make_int2(s[u].x0a, s[u].y0a);
                     if (idx_b != idx_a)
                         reinterpret_cast<int2 *>(idx_b)[(size_t)y * W + x] = make_int2(s[u].x0b, s[u].y0b);
@@ -838,6 +838,7 @@ struct BwdArgs {
     float *part;                    // [B*ntiles*NPART] loss partials of this tiling
     uint8_t *argmin_out;
     float *auto_mask_out, *to_opt_out;
+    int32_t *idx_xy;                // nullable [S,B,H,W,2] top-left taps (parity tests)
 };
 
 constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a backward region
@@ -953,9 +954,12 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         if (FUSED) {
             load_pose_pair(sh, ka, kb, P2);
 #endif
+            // FB: the region's 62x14 interior owns its entries of the (optional) index maps
+            int32_t *ia = (FB && a.idx_xy) ? a.idx_xy + ((size_t)ka * a.B + b) * N * 2 : nullptr;
+            int32_t *ib = (FB && a.idx_xy) ? a.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
             warp_pair_into_lds<2>(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
                                   a.src.p[kb] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0, px0,
-                               a.min_disp, a.range, a.eps, nullptr, nullptr, 0, 0);
+                               a.min_disp, a.range, a.eps, ia, ib, cy0 + 1, cx0 + 1, OH, OW);
         } else {
 #ifdef MVF_ABL_NOWARPB
             stage_pair3(pairP, a.src.p[ka] + (size_t)b * 3 * N, a.src.p[kb] + (size_t)b * 3 * N, N,
@@ -1755,7 +1759,8 @@ int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src
                     const float *K, const float *inv_K, const float *noise, const float *mask_rec,
                     int S, int flags, float smoothness, float min_disp, float range, float eps,
                     float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
-                    float *g_disp, float *g_T, float *workspace, int B, int H, int W, void *stream)
+                    int32_t *idx_xy, float *g_disp, float *g_T, float *workspace, int B, int H, int W,
+                    void *stream)
 {
     if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
     if (!g_disp || !g_T || !loss || !stats || !workspace) return (int)hipErrorInvalidValue;
@@ -1774,6 +1779,7 @@ int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src
     a.part = workspace + (size_t)B * NMEAN;
     a.ws = a.part + (size_t)B * ntiles * NPART;
     a.noise = noise; a.argmin_out = argmin; a.auto_mask_out = auto_mask; a.to_opt_out = to_opt;
+    a.idx_xy = idx_xy;
     a.g_disp = g_disp;
     hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, workspace, N);
     {

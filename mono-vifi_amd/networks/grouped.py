@@ -40,8 +40,8 @@ def split_groups(t, groups):
 
 class _AllReduceSyncBN(torch.autograd.Function):
     """Synchronised batch norm with plain tensor ops and ONE all-reduce per direction
-    (device-agnostic: this is what the gloo tests run; on a HIP device the native fused
-    SyncBatchNorm kernels are used instead, see GroupedBatchNorm2d._sync_bn)."""
+    (device-agnostic: this is what the CPU gloo tests run; on a HIP device ATen's fused
+    batch-norm kernels are used instead, see _FusedSyncBN)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, eps, group):
@@ -77,6 +77,56 @@ class _AllReduceSyncBN(torch.autograd.Function):
         return gx, s_gyx, s_gy, None, None
 
 
+class _FusedSyncBN(torch.autograd.Function):
+    """Synchronised batch norm on a HIP device from ATen's fused building blocks
+    (torch.batch_norm_stats / batch_norm_gather_stats_with_counts / batch_norm_elemt and the
+    two backward kernels): ONE all_gather of (mean, invstd, count) forward and ONE all_reduce
+    of (sum dy, sum dy*xmu) backward per layer, both on RCCL.  Same arithmetic as
+    nn.SyncBatchNorm, without its dependency on torch's private ``nn.modules._functions`` and
+    without its per-layer host synchronisation (it filters empty ranks with a boolean mask;
+    every rank here always holds the same non-empty batch, `drop_last=True`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group, world):
+        x = x.contiguous()
+        C = x.shape[1]
+        mean, invstd = torch.batch_norm_stats(x, eps)
+        count = torch.full((1,), x.numel() // C, dtype=mean.dtype, device=mean.device)
+        combined = torch.cat([mean, invstd, count])
+        if dist.get_backend(group) == "gloo":          # no all_gather_into_tensor on gloo
+            parts = [torch.empty_like(combined) for _ in range(world)]
+            dist.all_gather(parts, combined, group)
+            allc = torch.stack(parts, 0)
+        else:
+            flat = torch.empty(world * combined.numel(), dtype=combined.dtype, device=combined.device)
+            dist.all_gather_into_tensor(flat, combined, group)
+            allc = flat.view(world, combined.numel())
+        mean_all, invstd_all, count_all = torch.split(allc, C, dim=1)
+        counts = count_all.reshape(-1)
+        mean, invstd = torch.batch_norm_gather_stats_with_counts(
+            x, mean_all.contiguous(), invstd_all.contiguous(), running_mean, running_var, momentum, eps,
+            counts)
+        ctx.save_for_backward(x, weight, mean, invstd, counts.to(torch.int32))
+        ctx.group = group
+        return torch.batch_norm_elemt(x, weight, bias, mean, invstd, eps)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight, mean, invstd, counts = ctx.saved_tensors
+        gy = gy.contiguous()
+        sum_dy, sum_dy_xmu, gw, gb = torch.batch_norm_backward_reduce(
+            gy, x, mean, invstd, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+            ctx.needs_input_grad[2])
+        gx = None
+        if ctx.needs_input_grad[0]:
+            C = sum_dy.shape[0]
+            both = torch.cat([sum_dy, sum_dy_xmu])
+            dist.all_reduce(both, op=dist.ReduceOp.SUM, group=ctx.group)
+            sum_dy, sum_dy_xmu = torch.split(both, C)
+            gx = torch.batch_norm_backward_elemt(gy, x, mean, invstd, weight, sum_dy, sum_dy_xmu, counts)
+        return gx, gw, gb, None, None, None, None, None, None
+
+
 class GroupedBatchNorm2d(nn.BatchNorm2d):
     """``nn.BatchNorm2d`` whose input may hold ``groups`` interleaved independent calls."""
 
@@ -84,14 +134,14 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         super().__init__(*args, **kwargs)
         self.groups = 1
         self.sync = False            # synchronise statistics across ranks (SyncBatchNorm semantics)
+        self.force_sync = False      # take the synchronised branch even in a group of one (tests)
         self.process_group = None
 
     def _sync_bn(self, xv, w, b, rm, rv, world):
         """SyncBatchNorm over the folded view; updates rm/rv in place."""
         if xv.is_cuda:
-            from torch.nn.modules._functions import SyncBatchNorm as sync_fn
             group = self.process_group or dist.group.WORLD
-            return sync_fn.apply(xv, w, b, rm, rv, self.eps, self.momentum, group, world)
+            return _FusedSyncBN.apply(xv, w, b, rm, rv, self.eps, self.momentum, group, world)
         y, mean, var, n = _AllReduceSyncBN.apply(xv, w, b, self.eps, self.process_group)
         with torch.no_grad():
             rm.mul_(1 - self.momentum).add_(mean, alpha=self.momentum)
@@ -101,7 +151,7 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
     def forward(self, x):
         G = self.groups
         world = dist.get_world_size(self.process_group) if (self.sync and dist.is_initialized()) else 1
-        sync = self.sync and world > 1 and self.training
+        sync = self.sync and (world > 1 or self.force_sync) and self.training
         if not self.training or (G == 1 and not sync):
             return super().forward(x)       # eval: running statistics are the same for every call
         if self.momentum is None or not self.track_running_stats:
@@ -135,7 +185,7 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         self.num_batches_tracked += G
 
 
-def convert_grouped_batchnorm(module, sync=False, process_group=None):
+def convert_grouped_batchnorm(module, sync=False, process_group=None, force_sync=False):
     """Replace every ``nn.BatchNorm2d`` (or SyncBatchNorm) under ``module`` by a
     ``GroupedBatchNorm2d`` sharing its parameters and buffers; returns the module."""
     out = module
@@ -148,9 +198,9 @@ def convert_grouped_batchnorm(module, sync=False, process_group=None):
         out.num_batches_tracked = module.num_batches_tracked
         out.training = module.training
     if isinstance(out, GroupedBatchNorm2d):
-        out.sync, out.process_group = bool(sync), process_group
+        out.sync, out.process_group, out.force_sync = bool(sync), process_group, bool(force_sync)
     for name, child in module.named_children():
-        new = convert_grouped_batchnorm(child, sync, process_group)
+        new = convert_grouped_batchnorm(child, sync, process_group, force_sync)
         if new is not child:
             out.add_module(name, new)
     return out

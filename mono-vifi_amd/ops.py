@@ -395,7 +395,7 @@ class Unit(torch.autograd.Function):
         stats = torch.empty((B, 4), dtype=torch.float32, device=dev)
         ws = _ws(disp, B, H, W)
         sp, skeep = nat.ptr_array(src)
-        ctx.fwdbwd = bool(UNIT_FWDBWD and S <= 2 and not want_idx and
+        ctx.fwdbwd = bool(UNIT_FWDBWD and S <= 2 and
                           (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]))
         if ctx.fwdbwd:
             g_disp = torch.empty_like(disp)
@@ -403,12 +403,12 @@ class Unit(torch.autograd.Function):
             nat.check(nat.lib().mvf_unit_fwdbwd(
                 nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K), nat.ptr(inv_K), nat.ptr(noise),
                 nat.ptr(mask_rec), S, flags, smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
-                nat.ptr(auto_mask), None, nat.ptr(stats), nat.ptr(g_disp), nat.ptr(g_T), nat.ptr(ws),
-                B, H, W, _stream()), "unit_fwdbwd")
+                nat.ptr(auto_mask), None, nat.ptr(stats), nat.ptr(idx), nat.ptr(g_disp), nat.ptr(g_T),
+                nat.ptr(ws), B, H, W, _stream()), "unit_fwdbwd")
             ctx.save_for_backward(g_disp, g_T)
             ctx.n_src = S
             outs = [loss[0], auto_mask if want_mask else torch.empty(0, device=dev), argmin,
-                    torch.empty(0, device=dev), loss[1:]]
+                    idx if want_idx else torch.empty(0, device=dev), loss[1:]]
             ctx.mark_non_differentiable(*outs[1:])
             return tuple(outs)
         nat.check(nat.lib().mvf_unit_fwd(nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K),
@@ -550,8 +550,10 @@ class SILog(torch.autograd.Function):
         N = pred[0].numel()
         if pred.shape[1] != 1 or target.shape != pred.shape:
             raise RuntimeError("compute_SI_log_depth_loss expects pred/target [B,1,H,W]")
-        if B > 64:
-            raise RuntimeError("mvf_silog supports batch sizes up to 64")
+        if mask is not None and mask.shape != pred.shape:
+            # the kernel indexes the mask as [B,N]; the reference multiplies, so anything
+            # broadcastable is legal there (train.py:930-933)
+            mask = mask.expand(pred.shape).contiguous()
         dev = pred.device
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         sums = torch.empty((B, 4), dtype=torch.float32, device=dev)

@@ -107,6 +107,10 @@ def build_parser():
                    help="fused unit kernels (warped images in LDS) instead of the staged "
                         "generate_images_pred + compute_losses_base pair")
     p.add_argument("--bucket_mb", type=float, default=32.0, help="gradient all-reduce bucket size")
+    p.add_argument("--force_collectives", type=_str2bool, default=False,
+                   help="issue the data-parallel collectives (bucketed gradient all-reduce, "
+                        "SyncBatchNorm statistics) even when world_size is 1 -- exercises the RCCL "
+                        "code path on a one-GPU box; needs an initialised process group")
     p.add_argument("--channels_last", type=_str2bool, default=False)
     p.add_argument("--amp_bf16", type=_str2bool, default=False,
                    help="bf16 autocast for the conv networks (the hot path stays fp32)")

@@ -29,6 +29,10 @@ def init_distributed(opts, backend=None):
     """Initialise the default process group from the torchrun environment (or the
     reference's --local_rank / --world_size flags).  Returns (rank, world_size)."""
     import os
+    if torch.cuda.is_available():
+        # one process per GPU: make this rank's GPU the current device before any stream,
+        # allocation or communicator is created (reference: train.py torch.cuda.set_device)
+        torch.cuda.set_device(opts.local_rank % torch.cuda.device_count())
     if opts.world_size <= 1:
         return 0, 1
     if not dist.is_initialized():
@@ -38,7 +42,7 @@ def init_distributed(opts, backend=None):
             "nccl" if torch.cuda.is_available() else "gloo")
         kw = {}
         if backend == "nccl":
-            kw["device_id"] = torch.device("cuda", opts.local_rank)
+            kw["device_id"] = torch.device("cuda", opts.local_rank % torch.cuda.device_count())
         dist.init_process_group(backend=backend, init_method="env://",
                                 world_size=opts.world_size, rank=opts.global_rank, **kw)
     return dist.get_rank(), dist.get_world_size()
@@ -101,8 +105,11 @@ class _Bucket:
 class BucketedGradReducer:
     """Flat-bucket gradient averaging overlapped with backward (see module docstring)."""
 
-    def __init__(self, params, world_size=None, bucket_mb=32.0, process_group=None):
+    def __init__(self, params, world_size=None, bucket_mb=32.0, process_group=None,
+                 always_reduce=False):
         self.group = process_group
+        # always_reduce: issue the collectives even for a group of one (RCCL smoke on one GPU)
+        self.always_reduce = bool(always_reduce)
         self.world = world_size if world_size is not None else (
             dist.get_world_size(process_group) if dist.is_initialized() else 1)
         self.params = list(params)
@@ -146,7 +153,7 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         b.launched = True
-        if self.world > 1:
+        if self.world > 1 or self.always_reduce:
             b.buf.div_(self.world)
             b.handle = dist.all_reduce(b.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 

@@ -73,6 +73,12 @@ class Trainer(HotPathLosses):
 
         self.device = torch.device("cuda", o.local_rank % torch.cuda.device_count()) \
             if torch.cuda.is_available() else torch.device("cpu")
+        if self.device.type == "cuda":
+            # reference: train.py sets torch.cuda.set_device(opts.local_rank) before building the
+            # Trainer.  Everything that reads "the current device" -- torch's current stream (on
+            # which the HIP kernels are enqueued), torch.cuda.synchronize(), RCCL's default
+            # device -- must resolve to this rank's GPU, not to cuda:0.
+            torch.cuda.set_device(self.device)
         if o.seed > 0:
             self.set_seed(o.seed)
 
@@ -157,7 +163,8 @@ class Trainer(HotPathLosses):
             # per-call BatchNorm statistics for interleaved grouped calls; with sync_bn one
             # collective per layer carries the statistics of every call
             for m in self._modules_unique.values():
-                grouped.convert_grouped_batchnorm(m, sync=o.world_size > 1 and o.sync_bn)
+                grouped.convert_grouped_batchnorm(m, sync=(o.world_size > 1 or o.force_collectives) and o.sync_bn,
+                                                  force_sync=o.force_collectives)
         if o.world_size > 1:
             if o.sync_bn and self.device.type == "cuda" and not o.group_calls:
                 for k in list(self._modules_unique):
@@ -202,12 +209,31 @@ class Trainer(HotPathLosses):
             self.model_lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(
                 self.model_optimizer, o.decay_step, o.decay_rate)
         if checkpoint:
-            self.model_optimizer.load_state_dict(checkpoint["optimizer"])
-            self.model_lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
+            # Model weights interchange with the reference's ckpt.pth; optimiser state does not:
+            # the reference's optimiser holds the aliased encoder_mf / depth_mf parameters twice
+            # and the dead ImageNet fc head (train.py:198-200), this one holds each parameter
+            # once.  A foreign optimiser state is therefore dropped (fresh moments, schedule
+            # fast-forwarded to the checkpoint's step) instead of raising.
+            try:
+                self.model_optimizer.load_state_dict(checkpoint["optimizer"])
+                self.model_lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
+            except (ValueError, KeyError, RuntimeError) as e:
+                logging.warning("optimizer state of the checkpoint does not match this trainer's "
+                                "parameter list (%s): restarting the optimizer moments, keeping "
+                                "weights, epoch and step", e)
+                sched = checkpoint.get("lr_scheduler", {})
+                last = int(sched.get("last_epoch", 0)) if isinstance(sched, dict) else 0
+                if o.lr_sche_type == "cos":
+                    last = min(last, max(self.num_total_steps, 1))
+                import warnings
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")     # scheduler.step() before optimizer.step()
+                    for _ in range(last):
+                        self.model_lr_scheduler.step()
             del checkpoint
 
         self.reducer = parallel.BucketedGradReducer(self.parameters_to_train, o.world_size,
-                                                    o.bucket_mb)
+                                                    o.bucket_mb, always_reduce=o.force_collectives)
 
         # ---- hot-path modules (reference: train.py:248-256)
         if not o.no_ssim:
@@ -348,7 +374,9 @@ class Trainer(HotPathLosses):
             return [self._depth(decoder, f) for f in feats_list]
         G = len(feats_list)
         merged = [grouped.merge_groups([f[l] for f in feats_list]) for l in range(len(feats_list[0]))]
-        out = self._depth(decoder, merged)
+        # a no-op today (no decoder has BatchNorm); keeps per-call statistics if one ever does
+        with grouped.grouped(self.models[decoder], G):
+            out = self._depth(decoder, merged)
         split = {k: grouped.split_groups(v, G) for k, v in out.items()}
         return [{k: split[k][g] for k in out} for g in range(G)]
 
@@ -365,7 +393,8 @@ class Trainer(HotPathLosses):
         feats = [[grouped.merge_groups([j[0][pos][l] for j in jobs]) for l in range(L)] for pos in range(3)]
         flows = [grouped.merge_groups([j[1][k] for j in jobs]) for k in range(2)]
         mask = grouped.merge_groups([j[2] for j in jobs])
-        out = one(feats, flows, mask)
+        with grouped.grouped(self.models["fusion_module"], G), grouped.grouped(self.models["depth_mf"], G):
+            out = one(feats, flows, mask)
         split = {k: grouped.split_groups(v, G) for k, v in out.items()}
         return [{k: split[k][g] for k in out} for g in range(G)]
 

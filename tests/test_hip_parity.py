@@ -199,11 +199,27 @@ def test_unit_gradients(dev, case, path):
 
 
 # ------------------------------------------------------------------ full size (G4)
+@pytest.fixture
+def unit_kernel(request):
+    """Selects which tile kernels a unit with gradients runs: "fwdbwd" = mvf_unit_fwdbwd (one
+    kernel, what the training step runs), "separate" = mvf_unit_fwd + mvf_unit_bwd."""
+    from mono_vifi_amd import ops
+    old = ops.UNIT_FWDBWD
+    ops.UNIT_FWDBWD = request.param == "fwdbwd"
+    yield request.param
+    ops.UNIT_FWDBWD = old
+
+
+BOTH_KERNELS = pytest.mark.parametrize("unit_kernel", ["fwdbwd", "separate"], indirect=True)
+
+
+@BOTH_KERNELS
 @pytest.mark.parametrize("cfg", ["C1", "C2", "C4", "C5"])
-def test_fullsize_unit(dev, cfg):
-    """BASELINE.json shapes through the fused unit: index-map SHA-256, loss, auto-mask and
-    sampled gradients against what the reference produced on the same seeded inputs, and
-    the whole tensors against the oracle."""
+def test_fullsize_unit(dev, cfg, unit_kernel):
+    """BASELINE.json shapes through the fused unit -- with the training kernel
+    (mvf_unit_fwdbwd) and with the separate forward / backward kernels: index-map SHA-256,
+    loss, auto-mask and sampled gradients against what the reference produced on the same
+    seeded inputs, and the whole tensors (argmin, grad_disp, grad_T) against the oracle."""
     from mono_vifi_amd import ops, synthetic
     g = load_golden("g4_full_" + cfg)
     B, H, W = (int(v) for v in g["shape"])
@@ -244,11 +260,13 @@ RAGGED = [(1, 2, 2), (1, 3, 5), (2, 14, 62), (1, 15, 63), (1, 16, 64), (2, 17, 6
           (3, 33, 70), (1, 64, 200)]
 
 
+@BOTH_KERNELS
 @pytest.mark.parametrize("shape", RAGGED)
 @pytest.mark.parametrize("flags", [0, 1, 2, 4, 6])
-def test_ragged_shapes_vs_oracle(dev, shape, flags):
+def test_ragged_shapes_vs_oracle(dev, shape, flags, unit_kernel):
     """Tile-edge and tiny shapes (partial tiles, reflect halo == whole image, 1-tile
-    images) for every flag combination, staged and fused, against the oracle."""
+    images) for every flag combination, both kernel routes, against the oracle (indices,
+    argmin, loss, gradients)."""
     from mono_vifi_amd import ops, synthetic
     B, H, W = shape
     inp = synthetic.unit_inputs(900 + H * W + flags, B, H, W, pose_scale=0.03, with_mask=True)

@@ -149,3 +149,42 @@ def test_silog():
         assert abs(loss - float(g["loss_" + tag])) <= 2e-6 * abs(float(g["loss_" + tag]))
         assert rel_err(gp, g["grad_pred_" + tag]) <= 1e-5
         assert rel_err(gt, g["grad_target_" + tag]) <= 1e-5
+
+
+@pytest.mark.parametrize("case", ["default", "mask", "no_ssim", "avg", "noauto"])
+def test_unfused_torch_vs_golden(case):
+    """oracle/torch_unfused.py -- the un-fused ~130-ATen-op formulation timed as the second CPU
+    baseline -- reproduces what the reference produced on G3: warped
+    images, loss, gradients."""
+    from oracle import torch_unfused as U
+    g = load_golden("g3_grad_" + case)
+    fl = g["flags"]
+    flags = int(fl[0]) * U.NO_SSIM + int(fl[1]) * U.AVG_REPROJ + int(fl[2]) * U.NO_AUTOMASK
+    noise = g["noise"] if "noise" in g and not fl[2] else None
+    mask = g["mask_rec"] if case == "mask" else None
+    out = U.unit(g["disp"], g["tgt"], g["src"], g["T"], g["K"], g["inv_K"], noise, mask, flags)
+    for k in range(2):
+        assert np.max(np.abs(out["warped"][k] - g["warped"][k])) <= 1e-6
+    assert abs(out["loss"] - float(g["loss"])) <= 1e-6 * abs(float(g["loss"]))
+    assert rel_err(out["grad_disp"], g["grad_disp"]) <= 1e-5
+    assert rel_err(out["grad_T"], g["grad_T"]) <= 1e-5
+
+
+def test_require_device_rejects_foreign_and_mixed_devices(monkeypatch):
+    """kernels are enqueued on the CURRENT device's stream with raw pointers, so
+    tensors of another GPU (or of two GPUs) must be rejected, not silently accessed across
+    devices (one process per GPU: Trainer / bench.py select the rank's device)."""
+    import torch
+    from mono_vifi_amd import _native
+
+    class FakeT:
+        is_cuda = True
+
+        def __init__(self, i):
+            self.device = torch.device("cuda", i)
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    _native.require_device(FakeT(0), None, FakeT(0))
+    with pytest.raises(RuntimeError, match="different devices"):
+        _native.require_device(FakeT(0), FakeT(1))
+    with pytest.raises(RuntimeError, match="current device"):
+        _native.require_device(FakeT(1), FakeT(1))
