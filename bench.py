@@ -74,9 +74,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hotpath-leg", dest="no_hotpath_leg", action="store_true",
                     help="train workload: skip the extra hot-path-only measurement")
-    ap.add_argument("--inkernel-noise", dest="inkernel_noise", action="store_true",
-                    help="hotpath workload: tie-break noise generated in the tile kernel (counter-based) "
-                         "instead of a torch.randn tensor per unit")
+    ap.add_argument("--noise", default="kernel", choices=["kernel", "tensor"],
+                    help="auto-mask tie-break noise: drawn inside the tile kernel (counter-based, "
+                         "default) or supplied as a torch.randn tensor per unit (+8 B/px)")
     ap.add_argument("--amp-bf16", dest="amp_bf16", action="store_true",
                     help="bf16 autocast for the conv networks (reduced precision: not the default)")
     ap.add_argument("--channels-last", dest="channels_last", action="store_true")
@@ -126,7 +126,7 @@ class HotPathStep:
         self.l = L()
         self.l.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False,
                                      avg_reprojection=False, disable_automasking=False,
-                                     disparity_smoothness=1e-3)
+                                     disparity_smoothness=1e-3, inkernel_noise=args.noise == "kernel")
         B, H, W = args.batch, args.height, args.width
         self.units = []
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -298,7 +298,7 @@ def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n):
     r_bwd = roof(bwd_ms, bwd_n, BWD_BYTES_PER_PX, "k_photo_bwd<fused>")
     # forward+backward of a unit in one tile kernel (the training path): priced on ITS OWN
     # minimum traffic (inputs read once), plus the optional planes the launches were given
-    noise_px = 0 if args.inkernel_noise else NOISE_BYTES_PER_PX
+    noise_px = 0 if args.noise == "kernel" else NOISE_BYTES_PER_PX
     fb_px = FB_BYTES_PER_PX + noise_px + MASK_BYTES_PER_PX * MASKED_UNITS_PER_STEP / UNITS_PER_STEP
     r_fb = roof(fb_ms, fb_n, fb_px, "k_photo_fwdbwd<fused>")
     if r_fb:

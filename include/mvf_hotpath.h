@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 2
+#define MVF_ABI_VERSION 3
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -162,18 +162,30 @@ MVF_API int mvf_unit_bwd(const float *disp, const float *tgt, const float *const
                  float min_disp, float range, float eps, float *g_disp, float *g_T,
                  float *workspace, int B, int H, int W, void *stream);
 /* Forward AND backward of a unit in one tile kernel (S <= 2: one source pair), for the
- * training step, where both always run: loss[3], stats[B,4] as mvf_unit_fwd, plus
- * g_disp [B,1,H,W] and g_T [S,B,4,4] for an upstream gradient of 1 (the backward is linear in
- * it: the caller scales).  The warp, the staging and the target statistics are done once
- * instead of once per direction.  argmin / auto_mask / to_opt nullable; idx_xy nullable
- * int32 [S,B,H,W,2] as for mvf_unit_fwd (the parity tests read the sampling indices of the
- * kernel that trains).  workspace: mvf_workspace_floats(B,H,W) floats. */
+ * training step, where both always run: loss[3], stats[B,4] as mvf_unit_fwd, plus the
+ * gradients for an upstream gradient of 1 in RAW form -- g_disp_raw [B,1,H,W] lacks the
+ * per-image constant of the mean-normalised smoothness term (it needs the per-image smoothness
+ * sum, known only after the launch) and g_T_raw [S,B,4,4] is final; mvf_unit_fwdbwd_scale
+ * applies the constant and the upstream gradient in one pass (the backward is linear in it).
+ * The warp, the staging and the window statistics are done once instead of once per direction.
+ * argmin / auto_mask / to_opt nullable; idx_xy nullable int32 [S,B,H,W,2] as for mvf_unit_fwd
+ * (the parity tests read the sampling indices of the kernel that trains).
+ * noise == NULL (with auto-masking on): the tie-break draw of train.py:1023-1024 is generated
+ * in the kernel from a counter-based generator keyed by noise_seed and the element index, and
+ * written to noise_out (nullable, same layout as noise) so that it can be replayed.
+ * workspace: mvf_workspace_floats(B,H,W) floats. */
 MVF_API int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
                     const float *K, const float *inv_K, const float *noise, const float *mask_rec,
                     int S, int flags, float smoothness, float min_disp, float range, float eps,
                     float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
-                    int32_t *idx_xy, float *g_disp, float *g_T, float *workspace, int B, int H, int W,
-                    void *stream);
+                    int32_t *idx_xy, float *g_disp_raw, float *g_T_raw, float *workspace, int B, int H,
+                    int W, uint64_t noise_seed, float *noise_out, void *stream);
+/* backward() of the above: g_disp = (g_disp_raw - shift_b) * (*g_loss), g_T = g_T_raw * (*g_loss),
+ * shift_b = (smoothness * (stats[b,2] + stats[b,3]) / (H*W)) / stats[b,1]; g_loss device scalar.
+ * In-place use (g_disp == g_disp_raw) is allowed. */
+MVF_API int mvf_unit_fwdbwd_scale(const float *g_disp_raw, const float *g_T_raw, const float *stats,
+                          const float *g_loss, float smoothness, float *g_disp, float *g_T, int B,
+                          int S, int H, int W, void *stream);
 
 
 /* ---- a10: layers.transformation_from_parameters (layers.py:28-103) --------------------

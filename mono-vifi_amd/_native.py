@@ -10,8 +10,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 2
+# MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
+LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
+ABI_VERSION = 3
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -46,9 +47,10 @@ _SIGNATURES = {
     "mvf_unit_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
                      _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     # disp,tgt,src**,T,K,invK,noise,mask, S,flags, smooth,min_disp,range,eps, loss,argmin,auto_mask,
-    # to_opt,stats,idx_xy,g_disp,g_T,ws, B,H,W, stream
+    # to_opt,stats,idx_xy,g_disp_raw,g_T_raw,ws, B,H,W, noise_seed,noise_out, stream
     "mvf_unit_fwdbwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
-                        _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+                        _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_uint64, _vp, _vp],
+    "mvf_unit_fwdbwd_scale": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_unit_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp,
                      _vp, _vp, _i, _i, _i, _vp],
     "mvf_pose_fwd": [_vp, _vp, _vp, _i, _i, _vp],

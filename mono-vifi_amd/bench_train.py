@@ -25,7 +25,8 @@ class TrainStep:
             local_rank=dev.index or 0, log_dir=tempfile.mkdtemp(prefix="mvf_bench_"),
             exp_name=f"bench_r{rank}", num_workers=0, synthetic_len=max(4096, args.batch * world * 4),
             log_frequency=10 ** 9, save_frequency=10 ** 9, learning_rate=1e-4,
-            amp_bf16=getattr(args, "amp_bf16", False), channels_last=getattr(args, "channels_last", False))
+            amp_bf16=getattr(args, "amp_bf16", False), channels_last=getattr(args, "channels_last", False),
+            inkernel_noise=getattr(args, "noise", "kernel") == "kernel")
         self.trainer = Trainer(opts)
         self.trainer.set_train()
         b = synthetic.training_batch(1234 + 7919 * rank, args.batch, args.height, args.width)

@@ -18,498 +18,10 @@
 // Bound: the exact-mode window arithmetic (no shared partial sums, true divides) makes
 // these kernels VALU-bound below the HBM roofline -- see DESIGN.md section 5.
 // Compiled with -ffp-contract=off (arithmetic contract in mvf_common.hpp).
-#include "mvf_common.hpp"
-
-using namespace mvf;
+#include "mvf_tile.hpp"
 
 namespace {
 
-constexpr int TW = 64, TH = 16;          // compute region
-constexpr int PX = 4;                    // pixels per lane (one row segment)
-constexpr int NT = (TW / PX) * TH;       // 256 lanes
-constexpr int PW = TW + 2;               // staged plane width (1-px halo)
-constexpr int PH = TH + 2;
-constexpr int LDW = TW + 4;              // LDS row stride (floats), multiple of 4
-constexpr int PLANE = PH * LDW;          // floats per LDS plane
-constexpr int RPLANE = TH * LDW;         // floats per region-sized LDS plane
-constexpr int NMEAN = 32;                // partial sums per image of the disp mean
-constexpr int NPART = 4;                 // floats per tile partial (photo, sx, sy, pad)
-
-static_assert(NT == 256, "tile engine assumes 256 lanes");
-
-// XCD-aware tile order.  The dispatcher places workgroup i on XCD i % 8 (private 4 MiB L2
-// each).  Re-number so that each XCD owns one contiguous run of tiles (neighbouring tiles of
-// the same image rows): the 1-px halo columns/rows and the bilinear taps a tile shares with
-// its neighbours then hit in that XCD's L2 instead of being fetched once per XCD.  Pure
-// speed choice -- any placement gives the same results.
-struct TileId {
-    int bx, by, b;
-};
-MVF_DEV TileId tile_of_block(int tiles_x, int tiles_y, int B)
-{
-    const int total = tiles_x * tiles_y * B;
-    const int lin = blockIdx.x;
-    const int xcd = lin & 7, slot = lin >> 3;
-    const int q = total >> 3, r = total & 7;
-    const int vid = xcd * q + min(xcd, r) + slot;
-    TileId t;
-    t.bx = vid % tiles_x;
-    const int rest = vid / tiles_x;
-    t.by = rest % tiles_y;
-    t.b = rest / tiles_y;
-    return t;
-}
-
-MVF_DEV int refl_clamp(int j, int n)
-{
-    j = (j < 0) ? -j : j;
-    j = (j >= n) ? 2 * (n - 1) - j : j;
-    return min(max(j, 0), n - 1);
-}
-
-// stage one [H,W] plane into LDS with reflect addressing; plane origin (py0, px0)
-constexpr int NSTAGE = (PH * PW + NT - 1) / NT;   // plane elements per lane (5)
-
-// All global loads of a lane are issued before its first LDS store (fully unrolled,
-// constant trip count): one exposed memory latency per staging phase instead of five.
-MVF_DEV void stage_plane(float *__restrict__ lds, const float *__restrict__ img, int H, int W,
-                         int py0, int px0)
-{
-    float v[NSTAGE];
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
-        int r = idx / PW, c = idx - r * PW;
-        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        v[it] = img[(unsigned)gy * W + gx];
-    }
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = threadIdx.x + it * NT;
-        int r = idx / PW, c = idx - r * PW;
-        if (idx < PH * PW) lds[r * LDW + c] = v[it];
-    }
-}
-
-// stage 3 channel planes with all loads of a lane in flight together
-MVF_DEV void stage_planes3(float *__restrict__ lds, const float *__restrict__ img, size_t N, int H,
-                           int W, int py0, int px0)
-{
-    float v[NSTAGE][3];
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
-        int r = idx / PW, c = idx - r * PW;
-        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        unsigned o = (unsigned)gy * W + gx;
-        v[it][0] = img[o]; v[it][1] = img[N + o]; v[it][2] = img[2 * N + o];
-    }
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = threadIdx.x + it * NT;
-        int r = idx / PW, c = idx - r * PW;
-        if (idx < PH * PW) {
-            lds[r * LDW + c] = v[it][0];
-            lds[PLANE + r * LDW + c] = v[it][1];
-            lds[2 * PLANE + r * LDW + c] = v[it][2];
-        }
-    }
-}
-
-// ---- packed fp32 pairs -----------------------------------------------------------------
-// gfx950 VALU executes v_pk_{add,mul,fma}_f32: two IEEE fp32 operations per lane per
-// instruction.  The tile kernels evaluate candidates TWO AT A TIME (e.g. the two warped
-// sources, then the two identity sources): the pair is stored interleaved in LDS as
-// float2, so one ds_read_b128 feeds both, every window add / product / formula step is one
-// packed instruction for both candidates, and no register shuffles are needed.  Each lane
-// of a packed op is the same IEEE operation as the scalar form, so exact mode is unchanged.
-constexpr int PPLANE = PH * LDW;   // f2 elements per staged pair plane
-constexpr int RPPLANE = TH * LDW;  // f2 elements per region-sized pair plane
-
-// 6 consecutive floats of an LDS plane row, starting at a 16-B aligned column
-struct Row6 {
-    float v[6];
-};
-MVF_DEV Row6 load_row6(const float *__restrict__ p)
-{
-    Row6 r;
-    float4 a = *reinterpret_cast<const float4 *>(p);
-    float2 b = *reinterpret_cast<const float2 *>(p + 4);
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y;
-    return r;
-}
-// 6 consecutive pairs of a pair-plane row (48 B, 16-B aligned)
-struct Row6P {
-    f2 v[6];
-};
-MVF_DEV Row6P load_row6p(const f2 *__restrict__ p)
-{
-    Row6P r;
-    const float4 *q = reinterpret_cast<const float4 *>(p);
-    float4 a = q[0], b = q[1], c = q[2];
-    r.v[0] = mk2(a.x, a.y); r.v[1] = mk2(a.z, a.w); r.v[2] = mk2(b.x, b.y);
-    r.v[3] = mk2(b.z, b.w); r.v[4] = mk2(c.x, c.y); r.v[5] = mk2(c.z, c.w);
-    return r;
-}
-
-// Window sums of the 4 pixels of a lane for a candidate PAIR and for the target, row-major
-// sequential order (exact mode).  xs/ys point at plane element (row, 4*seg): window of pixel
-// j = cols j..j+2.  The target statistics ride along as a packed (y, y*y) accumulator; they
-// are recomputed per pair instead of being held in 24 registers across the whole kernel.
-struct Stats4P {
-    f2 sx[PX], sxx[PX], sxy[PX];
-    f2 sy[PX];      // (sum y, sum y*y)
-    f2 xc[PX];      // centre values of the pair
-    float yc[PX];   // centre values of the target
-};
-
-MVF_DEV void window_xp(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4P &o)
-{
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        Row6P x = load_row6p(xs + r * LDW);
-        Row6 y = load_row6(ys + r * LDW);
-        f2 xx[6], xy[6], yy[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            xx[i] = x.v[i] * x.v[i];
-            xy[i] = x.v[i] * f2s(y.v[i]);
-            yy[i] = mk2(y.v[i], y.v[i] * y.v[i]);
-        }
-#pragma unroll
-        for (int j = 0; j < PX; ++j) {
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                if (r == 0 && d == 0) {
-                    o.sx[j] = x.v[j];
-                    o.sxx[j] = xx[j];
-                    o.sxy[j] = xy[j];
-                    o.sy[j] = yy[j];
-                } else {
-                    o.sx[j] = o.sx[j] + x.v[j + d];
-                    o.sxx[j] = o.sxx[j] + xx[j + d];
-                    o.sxy[j] = o.sxy[j] + xy[j + d];
-                    o.sy[j] = o.sy[j] + yy[j + d];
-                }
-            }
-            if (r == 1) {
-                o.xc[j] = x.v[j + 1];
-                o.yc[j] = y.v[j + 1];
-            }
-        }
-    }
-}
-
-// reference: layers.py:281-290 for a candidate pair -- literal expression order per lane
-MVF_DEV f2 ssim_raw_pk(f2 mu_x, f2 mu_y, f2 exx, f2 eyy, f2 exy)
-{
-    f2 sigma_x = exx - mu_x * mu_x;
-    f2 sigma_y = eyy - mu_y * mu_y;
-    f2 sigma_xy = exy - mu_x * mu_y;
-    f2 n = (2.0f * mu_x * mu_y + f2s(kC1)) * (2.0f * sigma_xy + f2s(kC2));
-    f2 d = (mu_x * mu_x + mu_y * mu_y + f2s(kC1)) * (sigma_x + sigma_y + f2s(kC2));
-    // d >= C1*(C2 - rounding) > 0 and |n|, d = O(1) for images in [0,1]: the guard-free
-    // division core gives the correctly rounded quotient (see mvf_common.hpp)
-    return (f2s(1.0f) - div_core(n, d, recip_refined(d))) / 2.0f;
-}
-
-MVF_DEV f2 clamp01_pk(f2 v) { return mk2(clamp01(v.x), clamp01(v.y)); }
-
-// x-side partial derivatives of the clamped SSIM map for a candidate pair
-MVF_DEV void ssim_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &dmux, f2 &dexx, f2 &dexy)
-{
-    f2 sigma_x = exx - mx * mx, sigma_y = eyy - my * my, sigma_xy = exy - mx * my;
-    f2 A1 = 2.0f * mx * my + f2s(kC1), A2 = 2.0f * sigma_xy + f2s(kC2);
-    f2 B1 = mx * mx + my * my + f2s(kC1), B2 = sigma_x + sigma_y + f2s(kC2);
-    f2 n = A1 * A2, d = B1 * B2;
-    const f2 r1 = recip_refined(d);       // shared by n/d and 1/d
-    f2 raw = (f2s(1.0f) - div_core(n, d, r1)) / 2.0f;
-    f2 live = mk2((raw.x >= 0.0f && raw.x <= 1.0f) ? 1.0f : 0.0f,
-                  (raw.y >= 0.0f && raw.y <= 1.0f) ? 1.0f : 0.0f);
-    f2 inv_d = div_core(f2s(1.0f), d, r1);
-    f2 kn = -0.5f * inv_d * live;
-    f2 kd = 0.5f * n * inv_d * inv_d * live;
-    f2 dn_dmx = 2.0f * my * A2 - 2.0f * my * A1;
-    f2 dd_dmx = 2.0f * mx * B2 - 2.0f * mx * B1;
-    dmux = kn * dn_dmx + kd * dd_dmx;
-    dexy = kn * 2.0f * A1;
-    dexx = kd * B1;
-}
-
-// reprojection maps of a staged candidate pair against the staged target for the 4 pixels
-// of this lane.   reference: train.py:973-985.  Channel sums accumulate in the reference's
-// order ((c0 + c1) + c2).
-MVF_DEV void reproj4p(const f2 *__restrict__ pair, const float *__restrict__ tgt, int off,
-                      bool no_ssim, f2 out[PX])
-{
-    f2 ab[PX], ss[PX];
-#pragma unroll
-    for (int j = 0; j < PX; ++j) ab[j] = ss[j] = f2s(0.0f);
-#pragma unroll 1
-    for (int c = 0; c < 3; ++c) {
-        if (no_ssim) {
-            Row6P x = load_row6p(pair + c * PPLANE + off + LDW);
-            Row6 y = load_row6(tgt + c * PLANE + off + LDW);
-#pragma unroll
-            for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(y.v[j + 1]) - x.v[j + 1]);
-        } else {
-            Stats4P s;
-            window_xp(pair + c * PPLANE + off, tgt + c * PLANE + off, s);
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                f2 my = div9(s.sy[j]);     // (mu_y, E[y*y])
-                f2 raw = ssim_raw_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
-                                     div9(s.sxy[j]));
-                ss[j] = ss[j] + clamp01_pk(raw);
-                ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-        f2 l1 = div3(ab[j]);
-        if (no_ssim) {
-            out[j] = l1;
-        } else {
-            f2 sm = div3(ss[j]);
-            out[j] = 0.85f * sm + 0.15f * l1;
-        }
-    }
-}
-
-struct PoseLds {
-    float P[MVF_MAX_SRC][12];
-    float den;    // per-image mean disparity + 1e-7
-    float gpix;   // backward: upstream grad / (B*H*W)
-    float gloss;
-    float pad;
-};
-
-MVF_DEV void load_pose_pair(const PoseLds &sh, int ka, int kb, f2 P2[12])
-{
-#pragma unroll
-    for (int i = 0; i < 12; ++i) P2[i] = mk2(sh.P[ka][i], sh.P[kb][i]);
-}
-
-// overwrite one lane (0/1) of the 3 pair planes with a staged [3,H,W] image (reflect
-// addressing); all 15 loads of a lane are in flight before the first LDS store
-MVF_DEV void stage_lane3(f2 *__restrict__ pairP, int lane, const float *__restrict__ im, size_t N,
-                         int H, int W, int py0, int px0)
-{
-    float *base = reinterpret_cast<float *>(pairP) + lane;
-    float v[NSTAGE][3];
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
-        int r = idx / PW, c = idx - r * PW;
-        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        unsigned o = (unsigned)gy * W + gx;
-        v[it][0] = im[o]; v[it][1] = im[N + o]; v[it][2] = im[2 * N + o];
-    }
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = threadIdx.x + it * NT;
-        int r = idx / PW, c = idx - r * PW;
-        if (idx < PH * PW) {
-            base[2 * (r * LDW + c)] = v[it][0];
-            base[2 * (PPLANE + r * LDW + c)] = v[it][1];
-            base[2 * (2 * PPLANE + r * LDW + c)] = v[it][2];
-        }
-    }
-}
-
-// stage two images interleaved into the pair planes (two passes of 15 loads per lane)
-MVF_DEV void stage_pair3(f2 *__restrict__ pairP, const float *__restrict__ im0,
-                         const float *__restrict__ im1, size_t N, int H, int W, int py0, int px0)
-{
-    stage_lane3(pairP, 0, im0, N, H, W, py0, px0);
-    asm volatile("" ::: "memory");   // keep the passes apart: 15 live values, not 30
-    stage_lane3(pairP, 1, im1, N, H, W, py0, px0);
-}
-
-// Kernel prologue: target (3 planes), disparity and a first candidate pair taken straight
-// from global planes, with ALL 35 loads of a lane in flight before the first LDS store -- one
-// exposed memory latency for what would otherwise be three staging phases.
-MVF_DEV void stage_first(float *__restrict__ tgtP, float *__restrict__ dispP, f2 *__restrict__ pairP,
-                         const float *__restrict__ tgt, const float *__restrict__ disp,
-                         const float *__restrict__ im0, const float *__restrict__ im1, size_t N, int H,
-                         int W, int py0, int px0)
-{
-    float vt[NSTAGE][3], vd[NSTAGE], va[NSTAGE][3], vb[NSTAGE][3];
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
-        int r = idx / PW, c = idx - r * PW;
-        int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        unsigned o = (unsigned)gy * W + gx;
-        vt[it][0] = tgt[o]; vt[it][1] = tgt[N + o]; vt[it][2] = tgt[2 * N + o];
-        vd[it] = disp[o];
-        va[it][0] = im0[o]; va[it][1] = im0[N + o]; va[it][2] = im0[2 * N + o];
-        vb[it][0] = im1[o]; vb[it][1] = im1[N + o]; vb[it][2] = im1[2 * N + o];
-    }
-#pragma unroll
-    for (int it = 0; it < NSTAGE; ++it) {
-        int idx = threadIdx.x + it * NT;
-        int r = idx / PW, c = idx - r * PW;
-        if (idx < PH * PW) {
-            const int e = r * LDW + c;
-            tgtP[e] = vt[it][0]; tgtP[PLANE + e] = vt[it][1]; tgtP[2 * PLANE + e] = vt[it][2];
-            dispP[e] = vd[it];
-            pairP[e] = mk2(va[it][0], vb[it][0]);
-            pairP[PPLANE + e] = mk2(va[it][1], vb[it][1]);
-            pairP[2 * PPLANE + e] = mk2(va[it][2], vb[it][2]);
-        }
-    }
-}
-
-// generate_images_pred for TWO sources at one pixel: the ray, depth and camera point are
-// shared, the projection runs packed (lane 0 = source a, lane 1 = source b).
-struct WarpPair {
-    Tap ta, tb;
-    f2 u, v, z;
-    float X[3], r[3], depth;
-};
-
-MVF_DEV WarpPair warp_point_pair(float disp, const float *__restrict__ iK, const f2 P2[12], int x,
-                                 int y, int H, int W, float min_disp, float range, float eps)
-{
-    WarpPair w;
-    ray_of(iK, (float)x, (float)y, w.r);
-    w.depth = depth_of(disp, min_disp, range);
-    w.X[0] = w.depth * w.r[0];
-    w.X[1] = w.depth * w.r[1];
-    w.X[2] = w.depth * w.r[2];
-    f2 c[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        f2 a = P2[i * 4 + 0] * f2s(w.X[0]);
-        a = pk_fma(P2[i * 4 + 1], f2s(w.X[1]), a);
-        a = pk_fma(P2[i * 4 + 2], f2s(w.X[2]), a);
-        a = pk_fma(P2[i * 4 + 3], f2s(1.0f), a);
-        c[i] = a;
-    }
-    w.z = c[2] + f2s(eps);
-    w.u = c[0] / w.z;
-    w.v = c[1] / w.z;
-    f2 un = w.u / f2s((float)(W - 1));
-    f2 vn = w.v / f2s((float)(H - 1));
-    f2 gx = (un - f2s(0.5f)) * 2.0f;
-    f2 gy = (vn - f2s(0.5f)) * 2.0f;
-    w.ta = tap_of(gx.x, gy.x, H, W);
-    w.tb = tap_of(gx.y, gy.y, H, W);
-    return w;
-}
-
-struct Taps4 {
-    TapRows q;
-    float wnw, wne, wsw, wse;
-};
-MVF_DEV Taps4 taps_of(const Tap &t, int W)
-{
-    Taps4 r;
-    r.q = taprows_of(t, W);
-    float fw = t.wx, fe = 1.0f - fw, fn = t.wy, fs = 1.0f - fn;
-    r.wnw = fs * fe; r.wne = fs * fw; r.wsw = fn * fe; r.wse = fn * fw;
-    return r;
-}
-
-// fused warp of a source pair into the pair planes: bilinear samples of src_a / src_b at
-// the projected position of every plane pixel (reflect-mapped into the image).  Two plane
-// positions are processed per iteration: their projection chains (long dependent sequences
-// of divides) interleave, and all 48 taps are in flight before the first use.
-struct WarpSlot {
-    Taps4 qa, qb;
-    int r, c, x0a, y0a, x0b, y0b;
-    bool live;
-};
-
-MVF_DEV WarpSlot warp_slot(int idx, const float *__restrict__ dispP, const float *__restrict__ iK,
-                           const f2 P2[12], int H, int W, int py0, int px0, float min_disp,
-                           float range, float eps)
-{
-    WarpSlot s;
-    s.live = idx < PH * PW;
-    idx = min(idx, PH * PW - 1);
-    s.r = idx / PW;
-    s.c = idx - s.r * PW;
-    int gy = refl_clamp(py0 + s.r, H), gx = refl_clamp(px0 + s.c, W);
-#ifdef MVF_ABL_NOCHAIN
-    WarpPair w = {};
-#else
-    WarpPair w = warp_point_pair(dispP[s.r * LDW + s.c], iK, P2, gx, gy, H, W, min_disp, range, eps);
-#endif
-    s.qa = taps_of(w.ta, W);
-    s.qb = taps_of(w.tb, W);
-#ifdef MVF_ABL_COALESCED   // ablation: taps at the pixel itself (perfectly coalesced gathers)
-    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = (unsigned)gy * W + min(gx, W - 2);
-#endif
-#ifdef MVF_ABL_NOCHAIN     // ablation: no projection chain (taps from the disparity bits)
-    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = (unsigned)gy * W + min(gx, W - 2);
-    s.qa.wnw = s.qb.wnw = dispP[s.r * LDW + s.c];
-#endif
-    s.x0a = w.ta.x0; s.y0a = w.ta.y0; s.x0b = w.tb.x0; s.y0b = w.tb.y0;
-    return s;
-}
-
-template <int U>   // plane positions per iteration (1: fewest registers, 2: more overlap)
-MVF_DEV void warp_pair_into_lds(f2 *__restrict__ pairP, const float *__restrict__ dispP,
-                                const float *__restrict__ sa, const float *__restrict__ sb,
-                                const float *__restrict__ iK, const f2 P2[12], int H, int W, int py0,
-                                int px0, float min_disp, float range, float eps,
-                                int32_t *__restrict__ idx_a, int32_t *__restrict__ idx_b, int ty0,
-                                int tx0, int oh = TH, int ow = TW)
-{
-    const size_t N = (size_t)H * W;
-    constexpr int NIT = (NSTAGE + U - 1) / U;
-#pragma unroll 1
-    for (int it = 0; it < NIT; ++it) {
-        WarpSlot s[U];
-        float a[U][3][4], bq[U][3][4];
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-            s[u] = warp_slot((int)threadIdx.x + (U * it + u) * NT, dispP, iK, P2, H, W, py0, px0,
-                             min_disp, range, eps);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-#ifdef MVF_ABL_LDSGATHER   // ablation: taps from an LDS plane (access-pattern cost of an LDS-staged source)
-                {
-                    int ya = min(max(s[u].y0a - py0, 0), PH - 2), xa = min(max(s[u].x0a - px0, 0), PW - 2);
-                    int yb = min(max(s[u].y0b - py0, 0), PH - 2), xb = min(max(s[u].x0b - px0, 0), PW - 2);
-                    const float *la = dispP + ya * LDW + xa, *lb = dispP + yb * LDW + xb;
-                    a[u][ch][0] = la[0] + ch; a[u][ch][1] = la[1]; a[u][ch][2] = la[LDW]; a[u][ch][3] = la[LDW + 1];
-                    bq[u][ch][0] = lb[0] + ch; bq[u][ch][1] = lb[1]; bq[u][ch][2] = lb[LDW]; bq[u][ch][3] = lb[LDW + 1];
-                }
-#else
-                load_taps(sa + ch * N, s[u].qa.q, a[u][ch][0], a[u][ch][1], a[u][ch][2], a[u][ch][3]);
-                load_taps(sb + ch * N, s[u].qb.q, bq[u][ch][0], bq[u][ch][1], bq[u][ch][2], bq[u][ch][3]);
-#endif
-            }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!s[u].live) continue;
-            const Taps4 &qa = s[u].qa, &qb = s[u].qb;
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                float va = a[u][ch][0] * qa.wnw + a[u][ch][1] * qa.wne + a[u][ch][2] * qa.wsw +
-                           a[u][ch][3] * qa.wse;
-                float vb = bq[u][ch][0] * qb.wnw + bq[u][ch][1] * qb.wne + bq[u][ch][2] * qb.wsw +
-                           bq[u][ch][3] * qb.wse;
-                pairP[ch * PPLANE + s[u].r * LDW + s[u].c] = mk2(va, vb);
-            }
-            if (idx_a) {
-                // the un-reflected pixels of this tile own their index entry
-                int y = py0 + s[u].r, x = px0 + s[u].c;
-                if (y >= ty0 && y < min(ty0 + oh, H) && x >= tx0 && x < min(tx0 + ow, W)) {
-                    reinterpret_cast<int2 *>(idx_a)[(size_t)y * W + x] = make_int2(s[u].x0a, s[u].y0a);
-                    if (idx_b != idx_a)
-                        reinterpret_cast<int2 *>(idx_b)[(size_t)y * W + x] = make_int2(s[u].x0b, s[u].y0b);
-                }
-            }
-        }
-    }
-}
 
 // =============================================================================== forward
 struct FwdArgs {
@@ -833,12 +345,6 @@ struct BwdArgs {
     float *g_disp, *ws;
     int S, flags, B, H, W, tiles_x, tiles_y;
     float smoothness, min_disp, range, eps;
-    // forward+backward in one pass (FB): the forward's inputs and outputs
-    const float *noise, *mean_ws;   // tie-break noise; [B*NMEAN] mean partials of k_disp_mean
-    float *part;                    // [B*ntiles*NPART] loss partials of this tiling
-    uint8_t *argmin_out;
-    float *auto_mask_out, *to_opt_out;
-    int32_t *idx_xy;                // nullable [S,B,H,W,2] top-left taps (parity tests)
 };
 
 constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a backward region
@@ -848,19 +354,9 @@ constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a backward regio
 constexpr int BWD_TGT = 0, BWD_PAIR = 3 * PLANE, BWD_DISP = BWD_PAIR + 6 * PLANE,
               BWD_COEF = BWD_DISP + PLANE, BWD_GD = BWD_COEF + 6 * RPLANE, BWD_POSE = BWD_GD + RPLANE;
 
-// FB = forward AND backward of the unit in one pass.  Everything the backward needs from the
-// forward is per-pixel local (the candidates, their min/argmin, the mask) except two per-image
-// scalars: the mean disparity (k_disp_mean runs first, as for the forward) and the smoothness
-// sum of the mean-normalisation term, which enters grad_disp as a per-image constant and is
-// subtracted by k_gdisp_shift afterwards.  The upstream gradient is taken as 1 (the caller
-// scales: the backward is linear in it).  The region evaluates the candidates of all its
-// 64x16 pixels (the 3x3 adjoint gather needs the argmin of the halo ring), so compared with
-// forward + backward kernels the warp, the staging and the target statistics happen once.
-// Only for a single source pair (S <= 2): more pairs would have to be warped twice.
-template <bool FUSED, int S, bool FB = false>
+template <bool FUSED, int S>
 __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
 {
-    static_assert(!FB || (FUSED && S <= 2), "FB needs the fused warp and a single source pair");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *tgtP = smem + BWD_TGT;
     f2 *pairP = reinterpret_cast<f2 *>(smem + BWD_PAIR);
@@ -880,16 +376,10 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
     const int n_id = automask ? (avg ? 1 : S) : 0;
 
     if (threadIdx.x == 0) {
-        float g = FB ? 1.0f : a.g_loss[0];
+        float g = a.g_loss[0];
         sh.gloss = g;
         sh.gpix = g / (float)((double)a.B * (double)N);
-        if (FB) {
-            float m = 0.0f;
-            for (int i = 0; i < NMEAN; ++i) m += a.mean_ws[b * NMEAN + i];
-            sh.den = m / (float)N + 1e-7f;
-        } else {
-            sh.den = a.stats[b * 4 + 1];
-        }
+        sh.den = a.stats[b * 4 + 1];
     }
     if (FUSED && threadIdx.x < 12 * S) {
         int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
@@ -911,30 +401,17 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         const int x = x0 + j;
         const bool in = rowin && (x >= 0) && (x < W);
         const size_t pi = (size_t)b * N + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-        sel[j] = (in && !FB) ? (int)a.argmin[pi] : 254;
+        sel[j] = in ? (int)a.argmin[pi] : 254;
         float m = (in && a.mask) ? a.mask[pi] : 1.0f;
         wbase[j] = in ? m : 0.0f;
     }
-    // FB: identity candidates of every region pixel, fetched with the target and the disparity
-    f2 vid[PX];
-    float mraw[PX];      // mask value (1 without a mask), 0 outside the image
-#pragma unroll
-    for (int j = 0; j < PX; ++j) { vid[j] = f2s(0.0f); mraw[j] = wbase[j]; }
-    if (FB && automask) {
-        const int kb0 = (S > 1) ? 1 : 0;
-        stage_first(tgtP, dispP, pairP, a.tgt + (size_t)b * 3 * N, a.disp + (size_t)b * N,
-                    a.src.p[0] + (size_t)b * 3 * N, a.src.p[kb0] + (size_t)b * 3 * N, N, H, W, py0, px0);
-    } else {
-        stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
-        stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
-    }
+    stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
+    stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
     for (int i = threadIdx.x; i < RPLANE; i += NT) gdP[i] = 0.0f;
     __syncthreads();
-    if (FB && automask) reproj4p(pairP, tgtP, off, no_ssim, vid);
     // base weight of every region pixel: gpix * mask (0 outside the image)
 #pragma unroll
     for (int j = 0; j < PX; ++j) wbase[j] = sh.gpix * wbase[j];
-    float fb_photo = 0.0f;
 
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
 
@@ -954,12 +431,9 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         if (FUSED) {
             load_pose_pair(sh, ka, kb, P2);
 #endif
-            // FB: the region's 62x14 interior owns its entries of the (optional) index maps
-            int32_t *ia = (FB && a.idx_xy) ? a.idx_xy + ((size_t)ka * a.B + b) * N * 2 : nullptr;
-            int32_t *ib = (FB && a.idx_xy) ? a.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
             warp_pair_into_lds<2>(pairP, dispP, a.src.p[ka] + (size_t)b * 3 * N,
                                   a.src.p[kb] + (size_t)b * 3 * N, a.invK + b * 16, P2, H, W, py0, px0,
-                               a.min_disp, a.range, a.eps, ia, ib, cy0 + 1, cx0 + 1, OH, OW);
+                               a.min_disp, a.range, a.eps, nullptr, nullptr, 0, 0);
         } else {
 #ifdef MVF_ABL_NOWARPB
             stage_pair3(pairP, a.src.p[ka] + (size_t)b * 3 * N, a.src.p[kb] + (size_t)b * 3 * N, N,
@@ -970,61 +444,6 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
 #endif
         }
         __syncthreads();
-
-        if (FB) {
-            // ---- the forward's candidates, min / argmin, mask (reference: train.py:1010-1043)
-            f2 vw[PX];
-            reproj4p(pairP, tgtP, off, no_ssim, vw);
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const int x = x0 + j, col = seg * PX + j;
-                const bool in = rowin && (x >= 0) && (x < W);
-                const size_t pix = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-                const size_t pi = (size_t)b * N + pix;
-                float best = 0.0f;
-                int bi = 0, nc = 0;
-                if (automask) {
-                    if (avg) {
-                        float m = vid[j].x;
-                        if (S > 1) m = m + vid[j].y;
-                        m = m / (float)S;
-                        best = m + (in ? a.noise[pi] : 0.0f) * 0.00001f;
-                        nc = 1;
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < S; ++k) {
-                            float v = (k == 0 ? vid[j].x : vid[j].y) +
-                                      (in ? a.noise[((size_t)b * S + k) * N + pix] : 0.0f) * 0.00001f;
-                            if (nc == 0 || v < best) { best = v; bi = nc; }
-                            ++nc;
-                        }
-                    }
-                }
-                if (avg) {
-                    float m = vw[j].x;
-                    if (S > 1) m = m + vw[j].y;
-                    m = m / (float)S;
-                    if (nc == 0 || m < best) { best = m; bi = nc; }
-                    ++nc;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < S; ++k) {
-                        float v = (k == 0) ? vw[j].x : vw[j].y;
-                        if (nc == 0 || v < best) { best = v; bi = nc; }
-                        ++nc;
-                    }
-                }
-                if (a.mask) best = best * mraw[j];
-                sel[j] = in ? ((nc > 1) ? bi : 255) : 254;
-                const bool outp = row_out && (col >= 1) && (col <= OW) && in;
-                if (outp) {
-                    if (a.argmin_out) a.argmin_out[pi] = (nc > 1) ? (uint8_t)bi : (uint8_t)255;
-                    if (a.auto_mask_out) a.auto_mask_out[pi] = (bi > n_id - 1) ? 1.0f : 0.0f;
-                    if (a.to_opt_out) a.to_opt_out[pi] = best;
-                    fb_photo += best;
-                }
-            }
-        }
 
         // selection weights of the two sources: the argmin picked it (or the averaged channel)
         f2 wk[PX];
@@ -1239,14 +658,11 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
         const float scale = sh.gloss * a.smoothness;
         const float cx = scale / (float)((double)a.B * H * (W - 1));
         const float cy = scale / (float)((double)a.B * (H - 1) * W);
-        // FB: the per-image smoothness sum is not known yet; its (per-image constant) term is
-        // subtracted afterwards by k_gdisp_shift -- x - 0 is exact, so the bits are the same
-        const float smooth_b = FB ? 0.0f : a.stats[b * 4 + 2] + a.stats[b * 4 + 3];
+        const float smooth_b = a.stats[b * 4 + 2] + a.stats[b * 4 + 3];
         // d/d disp_j of scale*smooth(disp/den): gn_j/den - (sum_i gn_i d_i)/(den^2 N); the sum is
         // den*scale*smooth_b because the per-image term is positively homogeneous of degree 1
         const float corr = scale * smooth_b / (float)N;
         const float rden = 1.0f / den, corr_den = corr / den;
-        float fb_sx = 0.0f, fb_sy = 0.0f;
 #pragma unroll 1
         for (int j = 0; j < PX; ++j) {
             const int x = x0 + j;
@@ -1267,42 +683,17 @@ __global__ void __launch_bounds__(NT, MVF_BWD_WAVES) k_photo_bwd(BwdArgs a)
             auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
 #ifndef MVF_ABL_NOSMOOTHB
             if (x + 1 < W) {
-                const float w1 = wgt(1);
-                gn += cx * w1 * sgn(nd - dc[1]);
-                // FB: the forward's edge-aware smoothness sums (reference: layers.py:231-242)
-                if (FB) fb_sx += fabsf(dc[0] / den - dc[1] / den) * w1;
+                gn += cx * wgt(1) * sgn(nd - dc[1]);
             }
             if (x - 1 >= 0) gn -= cx * wgt(-1) * sgn(dc[-1] - nd);
             if (y + 1 < H) {
-                const float wl = wgt(LDW);
-                gn += cy * wl * sgn(nd - dc[LDW]);
-                if (FB) fb_sy += fabsf(dc[0] / den - dc[LDW] / den) * wl;
+                gn += cy * wgt(LDW) * sgn(nd - dc[LDW]);
             }
             if (y - 1 >= 0) gn -= cy * wgt(-LDW) * sgn(dc[-LDW] - nd);
 #endif
             a.g_disp[(size_t)b * N + (size_t)y * W + x] = gdP[roff + j] + gn * rden - corr_den;
         }
-        if (FB) {
-            float *part = a.part + (((size_t)b * a.tiles_y + tid.by) * a.tiles_x + tid.bx) * NPART;
-            const float sums[4] = {fb_photo, fb_sx, fb_sy, 0.0f};
-            const float tot = block_sum_many<NT, 4>(sums, scratch);
-            if (threadIdx.x < 4) part[threadIdx.x] = tot;
-        }
     }
-}
-
-// FB epilogue: grad_disp[b, :] -= (smoothness * smooth_b / N) / den_b  (see k_photo_bwd<.., FB>)
-__global__ void __launch_bounds__(256) k_gdisp_shift(float *__restrict__ g_disp,
-                                                     const float *__restrict__ stats,
-                                                     float smoothness, int N)
-{
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
-    const float den = stats[b * 4 + 1];
-    const float smooth_b = stats[b * 4 + 2] + stats[b * 4 + 3];
-    const float corr = smoothness * smooth_b / (float)N;
-    g_disp[(size_t)b * N + i] -= corr / den;
 }
 
 // =============================================================================== standalone
@@ -1579,12 +970,6 @@ void launch_bwd_kernel(const BwdArgs &a, dim3 grid, hipStream_t st)
     }
 }
 
-void launch_fb_kernel(const BwdArgs &a, dim3 grid, hipStream_t st)
-{
-    if (a.S == 1) hipLaunchKernelGGL((k_photo_bwd<true, 1, true>), grid, dim3(NT), bwd_smem(), st, a);
-    else hipLaunchKernelGGL((k_photo_bwd<true, 2, true>), grid, dim3(NT), bwd_smem(), st, a);
-}
-
 int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *stats, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
@@ -1604,6 +989,14 @@ int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *sta
 }
 
 }  // namespace
+
+// shared with mvf_unit_fb.hip
+namespace mvf_photo {
+void launch_disp_mean(const float *disp, float *ws, int B, int N, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, ws, N);
+}
+}  // namespace mvf_photo
 
 // from mvf_geom.hip
 namespace mvf_geom {
@@ -1753,44 +1146,6 @@ int mvf_unit_bwd(const float *disp, const float *tgt, const float *const *src, c
         launch_bwd_kernel<true>(a, dim3((unsigned)(a.tiles_x * a.tiles_y * B)), (hipStream_t)stream);
     }
     return mvf_geom::finish_gT(workspace, K, g_T, B, S, a.tiles_x * a.tiles_y, stream);
-}
-
-int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
-                    const float *K, const float *inv_K, const float *noise, const float *mask_rec,
-                    int S, int flags, float smoothness, float min_disp, float range, float eps,
-                    float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
-                    int32_t *idx_xy, float *g_disp, float *g_T, float *workspace, int B, int H, int W,
-                    void *stream)
-{
-    if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
-    if (!g_disp || !g_T || !loss || !stats || !workspace) return (int)hipErrorInvalidValue;
-    if (B * H * W <= 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const int N = H * W;
-    BwdArgs a = {};
-    a.disp = disp; a.tgt = tgt; a.mask = mask_rec; a.T = T; a.K = K; a.invK = inv_K;
-    for (int k = 0; k < S; ++k) a.src.p[k] = src[k];
-    a.S = S; a.flags = flags; a.B = B; a.H = H; a.W = W;
-    a.tiles_x = (W + OW - 1) / OW; a.tiles_y = (H + OH - 1) / OH;
-    a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
-    const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
-    // workspace: [B*NMEAN] mean partials | [B*ntiles*NPART] loss partials | [S*B*ntiles*12] grad_P
-    a.mean_ws = workspace;
-    a.part = workspace + (size_t)B * NMEAN;
-    a.ws = a.part + (size_t)B * ntiles * NPART;
-    a.noise = noise; a.argmin_out = argmin; a.auto_mask_out = auto_mask; a.to_opt_out = to_opt;
-    a.idx_xy = idx_xy;
-    a.g_disp = g_disp;
-    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, workspace, N);
-    {
-        ProfScope ps(MVF_PROF_UNIT_FWDBWD, st);
-        launch_fb_kernel(a, dim3((unsigned)(ntiles * B)), st);
-    }
-    hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(1024), 0, st, workspace, loss, stats, B, H, W,
-                       (int)ntiles, smoothness, 1);
-    hipLaunchKernelGGL(k_gdisp_shift, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, st,
-                       g_disp, stats, smoothness, N);
-    return mvf_geom::finish_gT(a.ws, K, g_T, B, S, (int)ntiles, stream);
 }
 
 }  // extern "C"

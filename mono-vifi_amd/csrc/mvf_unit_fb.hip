@@ -1,0 +1,808 @@
+// mvf_unit_fb.hip -- forward AND backward of one hot-path unit in a single tile kernel
+// (mvf_unit_fwdbwd): S <= 2 x generate_images_pred (train.py:956-971) + compute_losses_base
+// (train.py:987-1051) + its whole adjoint down to grad_disp and grad_T.  This is the kernel the
+// training step runs nine times (train.py:747-883).
+//
+// In training both directions of a unit always run, and everything the backward needs from the
+// forward is per-pixel local -- the candidates, their min / argmin, the mask -- except two
+// per-image scalars: the mean disparity (k_disp_mean runs first) and the smoothness sum of the
+// mean-normalisation term, which enters grad_disp as a per-image constant and is applied by
+// mvf_unit_fwdbwd_scale together with the upstream gradient (the backward is linear in it).
+//
+// One workgroup (256 lanes, 4 px per lane) owns a 64x16 region and emits its 62x14 interior, so
+// the 3x3 (reflect-aware) SSIM adjoint never leaves the workgroup.  Phases:
+//   1  stage target, disparity and the identity pair (one memory phase, 35 loads per lane)
+//   2  identity candidates (SSIM + L1, packed for the pair)
+//   3  fused warp of the source pair into LDS: exact projection chain (guard-free divides),
+//      all taps of two plane positions in flight
+//   4  warped candidates: ONE pass over the window statistics yields the SSIM value AND its
+//      partial derivatives, which stay in registers (unweighted) until the argmin is known
+//   5  min / argmin / mask / outputs
+//   6  per channel: weighted coefficients -> LDS -> 3x3 adjoint gather -> grad_warped parked
+//      in the channel's (consumed) pair plane
+//   7  bilinear + projection adjoint per output pixel -> grad_disp, grad_P partials
+//   8  smoothness (value and gradient), store, ONE reduction of all 27 tile partials
+// Compiled with -ffp-contract=off (arithmetic contract in mvf_common.hpp): everything that
+// feeds an integer (sampling indices, argmin) follows the reference's evaluation order.
+#include "mvf_tile.hpp"
+
+namespace {
+
+constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a region
+constexpr int NRED = 27;                  // 24 grad_P + photo + smooth x + smooth y
+
+struct FbArgs {
+    const float *disp, *tgt, *mask, *T, *K, *invK, *noise, *mean_ws;
+    SrcPtrs src;
+    float *g_disp;        // [B,1,H,W] for an upstream gradient of 1, WITHOUT the per-image shift
+    float *gp_ws;         // [S][B][ntiles][12] grad_P partials
+    float *part;          // [B][ntiles][NPART] loss partials
+    uint8_t *argmin_out;
+    float *auto_mask_out, *to_opt_out, *noise_out;
+    int32_t *idx_xy;
+    int flags, B, H, W, tiles_x, tiles_y;
+    float smoothness, min_disp, range, eps;
+    uint32_t seed0, seed1;   // in-kernel tie-break noise (noise == nullptr)
+};
+
+// LDS carve (floats): target 3 planes | pair 3 f2 planes | disparity | coefficient 3 f2 region
+// planes (A,B,G) | pose | scratch
+constexpr int FB_TGT = 0, FB_PAIR = 3 * PLANE, FB_DISP = FB_PAIR + 6 * PLANE,
+              FB_COEF = FB_DISP + PLANE, FB_POSE = FB_COEF + 6 * RPLANE;
+constexpr int FB_SCRATCH = (NT / kWave) * NRED;
+inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(PoseLds) + FB_SCRATCH * sizeof(float); }
+
+// ---- counter-based tie-break noise ------------------------------------------------------
+// train.py:1023-1024 draws torch.randn(identity_reprojection_loss.shape) * 1e-5 per call.  With
+// noise == nullptr the kernel draws its own standard normals from a counter-based generator
+// keyed by (seed, element index): two rounds of a 32-bit avalanche hash per uniform, Box-Muller
+// for the pair of identity candidates of a pixel.  A tie-breaker, not a statistics engine; the
+// draw can be written out (noise_out) so that a test can replay it through the oracle.
+MVF_DEV uint32_t mix32(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= x >> 15; x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+MVF_DEV f2 normal_pair(uint32_t seed0, uint32_t seed1, uint32_t idx)
+{
+    const uint32_t a = mix32(idx * 2u + seed0), bq = mix32((idx * 2u + 1u) ^ seed1);
+    // u1 in (0,1], u2 in [0,1)
+    const float u1 = ((float)(a >> 8) + 1.0f) * 0x1p-24f, u2 = (float)(bq >> 8) * 0x1p-24f;
+    const float r = __builtin_sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.28318530717958647692f * u2, &sn, &cs);
+    return mk2(r * cs, r * sn);
+}
+
+// SSIM value (exact: reference layers.py:281-290, literal order) AND its x-side partial
+// derivatives (tolerance) from ONE set of window means of a candidate pair.
+MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val, f2 &dmux, f2 &dexx2,
+                                  f2 &dexy)
+{
+    f2 sigma_x = exx - mx * mx, sigma_y = eyy - my * my, sigma_xy = exy - mx * my;
+    f2 A1 = 2.0f * mx * my + f2s(kC1), A2 = 2.0f * sigma_xy + f2s(kC2);
+    f2 B1 = mx * mx + my * my + f2s(kC1), B2 = sigma_x + sigma_y + f2s(kC2);
+    f2 n = A1 * A2, d = B1 * B2;
+    // d >= C1*(C2 - rounding) > 0 and |n|, d = O(1) for images in [0,1]: the guard-free
+    // division core gives the correctly rounded quotient (see mvf_common.hpp)
+    const f2 r1 = recip_refined(d);
+    const f2 q = div_core(n, d, r1);
+    const f2 raw = (f2s(1.0f) - q) / 2.0f;
+    val = clamp01_pk(raw);
+    const f2 live = mk2((raw.x >= 0.0f && raw.x <= 1.0f) ? 1.0f : 0.0f,
+                        (raw.y >= 0.0f && raw.y <= 1.0f) ? 1.0f : 0.0f);
+    const f2 kn = -0.5f * r1 * live;        // d raw / d n
+    const f2 kd = -kn * q;                  // d raw / d d = 0.5 n / d^2
+    dmux = kn * (2.0f * my * (A2 - A1)) + kd * (2.0f * mx * (B2 - B1));
+    dexy = kn * 2.0f * A1;
+    dexx2 = kd * B1 * 2.0f;
+}
+
+// warp of the source pair into the pair planes: plane positions tid + k*NT, k < NSTAGE.  Full
+// iterations take U positions at a time (their divide chains interleave, all taps in flight);
+// the last position runs alone, and waves whose positions all lie beyond the plane skip it.
+struct WarpCtx {
+    f2 *pairP;
+    const float *dispP, *sa, *sb, *iK;
+    const f2 *P2;
+    int H, W, py0, px0, oy0, ox0;
+    float min_disp, range, eps;
+    int32_t *idx_a, *idx_b;
+};
+
+template <int U>
+MVF_DEV void warp_slots(const WarpCtx &k, int slot0)
+{
+    const size_t N = (size_t)k.H * k.W;
+    WarpSlot s[U];
+    float a[U][3][4], bq[U][3][4];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        s[u] = warp_slot((int)threadIdx.x + (slot0 + u) * NT, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0,
+                         k.min_disp, k.range, k.eps);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            load_taps(k.sa + ch * N, s[u].qa.q, a[u][ch][0], a[u][ch][1], a[u][ch][2], a[u][ch][3]);
+            load_taps(k.sb + ch * N, s[u].qb.q, bq[u][ch][0], bq[u][ch][1], bq[u][ch][2], bq[u][ch][3]);
+        }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (!s[u].live) continue;
+        const Taps4 &qa = s[u].qa, &qb = s[u].qb;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            float va = a[u][ch][0] * qa.wnw + a[u][ch][1] * qa.wne + a[u][ch][2] * qa.wsw +
+                       a[u][ch][3] * qa.wse;
+            float vb = bq[u][ch][0] * qb.wnw + bq[u][ch][1] * qb.wne + bq[u][ch][2] * qb.wsw +
+                       bq[u][ch][3] * qb.wse;
+            k.pairP[ch * PPLANE + s[u].r * LDW + s[u].c] = mk2(va, vb);
+        }
+        if (k.idx_a) {
+            // the region's 62x14 interior owns its entries of the (optional) index maps
+            int y = k.py0 + s[u].r, x = k.px0 + s[u].c;
+            if (y >= k.oy0 && y < min(k.oy0 + OH, k.H) && x >= k.ox0 && x < min(k.ox0 + OW, k.W)) {
+                reinterpret_cast<int2 *>(k.idx_a)[(size_t)y * k.W + x] = make_int2(s[u].x0a, s[u].y0a);
+                if (k.idx_b != k.idx_a)
+                    reinterpret_cast<int2 *>(k.idx_b)[(size_t)y * k.W + x] = make_int2(s[u].x0b, s[u].y0b);
+            }
+        }
+    }
+}
+
+MVF_DEV void warp_pair_into_lds_fb(const WarpCtx &k)
+{
+#ifndef MVF_FB_WARP_U
+#define MVF_FB_WARP_U 2
+#endif
+    constexpr int U = MVF_FB_WARP_U;
+    constexpr int NFULL = NSTAGE / U;             // 2 iterations of 2 positions
+#pragma unroll 1
+    for (int it = 0; it < NFULL; ++it) warp_slots<U>(k, U * it);
+#pragma unroll
+    for (int q = NFULL * U; q < NSTAGE; ++q) {
+        // wave-uniform: the first lane of this wave is already beyond the plane
+        const int first = ((int)threadIdx.x & ~(kWave - 1)) + q * NT;
+        if (first < PH * PW) warp_slots<1>(k, q);
+    }
+}
+
+// =============================================================================== the kernel
+template <int S, bool AVG>     // AVG: --avg_reprojection (both sources carry gradient)
+__global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
+{
+    static_assert(S == 1 || S == 2, "one source pair");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *tgtP = smem + FB_TGT;
+    f2 *pairP = reinterpret_cast<f2 *>(smem + FB_PAIR);
+    float *dispP = smem + FB_DISP;
+    f2 *coefP = reinterpret_cast<f2 *>(smem + FB_COEF);
+    PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + FB_POSE);
+    float *scratch = smem + FB_POSE + sizeof(PoseLds) / 4;
+
+    const TileId tid = tile_of_block(a.tiles_x, a.tiles_y, a.B);
+    const int H = a.H, W = a.W, b = tid.b;
+    const size_t N = (size_t)H * W;
+    const int cy0 = tid.by * OH - 1, cx0 = tid.bx * OW - 1;   // region origin
+    const int py0 = cy0 - 1, px0 = cx0 - 1;                   // plane origin
+    const bool no_ssim = a.flags & MVF_NO_SSIM;
+    constexpr bool avg = AVG;
+    const bool automask = !(a.flags & MVF_NO_AUTOMASK);
+    const int n_id = automask ? (avg ? 1 : S) : 0;
+    constexpr bool hasb = S > 1;
+    constexpr int kb = hasb ? 1 : 0;
+
+    if (threadIdx.x == 0) {
+        float m = 0.0f;
+        for (int i = 0; i < NMEAN; ++i) m += a.mean_ws[b * NMEAN + i];
+        sh.den = m / (float)N + 1e-7f;
+        sh.gpix = 1.0f / (float)((double)a.B * (double)N);
+    }
+    if (threadIdx.x < 12 * S) {
+        int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
+        sh.P[k][e] = proj_entry(a.K + b * 16, a.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
+    }
+    const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
+    const int off = row * LDW + seg * PX;     // plane element of the window's top-left
+    const int roff = off;                     // region-plane element of this lane's first pixel
+    const int y = cy0 + row, x0 = cx0 + seg * PX;
+    const bool rowin = (y >= 0) && (y < H);
+    const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
+
+    // mask and tie-break noise of this lane's region pixels: in flight with the plane loads
+    float mraw[PX];            // mask value (1 without a mask), 0 outside the image
+    f2 nz[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int x = x0 + j;
+        const bool in = rowin && (x >= 0) && (x < W);
+        const size_t pix = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        const size_t pi = (size_t)b * N + pix;
+        mraw[j] = in ? ((a.mask) ? a.mask[pi] : 1.0f) : 0.0f;
+        nz[j] = f2s(0.0f);
+        if (automask && in) {
+            if (a.noise) {
+                if (avg) nz[j] = f2s(a.noise[pi]);
+                else nz[j] = mk2(a.noise[((size_t)b * S) * N + pix], hasb ? a.noise[((size_t)b * S + 1) * N + pix] : 0.0f);
+            } else {
+                nz[j] = normal_pair(a.seed0, a.seed1, (uint32_t)pi);
+                if (a.noise_out) {
+                    if (avg) a.noise_out[pi] = nz[j].x;
+                    else {
+                        a.noise_out[((size_t)b * S) * N + pix] = nz[j].x;
+                        if (hasb) a.noise_out[((size_t)b * S + 1) * N + pix] = nz[j].y;
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- 1: target, disparity (and the identity pair) -> LDS
+    if (automask) {
+        stage_first(tgtP, dispP, pairP, a.tgt + (size_t)b * 3 * N, a.disp + (size_t)b * N,
+                    a.src.p[0] + (size_t)b * 3 * N, a.src.p[kb] + (size_t)b * 3 * N, N, H, W, py0, px0);
+    } else {
+        stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
+        stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
+    }
+    __syncthreads();
+
+    // ---- 2: identity candidates of every region pixel
+    f2 vid[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) vid[j] = f2s(0.0f);
+    if (automask) {
+#ifndef MVF_ABL_NOID     // timing ablation: identity candidates not evaluated
+        reproj4p(pairP, tgtP, off, no_ssim, vid);
+#else
+        for (int j = 0; j < PX; ++j) vid[j] = pairP[off + LDW + 1 + j];
+#endif
+        __syncthreads();                       // identity pair consumed
+    }
+
+    // ---- 3: fused warp of the source pair
+    f2 P2[12];
+    load_pose_pair(sh, 0, kb, P2);
+    {
+        WarpCtx k;
+        k.pairP = pairP; k.dispP = dispP;
+        k.sa = a.src.p[0] + (size_t)b * 3 * N; k.sb = a.src.p[kb] + (size_t)b * 3 * N;
+        k.iK = a.invK + b * 16; k.P2 = P2;
+        k.H = H; k.W = W; k.py0 = py0; k.px0 = px0; k.oy0 = cy0 + 1; k.ox0 = cx0 + 1;
+        k.min_disp = a.min_disp; k.range = a.range; k.eps = a.eps;
+        k.idx_a = a.idx_xy ? a.idx_xy + ((size_t)b) * N * 2 : nullptr;
+        k.idx_b = a.idx_xy ? a.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
+#ifdef MVF_ABL_NOWARP    // timing ablation: the raw sources instead of the warped pair
+        stage_pair3(pairP, k.sa, k.sb, N, H, W, py0, px0);
+#else
+        warp_pair_into_lds_fb(k);
+#endif
+    }
+    __syncthreads();
+
+    // ---- 4: warped candidates; SSIM partials of the three channels stay in registers.
+    // The channel loop is rolled (code size); the partials rotate through three static slots:
+    // after the loop slot 2 holds channel 0, slot 1 channel 1, slot 0 channel 2.
+    f2 pm[3][PX], px2[3][PX], pg[3][PX];      // d/d mu_x, 2 d/d E[xx], d/d E[xy]
+    f2 vw[PX];
+    {
+        f2 ab[PX], ss[PX];
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            ab[j] = ss[j] = f2s(0.0f);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) pm[q][j] = px2[q][j] = pg[q][j] = f2s(0.0f);
+        }
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                pm[2][j] = pm[1][j]; px2[2][j] = px2[1][j]; pg[2][j] = pg[1][j];
+                pm[1][j] = pm[0][j]; px2[1][j] = px2[0][j]; pg[1][j] = pg[0][j];
+            }
+#ifdef MVF_ABL_NOSSIM4
+            if (true) {
+#else
+            if (no_ssim) {
+#endif
+                Row6P x = load_row6p(pairP + c * PPLANE + off + LDW);
+                Row6 yv = load_row6(tgtP + c * PLANE + off + LDW);
+#pragma unroll
+                for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(yv.v[j + 1]) - x.v[j + 1]);
+            } else {
+                Stats4P s;
+                window_xp(pairP + c * PPLANE + off, tgtP + c * PLANE + off, s);
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    f2 my = div9(s.sy[j]);     // (mu_y, E[y*y])
+                    f2 val;
+                    ssim_val_partials_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
+                                         div9(s.sxy[j]), val, pm[0][j], px2[0][j], pg[0][j]);
+                    ss[j] = ss[j] + val;
+                    ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            f2 l1 = div3(ab[j]);
+            vw[j] = no_ssim ? l1 : 0.85f * div3(ss[j]) + 0.15f * l1;
+        }
+    }
+
+    // ---- 5: min / argmin / mask / outputs (reference: train.py:1010-1043)
+    f2 wk[PX];                 // adjoint weight of the two warped candidates
+    float fb_photo = 0.0f;
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int x = x0 + j, col = seg * PX + j;
+        const bool in = rowin && (x >= 0) && (x < W);
+        const size_t pi = (size_t)b * N + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        float best = 0.0f;
+        int bi = 0, nc = 0;
+        if (automask) {
+            if (avg) {
+                float m = vid[j].x;
+                if (hasb) m = m + vid[j].y;
+                m = m / (float)S;
+                best = m + nz[j].x * 0.00001f;
+                nc = 1;
+            } else {
+#pragma unroll
+                for (int k = 0; k < S; ++k) {
+                    float v = (k == 0 ? vid[j].x : vid[j].y) + (k == 0 ? nz[j].x : nz[j].y) * 0.00001f;
+                    if (nc == 0 || v < best) { best = v; bi = nc; }
+                    ++nc;
+                }
+            }
+        }
+        if (avg) {
+            float m = vw[j].x;
+            if (hasb) m = m + vw[j].y;
+            m = m / (float)S;
+            if (nc == 0 || m < best) { best = m; bi = nc; }
+            ++nc;
+        } else {
+#pragma unroll
+            for (int k = 0; k < S; ++k) {
+                float v = (k == 0) ? vw[j].x : vw[j].y;
+                if (nc == 0 || v < best) { best = v; bi = nc; }
+                ++nc;
+            }
+        }
+        if (a.mask) best = best * mraw[j];
+        const int sel = (nc > 1) ? bi : 255;
+        const bool outp = row_out && (col >= 1) && (col <= OW) && in;
+        if (outp) {
+            if (a.argmin_out) a.argmin_out[pi] = (uint8_t)sel;
+            if (a.auto_mask_out) a.auto_mask_out[pi] = (bi > n_id - 1) ? 1.0f : 0.0f;
+            if (a.to_opt_out) a.to_opt_out[pi] = best;
+            fb_photo += best;
+        }
+        // selection weight of the two sources: the argmin picked it (or the averaged channel)
+        float wa, wb;
+        if (sel == 255) wa = wb = avg ? 1.0f / (float)S : 1.0f;        // single candidate
+        else if (avg) wa = wb = (sel == n_id) ? 1.0f / (float)S : 0.0f;
+        else { wa = (sel == n_id) ? 1.0f : 0.0f; wb = (sel == n_id + 1) ? 1.0f : 0.0f; }
+        const float wbase = sh.gpix * mraw[j];                         // 0 outside the image
+        wk[j] = mk2(wbase * wa, hasb ? wbase * wb : 0.0f);
+    }
+
+    // ---- 6: SSIM adjoint, one channel at a time through the coefficient planes.
+    // g_x(q) = sum over the 3x3 windows p around q of A(p) + x(q) B(p) + y(q) G(p).  The
+    // horizontal 3-sums are formed in registers before the LDS round trip: a lane owns 4
+    // consecutive columns, the two missing neighbours come from lanes seg-1 / seg+1 of the same
+    // 16-lane row by DPP row shifts (zero-filled at the row ends: columns -1 and 64 do not exist
+    // and would only reach region columns 0 and 63, which are never outputs).  The planes then
+    // hold row sums, and the vertical step reads two rows instead of nine row segments.
+    // Reflect-pad multiplicities only exist next to the image border (rows 1, H-2, cols 1, W-2).
+    const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
+    float mlx[PX], mrx[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        mlx[j] = (x0 + j == 1) ? 2.0f : 1.0f;
+        mrx[j] = (x0 + j == W - 2) ? 2.0f : 1.0f;
+    }
+    const bool col_border = (cx0 <= 1) || (cx0 + TW >= W - 1);          // workgroup-uniform
+    // DPP row shifts inside the 16-lane rows (= the 16 column segments of a region row).  The empty
+    // asm pins each 32-bit move: without it hipcc 7.2 folds the two halves of a pair into ONE move
+    // and broadcasts it (observed in the ISA: v_mov_b32_dpp + op_sel_hi:[0,1]).
+    auto dpp1 = [](float v, bool right) {
+        int r = right ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x101, 0xf, 0xf, true)
+                      : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x111, 0xf, 0xf, true);
+        asm volatile("" : "+v"(r));
+        return __builtin_bit_cast(float, r);
+    };
+    auto from_left = [&](f2 v) { return mk2(dpp1(v.x, false), dpp1(v.y, false)); };    // lane seg-1 (0 at seg 0)
+    auto from_right = [&](f2 v) { return mk2(dpp1(v.x, true), dpp1(v.y, true)); };     // lane seg+1 (0 at seg 15)
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        f2 hs[3][PX];              // row sums of A, B, G at this lane's 4 columns
+        if (!no_ssim) {
+            if (c > 0) __syncthreads();        // vertical reads of the previous channel done
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                f2 cf[PX + 2];
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    // slot 2 holds the current channel; the slots rotate down below
+                    const f2 g = wk[j] * ((0.85f / 3.0f) / 9.0f);
+                    cf[j + 1] = g * (pl == 0 ? pm[2][j] : (pl == 1 ? px2[2][j] : pg[2][j]));
+                }
+                cf[0] = from_left(cf[PX]);
+                cf[PX + 1] = from_right(cf[1]);
+                if (col_border) {
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) hs[pl][j] = mlx[j] * cf[j] + cf[j + 1] + mrx[j] * cf[j + 2];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) hs[pl][j] = (cf[j] + cf[j + 1]) + cf[j + 2];
+                }
+                float4 *cp = reinterpret_cast<float4 *>(coefP + pl * RPPLANE + roff);
+                cp[0] = make_float4(hs[pl][0].x, hs[pl][0].y, hs[pl][1].x, hs[pl][1].y);
+                cp[1] = make_float4(hs[pl][2].x, hs[pl][2].y, hs[pl][3].x, hs[pl][3].y);
+            }
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                pm[2][j] = pm[1][j]; px2[2][j] = px2[1][j]; pg[2][j] = pg[1][j];
+                pm[1][j] = pm[0][j]; px2[1][j] = px2[0][j]; pg[1][j] = pg[0][j];
+            }
+            __syncthreads();
+        }
+        // own centre values (the pair plane of this channel is only read by its owner from now on)
+        f2 xq[PX], gw[PX];
+        float yq[PX];
+        {
+            const f2 *xc = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
+            const float *yc = tgtP + c * PLANE + (row + 1) * LDW + seg * PX + 1;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) { xq[j] = xc[j]; yq[j] = yc[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            // L1 term: d|t-p|/dp = -sign(t-p), channel mean
+            f2 df = f2s(yq[j]) - xq[j];
+            f2 sg = mk2((df.x > 0.0f) ? -1.0f : ((df.x < 0.0f) ? 1.0f : 0.0f),
+                        (df.y > 0.0f) ? -1.0f : ((df.y < 0.0f) ? 1.0f : 0.0f));
+            gw[j] = wk[j] * (no_ssim ? 1.0f : 0.15f) * sg / 3.0f;
+        }
+#ifdef MVF_ABL_NOGATHER
+        if (false) {
+#else
+        if (!no_ssim && row >= 1 && row <= OH) {
+#endif
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                const float4 *up = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff - LDW);
+                const float4 *dn = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff + LDW);
+                const float4 u0 = up[0], u1 = up[1], d0 = dn[0], d1 = dn[1];
+                const f2 uu[PX] = {mk2(u0.x, u0.y), mk2(u0.z, u0.w), mk2(u1.x, u1.y), mk2(u1.z, u1.w)};
+                const f2 dd[PX] = {mk2(d0.x, d0.y), mk2(d0.z, d0.w), mk2(d1.x, d1.y), mk2(d1.z, d1.w)};
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const f2 t = myu * uu[j] + hs[pl][j] + myd * dd[j];
+                    if (pl == 0) gw[j] += t;
+                    else if (pl == 1) gw[j] += xq[j] * t;
+                    else gw[j] += f2s(yq[j]) * t;
+                }
+            }
+        }
+        // park grad_warped of this channel in its own pair plane (own 4 entries only)
+        {
+            f2 *gp = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
+#pragma unroll
+            for (int j = 0; j < PX; ++j) gp[j] = gw[j];
+        }
+    }
+    __syncthreads();      // every grad_warped is parked
+
+    // ---- 7 + 8: bilinear + projection adjoint, smoothness value + gradient, store grad_disp.
+    // Lanes now walk the region linearly (position p = tid + k*256, 64 per row): neighbouring
+    // lanes handle neighbouring pixels, so the bilinear taps of a wave fall into a few cache
+    // lines (with the owner mapping a wave's taps were 4 pixels apart per lane).
+    load_pose_pair(sh, 0, kb, P2);
+    const float *sa = a.src.p[0] + (size_t)b * 3 * N, *sb = a.src.p[kb] + (size_t)b * 3 * N;
+    f2 accP[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) accP[q] = f2s(0.0f);
+    float fb_sx = 0.0f, fb_sy = 0.0f;
+    const float rden = 1.0f / sh.den;
+    const float cxs = a.smoothness / (float)((double)a.B * H * (W - 1));
+    const float cys = a.smoothness / (float)((double)a.B * (H - 1) * W);
+#ifndef MVF_FB_UNROLL7
+#define MVF_FB_UNROLL7 4
+#endif
+#pragma unroll MVF_FB_UNROLL7
+    for (int k = 0; k < (TW * TH) / NT; ++k) {
+        const int p = (int)threadIdx.x + k * NT;
+        const int r = p / TW, cc = p - r * TW;
+        const int yy = cy0 + r, xx = cx0 + cc;
+        const bool outp = (r >= 1) && (r <= OH) && (cc >= 1) && (cc <= OW) && (yy < H) && (xx < W);
+        if (!outp) continue;       // yy, xx >= 0 for interior positions
+        const int e = (r + 1) * LDW + cc + 1;
+        float gdp = 0.0f;
+#ifdef MVF_ABL_NO7      // timing ablation: no bilinear / projection adjoint
+        gdp = pairP[e].x;
+#else
+        const f2 g0 = pairP[e], g1 = pairP[PPLANE + e], g2 = pairP[2 * PPLANE + e];
+        // grad_warped of a source is non-zero wherever ANY window of the pixel's 3x3 neighbourhood
+        // selected it, so both sources are usually live; pixels deep inside auto-masked areas
+        // (every neighbour won by an identity candidate) fetch no taps at all
+        const bool live = (g0.x != 0.0f) || (g1.x != 0.0f) || (g2.x != 0.0f) ||
+                          (hasb && ((g0.y != 0.0f) || (g1.y != 0.0f) || (g2.y != 0.0f)));
+        if (live) {
+            // the exact chain again: the taps must be the forward's (a flipped cell would flip the
+            // bilinear gradient)
+            const WarpPair w = warp_point_pair(dispP[e], a.invK + b * 16, P2, xx, yy, H, W, a.min_disp,
+                                               a.range, a.eps);
+            float dxa[3], dya[3], dxb[3], dyb[3];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                bilerp_grad(sa + ch * N, W, w.ta, dxa[ch], dya[ch]);
+                bilerp_grad(sb + ch * N, W, w.tb, dxb[ch], dyb[ch]);
+            }
+            const f2 gix = g0 * mk2(dxa[0], dxb[0]) + g1 * mk2(dxa[1], dxb[1]) + g2 * mk2(dxa[2], dxb[2]);
+            const f2 giy = g0 * mk2(dya[0], dyb[0]) + g1 * mk2(dya[1], dyb[1]) + g2 * mk2(dya[2], dyb[2]);
+            // adjoint of unnormalise / normalise ((W-1)/2 * 2/(W-1) = 1) and of the perspective
+            // divide; tolerance arithmetic: one reciprocal of z per source (see warp_point_bwd)
+            const f2 gu = mk2(w.ta.inx ? gix.x : 0.0f, w.tb.inx ? gix.y : 0.0f);
+            const f2 gv = mk2(w.ta.iny ? giy.x : 0.0f, w.tb.iny ? giy.y : 0.0f);
+            const f2 rz = mk2(__builtin_amdgcn_rcpf(w.z.x), __builtin_amdgcn_rcpf(w.z.y));
+            f2 gc[3];
+            gc[0] = gu * rz;
+            gc[1] = gv * rz;
+            gc[2] = -(gc[0] * w.u + gc[1] * w.v);
+            f2 gd = f2s(0.0f);
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                f2 gX = gc[0] * P2[0 * 4 + jj] + gc[1] * P2[1 * 4 + jj] + gc[2] * P2[2 * 4 + jj];
+                gd += gX * w.r[jj];
+            }
+            gdp = -(hasb ? gd.x + gd.y : gd.x) * w.depth * w.depth * a.range;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                accP[q * 4 + 0] += gc[q] * w.X[0];
+                accP[q * 4 + 1] += gc[q] * w.X[1];
+                accP[q * 4 + 2] += gc[q] * w.X[2];
+                accP[q * 4 + 3] += gc[q];
+            }
+        }
+#endif
+        // smoothness: d/d disp_j of s*smooth(disp/den) = gn_j/den - (per-image constant); the
+        // constant needs the per-image smoothness sum and is applied by mvf_unit_fwdbwd_scale.
+        const float *dc = dispP + e;
+        const float *t0 = tgtP + e;
+        auto wgt = [&](int o) {
+            float gi = div3((fabsf(t0[0] - t0[o]) + fabsf(t0[PLANE] - t0[PLANE + o])) +
+                            fabsf(t0[2 * PLANE] - t0[2 * PLANE + o]));
+            return __expf(-gi);
+        };
+        auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
+        // only the SIGN of differences of normalised disparities is needed for the gradient:
+        // dividing by the positive per-image constant cannot change it
+        const float nd = dc[0];
+        float gn = 0.0f;
+#ifndef MVF_ABL_NOSMOOTH
+        if (xx + 1 < W) {
+            const float w1 = wgt(1), df = nd - dc[1];
+            gn += cxs * w1 * sgn(df);
+            fb_sx += fabsf(df) * rden * w1;
+        }
+        if (xx - 1 >= 0) gn -= cxs * wgt(-1) * sgn(dc[-1] - nd);
+        if (yy + 1 < H) {
+            const float wl = wgt(LDW), df = nd - dc[LDW];
+            gn += cys * wl * sgn(df);
+            fb_sy += fabsf(df) * rden * wl;
+        }
+        if (yy - 1 >= 0) gn -= cys * wgt(-LDW) * sgn(dc[-LDW] - nd);
+#endif
+        a.g_disp[(size_t)b * N + (size_t)yy * W + xx] = gdp + gn * rden;
+    }
+
+    // ---- one reduction for all tile partials: grad_P of both sources, photo, smoothness sums
+    {
+        const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
+        const size_t tile = (size_t)tid.by * a.tiles_x + tid.bx;
+        float flat[NRED];
+#pragma unroll
+        for (int q = 0; q < 12; ++q) { flat[q] = accP[q].x; flat[12 + q] = accP[q].y; }
+        flat[24] = fb_photo; flat[25] = fb_sx; flat[26] = fb_sy;
+        const float tot = block_sum_many<NT, NRED>(flat, scratch);
+        const int t = threadIdx.x;
+        if (t < 12) a.gp_ws[(((size_t)b) * ntiles + tile) * 12 + t] = tot;
+        else if (t < 24) { if (hasb) a.gp_ws[(((size_t)kb * a.B + b) * ntiles + tile) * 12 + t - 12] = tot; }
+        else if (t < NRED) a.part[((size_t)b * ntiles + tile) * NPART + (t - 24)] = tot;
+    }
+}
+
+// ---- finishing kernel: loss[3], stats[B,4], grad_T -- one launch -------------------------------
+// block b < B*S : grad_T of (source s, image b) = K^T [grad_P ; 0], tile partials folded in fp64
+// block B*S     : loss[0..2] and stats[B][4] = {mean, den, sx_b, sy_b}
+__global__ void __launch_bounds__(256) k_fb_finish(const float *__restrict__ mean_ws,
+                                                   const float *__restrict__ part,
+                                                   const float *__restrict__ gp_ws,
+                                                   const float *__restrict__ K, float *__restrict__ loss,
+                                                   float *__restrict__ stats, float *__restrict__ gT,
+                                                   int B, int S, int H, int W, int ntiles, float smoothness)
+{
+    __shared__ double sh[4][12];
+    __shared__ double gP[12];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    if ((int)blockIdx.x < B * S) {
+        const int s = blockIdx.x / B, b = blockIdx.x - s * B;
+        const float *w = gp_ws + ((size_t)s * B + b) * ntiles * 12;
+        double acc[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc[k] = 0.0;
+        for (int t = threadIdx.x; t < ntiles; t += 256)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc[k] += (double)w[(size_t)t * 12 + k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            double v = acc[k];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0) sh[wid][k] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 12) gP[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) +
+                                                 (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+        __syncthreads();
+        if (threadIdx.x < 16) {
+            const int k = threadIdx.x >> 2, j = threadIdx.x & 3;
+            const float *Kb = K + b * 16;
+            double v = 0.0;
+            for (int q = 0; q < 3; ++q) v += (double)Kb[q * 4 + k] * gP[q * 4 + j];
+            gT[((size_t)s * B + b) * 16 + threadIdx.x] = (float)v;
+        }
+        return;
+    }
+    // loss / stats block: one wave per image, 4 images per pass, images folded in index order
+    __shared__ double shp[4], shs[4];
+    __shared__ double acc_photo, acc_smooth;
+    const double N = (double)H * W;
+    if (threadIdx.x == 0) { acc_photo = 0.0; acc_smooth = 0.0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 4) {
+        const int b = b0 + wid;
+        if (b < B) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int t = lane; t < ntiles; t += 64) {
+                const float *q = part + ((size_t)b * ntiles + t) * NPART;
+                a0 += (double)q[0]; a1 += (double)q[1]; a2 += (double)q[2];
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                a0 += __shfl_down(a0, off, 64);
+                a1 += __shfl_down(a1, off, 64);
+                a2 += __shfl_down(a2, off, 64);
+            }
+            if (lane == 0) {
+                const double sxb = a1 / ((double)B * H * (W - 1)), syb = a2 / ((double)B * (H - 1) * W);
+                shp[wid] = a0;
+                shs[wid] = sxb + syb;
+                float m = 0.0f;
+                for (int i = 0; i < NMEAN; ++i) m += mean_ws[b * NMEAN + i];
+                const float mean = m / (float)N;
+                stats[b * 4 + 0] = mean;
+                stats[b * 4 + 1] = mean + 1e-7f;
+                stats[b * 4 + 2] = (float)sxb;
+                stats[b * 4 + 3] = (float)syb;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 4 && b0 + i < B; ++i) { acc_photo += shp[i]; acc_smooth += shs[i]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double pm = acc_photo / ((double)B * N);
+        loss[0] = (float)(pm + (double)smoothness * acc_smooth);
+        loss[1] = (float)pm;
+        loss[2] = (float)acc_smooth;
+    }
+}
+
+// backward(): out = (raw - shift_b) * g_loss for grad_disp, g_T_raw * g_loss for grad_T.
+// shift_b = (smoothness * smooth_b / N) / den_b is the mean-normalisation term of the smoothness
+// gradient; (x - s) * g in this order reproduces the bits of the two-kernel path for g = 1.
+__global__ void __launch_bounds__(256) k_fb_scale(const float *__restrict__ g_raw,
+                                                  const float *__restrict__ gT_raw,
+                                                  const float *__restrict__ stats,
+                                                  const float *__restrict__ g_loss, float smoothness,
+                                                  float *__restrict__ g_disp, float *__restrict__ gT,
+                                                  int N4, int N, int nT)
+{
+    const float g = g_loss[0];
+    if (blockIdx.y == gridDim.y - 1) {            // the extra row of blocks scales grad_T
+        const int i = blockIdx.x * 256 + threadIdx.x;
+        if (i < nT) gT[i] = gT_raw[i] * g;
+        return;
+    }
+    const int b = blockIdx.y;
+    const float den = stats[b * 4 + 1];
+    const float smooth_b = stats[b * 4 + 2] + stats[b * 4 + 3];
+    const float shift = (smoothness * smooth_b / (float)N) / den;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < N4) {
+        const float4 v = reinterpret_cast<const float4 *>(g_raw + (size_t)b * N)[i];
+        reinterpret_cast<float4 *>(g_disp + (size_t)b * N)[i] =
+            make_float4((v.x - shift) * g, (v.y - shift) * g, (v.z - shift) * g, (v.w - shift) * g);
+    } else {
+        for (int k = 4 * i; k < N && k < 4 * i + 4; ++k)
+            if (k >= 4 * N4) g_disp[(size_t)b * N + k] = (g_raw[(size_t)b * N + k] - shift) * g;
+    }
+}
+
+}  // namespace
+
+// per-image mean partials of the disparity (mvf_photo.hip)
+namespace mvf_photo {
+void launch_disp_mean(const float *disp, float *ws, int B, int N, hipStream_t st);
+}
+
+extern "C" {
+
+int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
+                    const float *K, const float *inv_K, const float *noise, const float *mask_rec,
+                    int S, int flags, float smoothness, float min_disp, float range, float eps,
+                    float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
+                    int32_t *idx_xy, float *g_disp, float *g_T, float *workspace, int B, int H, int W,
+                    uint64_t noise_seed, float *noise_out, void *stream)
+{
+    if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
+    if (!g_disp || !g_T || !loss || !stats || !workspace) return (int)hipErrorInvalidValue;
+    if (B * H * W <= 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = H * W;
+    FbArgs a = {};
+    a.disp = disp; a.tgt = tgt; a.mask = mask_rec; a.T = T; a.K = K; a.invK = inv_K;
+    for (int k = 0; k < S; ++k) a.src.p[k] = src[k];
+    a.flags = flags; a.B = B; a.H = H; a.W = W;
+    a.tiles_x = (W + OW - 1) / OW; a.tiles_y = (H + OH - 1) / OH;
+    a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
+    const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
+    // workspace: [B*NMEAN] mean partials | [B*ntiles*NPART] loss partials | [S*B*ntiles*12] grad_P
+    a.mean_ws = workspace;
+    a.part = workspace + (size_t)B * NMEAN;
+    a.gp_ws = a.part + (size_t)B * ntiles * NPART;
+    a.noise = noise; a.argmin_out = argmin; a.auto_mask_out = auto_mask; a.to_opt_out = to_opt;
+    a.noise_out = noise_out;
+    a.seed0 = (uint32_t)noise_seed; a.seed1 = (uint32_t)(noise_seed >> 32);
+    a.idx_xy = idx_xy;
+    a.g_disp = g_disp;
+    mvf_photo::launch_disp_mean(disp, workspace, B, N, st);
+    {
+        ProfScope ps(MVF_PROF_UNIT_FWDBWD, st);
+        const dim3 grid((unsigned)(ntiles * B));
+        const bool avg = flags & MVF_AVG_REPROJ;
+        if (S == 1 && !avg) hipLaunchKernelGGL((k_unit_fb<1, false>), grid, dim3(NT), fb_smem(), st, a);
+        else if (S == 1) hipLaunchKernelGGL((k_unit_fb<1, true>), grid, dim3(NT), fb_smem(), st, a);
+        else if (!avg) hipLaunchKernelGGL((k_unit_fb<2, false>), grid, dim3(NT), fb_smem(), st, a);
+        else hipLaunchKernelGGL((k_unit_fb<2, true>), grid, dim3(NT), fb_smem(), st, a);
+    }
+    hipLaunchKernelGGL(k_fb_finish, dim3((unsigned)(B * S + 1)), dim3(256), 0, st, a.mean_ws, a.part,
+                       a.gp_ws, K, loss, stats, g_T, B, S, H, W, (int)ntiles, smoothness);
+    return hip_check_launch();
+}
+
+int mvf_unit_fwdbwd_scale(const float *g_disp_raw, const float *g_T_raw, const float *stats,
+                          const float *g_loss, float smoothness, float *g_disp, float *g_T, int B,
+                          int S, int H, int W, void *stream)
+{
+    if (B * H * W <= 0) return 0;
+    if (!g_disp_raw || !g_T_raw || !stats || !g_loss || !g_disp || !g_T) return (int)hipErrorInvalidValue;
+    const int N = H * W;
+    // float4 path needs 16-B aligned image rows: N % 4 == 0 and aligned bases, else scalar
+    const bool vec = (N % 4 == 0) && ((((uintptr_t)g_disp_raw) | ((uintptr_t)g_disp)) % 16 == 0);
+    const int N4 = vec ? N / 4 : 0;
+    const int per = vec ? N4 : (N + 3) / 4;
+    const int nT = S * B * 16;
+    const unsigned gx = (unsigned)((max(per, nT) + 255) / 256);
+    hipLaunchKernelGGL(k_fb_scale, dim3(gx, (unsigned)B + 1), dim3(256), 0, (hipStream_t)stream,
+                       g_disp_raw, g_T_raw, stats, g_loss, smoothness, g_disp, g_T, N4, N, nT);
+    return hip_check_launch();
+}
+
+}  // extern "C"

@@ -83,7 +83,11 @@ class HotPathLosses:
         o = self.opt
         T = poses if torch.is_tensor(poses) else torch.stack(list(poses), 0)
         S = T.shape[0]
-        noise = self._tie_break_noise(disp, S)
+        # tie-break draw (train.py:1023-1024): generated inside the forward+backward tile kernel
+        # unless a test injected a fixed tensor or the route with separate kernels runs
+        in_kernel = (getattr(o, "inkernel_noise", True) and getattr(self, "tie_break_noise", None) is None
+                     and ops.unit_uses_fwdbwd(S, disp, T))
+        noise = None if in_kernel else self._tie_break_noise(disp, S)
         cfg = (S, self._loss_flags(), float(o.disparity_smoothness), o.min_depth, o.max_depth,
                1e-7, bool(want_auto_mask), False)
         loss, auto_mask, _, _, _ = ops.Unit.apply(disp, img_tgt, T, K, inv_K, mask_rec, noise, cfg,

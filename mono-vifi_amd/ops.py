@@ -372,6 +372,12 @@ class LossesBase(torch.autograd.Function):
 UNIT_FWDBWD = True
 
 
+def unit_uses_fwdbwd(S, disp, T):
+    """True when Unit.apply will take the one-kernel forward+backward route."""
+    return bool(UNIT_FWDBWD and S <= 2 and torch.is_grad_enabled() and
+                (disp.requires_grad or T.requires_grad))
+
+
 class Unit(torch.autograd.Function):
     """One hot-path unit: S x generate_images_pred + compute_losses_base with the warped
     images kept in LDS (reference: train.py:956-1051).
@@ -380,7 +386,8 @@ class Unit(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, disp, tgt, T, K, inv_K, mask_rec, noise, cfg, *src):
-        S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx = cfg
+        S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx = cfg[:8]
+        noise_out = cfg[8] if len(cfg) > 8 else None     # tests: receives the in-kernel draw
         src = [_c(t) for t in src]
         nat.require_device(disp, tgt, T, K, inv_K, mask_rec, noise, *src)
         disp, tgt, T, K, inv_K = _c(disp), _c(tgt), _c(T), _c(K), _c(inv_K)
@@ -400,17 +407,27 @@ class Unit(torch.autograd.Function):
         if ctx.fwdbwd:
             g_disp = torch.empty_like(disp)
             g_T = torch.empty_like(T)
+            automask = not (flags & NO_AUTOMASK)
+            seed = 0
+            if noise is None and automask:
+                # tie-break draw of train.py:1023-1024 generated in the kernel: one 64-bit key per
+                # call from torch's CPU generator (reproducible under torch.manual_seed)
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
             nat.check(nat.lib().mvf_unit_fwdbwd(
                 nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K), nat.ptr(inv_K), nat.ptr(noise),
                 nat.ptr(mask_rec), S, flags, smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
                 nat.ptr(auto_mask), None, nat.ptr(stats), nat.ptr(idx), nat.ptr(g_disp), nat.ptr(g_T),
-                nat.ptr(ws), B, H, W, _stream()), "unit_fwdbwd")
-            ctx.save_for_backward(g_disp, g_T)
+                nat.ptr(ws), B, H, W, seed, nat.ptr(noise_out), _stream()), "unit_fwdbwd")
+            ctx.save_for_backward(g_disp, g_T, stats)
             ctx.n_src = S
+            ctx.smoothness = smoothness
             outs = [loss[0], auto_mask if want_mask else torch.empty(0, device=dev), argmin,
                     idx if want_idx else torch.empty(0, device=dev), loss[1:]]
             ctx.mark_non_differentiable(*outs[1:])
             return tuple(outs)
+        if noise is None and not (flags & NO_AUTOMASK):
+            raise RuntimeError("mvf_unit_fwd needs the tie-break noise tensor (only the "
+                               "forward+backward kernel draws it itself)")
         nat.check(nat.lib().mvf_unit_fwd(nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K),
                                          nat.ptr(inv_K), nat.ptr(noise), nat.ptr(mask_rec), S, flags,
                                          smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
@@ -426,9 +443,16 @@ class Unit(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, *_unused):
         if ctx.fwdbwd:
-            g_disp, g_T = ctx.saved_tensors      # for an upstream gradient of 1; linear in it
-            return (g_disp * g_loss, None, g_T * g_loss, None, None, None, None, None,
-                    *([None] * ctx.n_src))
+            # raw gradients for an upstream gradient of 1; one pass applies the per-image
+            # constant of the mean-normalised smoothness term and the upstream gradient
+            g_raw, gT_raw, stats = ctx.saved_tensors
+            B, _, H, W = g_raw.shape
+            g_loss = _c(g_loss).reshape(1)
+            g_disp, g_T = torch.empty_like(g_raw), torch.empty_like(gT_raw)
+            nat.check(nat.lib().mvf_unit_fwdbwd_scale(
+                nat.ptr(g_raw), nat.ptr(gT_raw), nat.ptr(stats), nat.ptr(g_loss), ctx.smoothness,
+                nat.ptr(g_disp), nat.ptr(g_T), B, ctx.n_src, H, W, _stream()), "unit_fwdbwd_scale")
+            return (g_disp, None, g_T, None, None, None, None, None, *([None] * ctx.n_src))
         disp, tgt, T, K, inv_K, mask_rec, argmin, stats, *src = ctx.saved_tensors
         S, flags, smoothness, md, rg, eps = ctx.cfg
         B, _, H, W = disp.shape

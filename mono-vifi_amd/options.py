@@ -106,6 +106,9 @@ def build_parser():
     p.add_argument("--fused_units", type=_str2bool, default=True,
                    help="fused unit kernels (warped images in LDS) instead of the staged "
                         "generate_images_pred + compute_losses_base pair")
+    p.add_argument("--inkernel_noise", type=_str2bool, default=True,
+                   help="auto-mask tie-break noise (train.py:1023-1024) drawn inside the unit kernel "
+                        "from a counter-based generator instead of a torch.randn tensor per unit")
     p.add_argument("--bucket_mb", type=float, default=32.0, help="gradient all-reduce bucket size")
     p.add_argument("--force_collectives", type=_str2bool, default=False,
                    help="issue the data-parallel collectives (bucketed gradient all-reduce, "

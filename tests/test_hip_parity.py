@@ -356,9 +356,9 @@ def test_source_counts_vs_oracle(dev, S, flags, path):
 @pytest.mark.parametrize("S", [1, 2])
 def test_unit_fwdbwd_equals_separate_kernels(dev, shape, flags, S):
     """mvf_unit_fwdbwd (what the training step runs: loss and gradients from one tile kernel)
-    against mvf_unit_fwd + mvf_unit_bwd: same argmin and auto-mask, grad_disp / grad_T and
-    loss equal up to the order of the tile partial sums (1e-6), also under a non-unit upstream
-    gradient; and against the oracle at the small shapes."""
+    against mvf_unit_fwd + mvf_unit_bwd: same argmin and auto-mask, loss to 2e-6, grad_disp /
+    grad_T within the gradient tolerance, also under a non-unit upstream gradient; and against
+    the oracle at the small shapes."""
     from mono_vifi_amd import ops, synthetic
     B, H, W = shape
     inp = synthetic.unit_inputs(1300 + H * W + flags + S, B, H, W, num_src=S, pose_scale=0.03,
@@ -394,13 +394,16 @@ def test_unit_fwdbwd_equals_separate_kernels(dev, shape, flags, S):
             ops.UNIT_FWDBWD = True
     fb, sep = res[True], res[False]
     assert abs(fb[0] - sep[0]) <= 2e-6 * abs(sep[0])
-    assert np.array_equal(fb[1], sep[1]) and np.array_equal(fb[2], sep[2])
-    # grad_disp: same arithmetic; the per-image smoothness sum is folded from a different tiling
-    assert rel_err(fb[3], sep[3]) <= 1e-6
-    assert rel_err(fb[4], sep[4]) <= 1e-6                      # grad_T: tile partials differ in count
-    # upstream gradient 4 (a power of two commutes with every rounding): scaled afterwards (FB)
-    # == scaled inside (separate kernels)
-    assert rel_err(fb[5], sep[5]) <= 1e-6
+    assert np.array_equal(fb[1], sep[1]) and np.array_equal(fb[2], sep[2])     # argmin, auto-mask: exact
+    # gradients: the one-kernel route evaluates the (tolerance-level) adjoint in its own order
+    # (SSIM partials from the forward's window statistics, reciprocal of z shared by the
+    # perspective adjoint), so the two routes agree as two fp32 evaluation orders do
+    assert_grad_close(fb[3], sep[3], TOL, "grad_disp: one kernel vs separate kernels")
+    assert rel_err(fb[4], sep[4]) <= TOL
+    # upstream gradient 4 (a power of two commutes with every rounding): scaled afterwards (one
+    # kernel) == scaled inside (separate kernels)
+    assert_grad_close(fb[5], sep[5], TOL, "grad_disp under upstream gradient 4")
+    assert np.array_equal(fb[5], fb[3] * 4.0)
     assert np.allclose(fb[6], sep[6], rtol=2e-6, atol=1e-9)
     if H * W <= 20000:
         ref = O.unit(inp["disp"], inp["tgt"], inp["src"], T_np, inp["K"], inp["inv_K"], noise_np,
@@ -464,8 +467,10 @@ def test_properties_fullsize(dev):
                                     tens["mask"])
     loss.backward()
     assert abs(float(loss) - l1) <= 1e-6 * abs(l1)
-    assert rel_err(N(disp.grad), gd1) <= 1e-5
-    assert rel_err(N(Tt.grad), gT1) <= 1e-5
+    # two fp32 evaluation orders of the same adjoint (the one-kernel route derives the SSIM
+    # partials from the forward's window statistics): gradient tolerance, not bit equality
+    assert_grad_close(N(disp.grad), gd1, TOL, "grad_disp staged vs fused")
+    assert rel_err(N(Tt.grad), gT1) <= TOL
 
 
 def test_error_behaviour(dev):
@@ -623,3 +628,50 @@ def test_reflect_pad1(dev, shape):
     ref = conv.conv(conv.pad(x))
     assert torch.allclose(conv(x), ref, atol=1e-6)
 
+
+
+# ------------------------------------------------------------------ in-kernel tie-break noise
+@pytest.mark.parametrize("shape,flags,S", [((2, 33, 70), 0, 2), ((1, 64, 200), 2, 2), ((2, 17, 65), 0, 1),
+                                           ((4, 192, 640), 0, 2)])
+def test_inkernel_noise_replayed_through_the_oracle(dev, shape, flags, S):
+    """noise=None: the forward+backward kernel draws the tie-break noise of train.py:1023-1024
+    itself (counter-based generator keyed by a per-call seed).  The draw is written out and
+    replayed through the oracle: argmin / loss / gradients must be those of the oracle on that
+    noise; the draw is standard normal, differs between seeds and repeats for a seed."""
+    from mono_vifi_amd import ops, synthetic
+    B, H, W = shape
+    inp = synthetic.unit_inputs(1700 + H * W + flags + S, B, H, W, num_src=S, pose_scale=0.03,
+                                with_mask=True, disp_mode="smooth" if H * W > 10000 else "noise")
+    T_np = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
+                     for k in range(S)], 0)
+    n_id = 1 if flags & 2 else S
+    srcs = [T(inp["src"][k], dev) for k in range(S)]
+
+    def run(seed):
+        torch.manual_seed(seed)
+        noise_out = torch.zeros((B, n_id, H, W), device=dev)
+        disp, Tt = T(inp["disp"], dev, True), T(T_np, dev, True)
+        cfgt = (S, flags, 1e-3, 0.1, 100.0, 1e-7, True, False, noise_out)
+        loss, am, argmin, _, _ = ops.Unit.apply(disp, T(inp["tgt"], dev), Tt, T(inp["K"], dev),
+                                                T(inp["inv_K"], dev), T(inp["mask_rec"], dev), None, cfgt, *srcs)
+        loss.backward()
+        return float(loss.detach()), N(argmin), N(disp.grad), N(Tt.grad), N(noise_out)
+
+    l1, a1, gd1, gT1, nz1 = run(5)
+    l1b, a1b, gd1b, _, nz1b = run(5)
+    _, _, _, _, nz2 = run(6)
+    assert np.array_equal(nz1, nz1b) and l1 == l1b and np.array_equal(a1, a1b) and np.array_equal(gd1, gd1b)
+    assert not np.array_equal(nz1, nz2)
+    assert np.all(np.isfinite(nz1))
+    if nz1.size >= 4000:
+        assert abs(float(nz1.mean())) < 5.0 / np.sqrt(nz1.size) and abs(float(nz1.std()) - 1.0) < 0.05
+        if n_id == 2:    # the two candidates of a pixel are uncorrelated
+            assert abs(float(np.corrcoef(nz1[:, 0].ravel(), nz1[:, 1].ravel())[0, 1])) < 0.05
+    ref = O.unit(inp["disp"], inp["tgt"], inp["src"], T_np, inp["K"], inp["inv_K"],
+                 np.ascontiguousarray(nz1), inp["mask_rec"], flags, want_grads=True)
+    am = a1.astype(np.int32)
+    am[am == 255] = -1
+    assert np.array_equal(am, ref["idx"])
+    assert abs(l1 - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    assert_grad_close(gd1, ref["grad_disp"], TOL, "grad_disp vs oracle (replayed noise)")
+    assert rel_err(gT1, ref["grad_T"]) <= TOL
