@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 3
+#define MVF_ABI_VERSION 4
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -209,6 +209,31 @@ MVF_API int mvf_flow_warp_bwd(const float *img, const float *flow, const float *
                       const float *g_out, float *g_img, float *g_flow, float *workspace, int B, int C,
                       int H, int W, void *stream);
 MVF_API size_t mvf_flow_warp_workspace_floats(int B, int C, int H, int W);
+
+/* ---- f1: FusionModule (networks/fusion_module.py:65-130) -----------
+ * The tensor that enters the 1x1 convolution of one pyramid level,
+ *   out [B, 2*(C+42), h, w] = cat[ feat_0 | emb(0) | m*(warp(feat_n1, fl_n1) | emb(e_n1))
+ *                                                  + (1-m)*(warp(feat_p1, fl_p1) | emb(e_p1)) ],
+ * in one launch (get_embedding_flow :65-78, warp_features :80-90, merge_features :92-103 and
+ * the cats of forward :105-130).  flows [B,2,Hf,Wf] and merge mask [B,1,Hf,Wf] are the frozen
+ * teacher's full-resolution outputs.
+ * mvf_fusion_prep fills the per-level side tensor prep [B,9,h,w] = {e_n1 (2), e_p1 (2): cascaded
+ * half-resolution flows, halved at every step; fl_n1 (2), fl_p1 (2): F.interpolate(flow, (h,w))
+ * scaled by (w/Wf, h/Hf); m (1): F.interpolate(mask, (h,w))}.  The cascade continues from
+ * prev_prep ([B,9,prev_h,prev_w], the level above) or starts at the flows when prev_prep is NULL;
+ * halvings = 2 only for Lite-Mono's first level (fusion_module.py:71-74), else 1. */
+MVF_API size_t mvf_fusion_prep_floats(int B, int h, int w);
+MVF_API int mvf_fusion_prep(const float *flow_n1, const float *flow_p1, const float *mask,
+                    const float *prev_prep, float *prep, int B, int h, int w, int Hf, int Wf, int prev_h,
+                    int prev_w, int halvings, void *stream);
+/* feat_* [B,C,h,w]; xs = linspace(-1,1,w), ys = linspace(-1,1,h) (the reference's fp32 values) */
+MVF_API int mvf_fusion_level_fwd(const float *feat_0, const float *feat_n1, const float *feat_p1,
+                         const float *prep, const float *xs, const float *ys, float *out, int B, int C,
+                         int h, int w, void *stream);
+/* g_out [B,2*(C+42),h,w] -> g_feat_n1 / g_feat_p1 [B,C,h,w] (nullable; zero-initialised by the
+ * caller: scatter-add).  grad of feat_0 is g_out[:, :C] itself; flows and mask carry no gradient. */
+MVF_API int mvf_fusion_level_bwd(const float *g_out, const float *prep, const float *xs, const float *ys,
+                         float *g_feat_n1, float *g_feat_p1, int B, int C, int h, int w, void *stream);
 
 /* ---- f2: Trainer.compute_SI_log_depth_loss (train.py:924-941) ----
  * pred, target [B,1,H,W] (N = H*W), mask nullable [B,1,H,W] (same shape; any batch size).

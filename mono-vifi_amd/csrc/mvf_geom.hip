@@ -275,16 +275,6 @@ __global__ void __launch_bounds__(NT) k_grid_sample_bwd(const float *__restrict_
 // channels per lane: the tap is computed once and reused by every channel of the chunk.
 constexpr int FW_CCH = 8;
 
-MVF_DEV Tap flow_tap(const float *__restrict__ flow, const float *__restrict__ xs,
-                     const float *__restrict__ ys, int b, int i, int x, int y, int H, int W)
-{
-    size_t N = (size_t)H * W;
-    float fx = flow[((size_t)b * 2 + 0) * N + i], fy = flow[((size_t)b * 2 + 1) * N + i];
-    float gx = xs[x] + fx / (((float)W - 1.0f) / 2.0f);
-    float gy = ys[y] + fy / (((float)H - 1.0f) / 2.0f);
-    return tap_of(gx, gy, H, W);
-}
-
 __global__ void __launch_bounds__(NT) k_flow_warp_fwd(const float *__restrict__ img,
                                                       const float *__restrict__ flow,
                                                       const float *__restrict__ xs,
@@ -303,48 +293,6 @@ __global__ void __launch_bounds__(NT) k_flow_warp_fwd(const float *__restrict__ 
     int c0 = blockIdx.y * FW_CCH, c1 = min(c0 + FW_CCH, C);
     for (int c = c0; c < c1; ++c)
         out[((size_t)b * C + c) * N + i] = bilerp(img + ((size_t)b * C + c) * N, W, t);
-}
-
-// The L2 executes fp32 atomics at about one dword per clock per channel, so the scatter is
-// bound by the NUMBER of atomics (4 per element), not by bytes.  Lanes of a wavefront walk
-// consecutive x; for a locally uniform integer displacement the east tap of lane l is the
-// west tap of lane l+1 (same rows): lane l+1 then takes that contribution over with a
-// cross-lane move and ONE atomic serves both -- 2 atomics per element instead of 4.  The
-// hand-over is decided per lane pair from the integer taps, so any flow field is handled
-// (lanes that do not line up keep their own atomics).
-struct ScatterLinks {
-    bool from_left;    // my west column == left neighbour's east column, same rows: I add its east values
-    bool to_right;     // ... and the right neighbour takes my east values
-};
-MVF_DEV ScatterLinks scatter_links(const Tap &t, bool active)
-{
-    const int lane = threadIdx.x & (kWave - 1);
-    const int act = active ? 1 : 0;
-    const int lx1 = __shfl_up(t.x1, 1), ly0 = __shfl_up(t.y0, 1), ly1 = __shfl_up(t.y1, 1),
-              la = __shfl_up(act, 1);
-    const int rx0 = __shfl_down(t.x0, 1), ry0 = __shfl_down(t.y0, 1), ry1 = __shfl_down(t.y1, 1),
-              ra = __shfl_down(act, 1);
-    ScatterLinks k;
-    k.from_left = active && lane > 0 && la && lx1 == t.x0 && ly0 == t.y0 && ly1 == t.y1;
-    k.to_right = active && lane < kWave - 1 && ra && rx0 == t.x1 && ry0 == t.y0 && ry1 == t.y1;
-    return k;
-}
-// all lanes of the wavefront must call this (cross-lane moves); inactive lanes pass g = 0
-MVF_DEV void scatter_taps_linked(float *__restrict__ gi, int W, const Tap &t, float g, bool active,
-                                 const ScatterLinks &k)
-{
-    float w = t.wx, e = 1.0f - w, n = t.wy, s = 1.0f - n;
-    float nw = g * (s * e), ne = g * (s * w), sw = g * (n * e), se = g * (n * w);
-    const float lne = __shfl_up(ne, 1), lse = __shfl_up(se, 1);
-    if (k.from_left) { nw += lne; sw += lse; }
-    if (active) {
-        atomicAdd(gi + t.y0 * W + t.x0, nw);
-        atomicAdd(gi + t.y1 * W + t.x0, sw);
-        if (!k.to_right) {
-            atomicAdd(gi + t.y0 * W + t.x1, ne);
-            atomicAdd(gi + t.y1 * W + t.x1, se);
-        }
-    }
 }
 
 __global__ void __launch_bounds__(NT) k_flow_warp_bwd(const float *__restrict__ img,

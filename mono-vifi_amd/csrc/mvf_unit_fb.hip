@@ -50,7 +50,10 @@ struct FbArgs {
 constexpr int FB_TGT = 0, FB_PAIR = 3 * PLANE, FB_DISP = FB_PAIR + 6 * PLANE,
               FB_COEF = FB_DISP + PLANE, FB_POSE = FB_COEF + 6 * RPLANE;
 constexpr int FB_SCRATCH = (NT / kWave) * NRED;
-inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(PoseLds) + FB_SCRATCH * sizeof(float); }
+#ifndef MVF_FB_EXTRA_LDS
+#define MVF_FB_EXTRA_LDS 0     // occupancy experiments: pad the workgroup's LDS
+#endif
+inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(PoseLds) + FB_SCRATCH * sizeof(float) + MVF_FB_EXTRA_LDS; }
 
 // ---- counter-based tie-break noise ------------------------------------------------------
 // train.py:1023-1024 draws torch.randn(identity_reprojection_loss.shape) * 1e-5 per call.  With
@@ -112,61 +115,79 @@ struct WarpCtx {
     int32_t *idx_a, *idx_b;
 };
 
+// one batch of U plane positions: chain + tap loads issued (issue), bilinear combine + store (finish)
 template <int U>
-MVF_DEV void warp_slots(const WarpCtx &k, int slot0)
-{
-    const size_t N = (size_t)k.H * k.W;
+struct WarpBatch {
     WarpSlot s[U];
     float a[U][3][4], bq[U][3][4];
+};
+
+template <int U>
+MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
+{
+    const size_t N = (size_t)k.H * k.W;
 #pragma unroll
     for (int u = 0; u < U; ++u)
-        s[u] = warp_slot((int)threadIdx.x + (slot0 + u) * NT, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0,
-                         k.min_disp, k.range, k.eps);
+        w.s[u] = warp_slot((int)threadIdx.x + (slot0 + u) * NT, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0,
+                           k.min_disp, k.range, k.eps);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            load_taps(k.sa + ch * N, s[u].qa.q, a[u][ch][0], a[u][ch][1], a[u][ch][2], a[u][ch][3]);
-            load_taps(k.sb + ch * N, s[u].qb.q, bq[u][ch][0], bq[u][ch][1], bq[u][ch][2], bq[u][ch][3]);
+            load_taps(k.sa + ch * N, w.s[u].qa.q, w.a[u][ch][0], w.a[u][ch][1], w.a[u][ch][2], w.a[u][ch][3]);
+            load_taps(k.sb + ch * N, w.s[u].qb.q, w.bq[u][ch][0], w.bq[u][ch][1], w.bq[u][ch][2], w.bq[u][ch][3]);
         }
+}
+
+template <int U>
+MVF_DEV void warp_finish(const WarpCtx &k, const WarpBatch<U> &w)
+{
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-        if (!s[u].live) continue;
-        const Taps4 &qa = s[u].qa, &qb = s[u].qb;
+        if (!w.s[u].live) continue;
+        const Taps4 &qa = w.s[u].qa, &qb = w.s[u].qb;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float va = a[u][ch][0] * qa.wnw + a[u][ch][1] * qa.wne + a[u][ch][2] * qa.wsw +
-                       a[u][ch][3] * qa.wse;
-            float vb = bq[u][ch][0] * qb.wnw + bq[u][ch][1] * qb.wne + bq[u][ch][2] * qb.wsw +
-                       bq[u][ch][3] * qb.wse;
-            k.pairP[ch * PPLANE + s[u].r * LDW + s[u].c] = mk2(va, vb);
+            float va = w.a[u][ch][0] * qa.wnw + w.a[u][ch][1] * qa.wne + w.a[u][ch][2] * qa.wsw +
+                       w.a[u][ch][3] * qa.wse;
+            float vb = w.bq[u][ch][0] * qb.wnw + w.bq[u][ch][1] * qb.wne + w.bq[u][ch][2] * qb.wsw +
+                       w.bq[u][ch][3] * qb.wse;
+            k.pairP[ch * PPLANE + w.s[u].r * LDW + w.s[u].c] = mk2(va, vb);
         }
         if (k.idx_a) {
             // the region's 62x14 interior owns its entries of the (optional) index maps
-            int y = k.py0 + s[u].r, x = k.px0 + s[u].c;
+            int y = k.py0 + w.s[u].r, x = k.px0 + w.s[u].c;
             if (y >= k.oy0 && y < min(k.oy0 + OH, k.H) && x >= k.ox0 && x < min(k.ox0 + OW, k.W)) {
-                reinterpret_cast<int2 *>(k.idx_a)[(size_t)y * k.W + x] = make_int2(s[u].x0a, s[u].y0a);
+                reinterpret_cast<int2 *>(k.idx_a)[(size_t)y * k.W + x] = make_int2(w.s[u].x0a, w.s[u].y0a);
                 if (k.idx_b != k.idx_a)
-                    reinterpret_cast<int2 *>(k.idx_b)[(size_t)y * k.W + x] = make_int2(s[u].x0b, s[u].y0b);
+                    reinterpret_cast<int2 *>(k.idx_b)[(size_t)y * k.W + x] = make_int2(w.s[u].x0b, w.s[u].y0b);
             }
         }
     }
 }
 
-MVF_DEV void warp_pair_into_lds_fb(const WarpCtx &k)
+template <int U>
+MVF_DEV void warp_slots(const WarpCtx &k, int slot0)
 {
-#ifndef MVF_FB_WARP_U
-#define MVF_FB_WARP_U 2
-#endif
-    constexpr int U = MVF_FB_WARP_U;
-    constexpr int NFULL = NSTAGE / U;             // 2 iterations of 2 positions
-#pragma unroll 1
-    for (int it = 0; it < NFULL; ++it) warp_slots<U>(k, U * it);
-#pragma unroll
-    for (int q = NFULL * U; q < NSTAGE; ++q) {
-        // wave-uniform: the first lane of this wave is already beyond the plane
-        const int first = ((int)threadIdx.x & ~(kWave - 1)) + q * NT;
-        if (first < PH * PW) warp_slots<1>(k, q);
+    WarpBatch<U> w;
+    warp_issue<U>(k, slot0, w);
+    warp_finish<U>(k, w);
+}
+
+// positions first .. NSTAGE-1 (position `first`-1 and below were handled by the caller)
+MVF_DEV void warp_pair_into_lds_fb(const WarpCtx &k, int first)
+{
+    static_assert(NSTAGE == 5, "slot schedule below assumes 5 plane positions per lane");
+    // wave-uniform: is any lane of this wave inside the plane at the last position?
+    const bool tail = (((int)threadIdx.x & ~(kWave - 1)) + (NSTAGE - 1) * NT) < PH * PW;
+    if (first == 0) {
+        warp_slots<2>(k, 0);
+        warp_slots<2>(k, 2);
+        if (tail) warp_slots<1>(k, 4);
+    } else {            // position 0 was prefetched
+        warp_slots<2>(k, 1);
+        if (tail) warp_slots<2>(k, 3);
+        else warp_slots<1>(k, 3);
     }
 }
 
@@ -250,6 +271,27 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
     }
     __syncthreads();
 
+    // ---- 3a: the first plane position of the fused warp is started BEFORE the identity pass:
+    // its projection chain only needs the staged disparity, and its 24 tap pairs then fly
+    // while the identity SSIM (pure LDS / VALU work) runs
+    f2 P2[12];
+    load_pose_pair(sh, 0, kb, P2);
+    WarpCtx wk_ctx;
+    {
+        WarpCtx &k = wk_ctx;
+        k.pairP = pairP; k.dispP = dispP;
+        k.sa = a.src.p[0] + (size_t)b * 3 * N; k.sb = a.src.p[kb] + (size_t)b * 3 * N;
+        k.iK = a.invK + b * 16; k.P2 = P2;
+        k.H = H; k.W = W; k.py0 = py0; k.px0 = px0; k.oy0 = cy0 + 1; k.ox0 = cx0 + 1;
+        k.min_disp = a.min_disp; k.range = a.range; k.eps = a.eps;
+        k.idx_a = a.idx_xy ? a.idx_xy + ((size_t)b) * N * 2 : nullptr;
+        k.idx_b = a.idx_xy ? a.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
+    }
+#ifndef MVF_FB_NO_PREFETCH
+    WarpBatch<1> pre;
+    if (automask) warp_issue<1>(wk_ctx, 0, pre);
+#endif
+
     // ---- 2: identity candidates of every region pixel
     f2 vid[PX];
 #pragma unroll
@@ -264,23 +306,13 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
     }
 
     // ---- 3: fused warp of the source pair
-    f2 P2[12];
-    load_pose_pair(sh, 0, kb, P2);
-    {
-        WarpCtx k;
-        k.pairP = pairP; k.dispP = dispP;
-        k.sa = a.src.p[0] + (size_t)b * 3 * N; k.sb = a.src.p[kb] + (size_t)b * 3 * N;
-        k.iK = a.invK + b * 16; k.P2 = P2;
-        k.H = H; k.W = W; k.py0 = py0; k.px0 = px0; k.oy0 = cy0 + 1; k.ox0 = cx0 + 1;
-        k.min_disp = a.min_disp; k.range = a.range; k.eps = a.eps;
-        k.idx_a = a.idx_xy ? a.idx_xy + ((size_t)b) * N * 2 : nullptr;
-        k.idx_b = a.idx_xy ? a.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
-#ifdef MVF_ABL_NOWARP    // timing ablation: the raw sources instead of the warped pair
-        stage_pair3(pairP, k.sa, k.sb, N, H, W, py0, px0);
-#else
-        warp_pair_into_lds_fb(k);
+#ifndef MVF_FB_NO_PREFETCH
+    if (automask) {
+        warp_finish<1>(wk_ctx, pre);
+        warp_pair_into_lds_fb(wk_ctx, 1);
+    } else
 #endif
-    }
+        warp_pair_into_lds_fb(wk_ctx, 0);
     __syncthreads();
 
     // ---- 4: warped candidates; SSIM partials of the three channels stay in registers.

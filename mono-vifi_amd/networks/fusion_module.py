@@ -11,6 +11,12 @@ import torch.nn.functional as F
 from ..layers import ConvBlock1x1
 from .ifrnet import warp
 
+# On a HIP device everything up to the 1x1 convolution of a level -- the two flow warps, the
+# three resizes, the 84 sin/cos embedding channels, the mask merge and the concatenations -- is
+# ONE kernel per level (ops.fusion_level / csrc/mvf_fusion.hip).  False (or CPU tensors, which
+# only the build-container tests against the reference's module use) = the op-by-op form below.
+FUSED_LEVELS = True
+
 
 class Embedder:
     """x -> [x, sin(2^0 x), cos(2^0 x), ..., sin(2^(L-1) x), cos(2^(L-1) x)] on dim 1."""
@@ -61,6 +67,13 @@ class FusionModule(nn.Module):
     def forward(self, features, flows, merge_mask):
         feats_n1, feats_0, feats_p1 = features
         flow_0_n1, flow_0_p1 = flows
+        if FUSED_LEVELS and feats_0[0].is_cuda:
+            from .. import ops
+            sizes = [tuple(f.shape[-2:]) for f in feats_0]
+            preps = ops.fusion_prep(flow_0_n1, flow_0_p1, merge_mask, sizes, self.backbone == "LiteMono")
+            return [self.fusion_conv[self._slot[i]](
+                ops.fusion_level(feats_0[i].float(), feats_n1[i].float(), feats_p1[i].float(), preps[i]))
+                for i in range(len(feats_0))]
         w_n1 = self.warp_features(feats_n1, flow_0_n1)
         w_p1 = self.warp_features(feats_p1, flow_0_p1)
         e_0 = self.get_embedding_flow(torch.zeros_like(flow_0_n1))

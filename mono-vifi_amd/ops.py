@@ -562,6 +562,74 @@ def flow_warp_indices(img_shape, flow):
     return idx
 
 
+# ------------------------------------------------------------------ f1 fusion module
+EMB_CH = 42     # Embedder: 2 * (1 + 2 * 10) channels (reference fusion_module.py:43-52)
+
+
+def fusion_prep(flow_n1, flow_p1, mask, sizes, litemono=False):
+    """Per-level side tensors [B,9,h,w] of the FusionModule (cascaded embedding flows, resized
+    warp flows, resized merge mask; reference fusion_module.py:65-103) for the pyramid
+    ``sizes`` = [(h, w), ...] finest first.  Teacher outputs: no gradient."""
+    nat.require_device(flow_n1, flow_p1, mask)
+    flow_n1, flow_p1, mask = _c(flow_n1.detach()), _c(flow_p1.detach()), _c(mask.detach())
+    B, _, Hf, Wf = flow_n1.shape
+    if tuple(flow_p1.shape) != (B, 2, Hf, Wf) or tuple(mask.shape) != (B, 1, Hf, Wf):
+        raise RuntimeError("fusion_prep: flows must be [B,2,H,W] and the mask [B,1,H,W]")
+    preps, prev, ph, pw = [], None, 0, 0
+    eh, ew = Hf, Wf
+    for i, (h, w) in enumerate(sizes):
+        halv = 2 if (i == 0 and litemono) else 1
+        for _ in range(halv):
+            eh, ew = eh // 2, ew // 2
+        if (eh, ew) != (h, w):
+            raise RuntimeError(f"fusion_prep: level {i} is {h}x{w} but the flow cascade gives {eh}x{ew}")
+        prep = torch.empty((B, 9, h, w), dtype=torch.float32, device=flow_n1.device)
+        nat.check(nat.lib().mvf_fusion_prep(nat.ptr(flow_n1), nat.ptr(flow_p1), nat.ptr(mask), nat.ptr(prev),
+                                            nat.ptr(prep), B, h, w, Hf, Wf, ph, pw, halv, _stream()),
+                  "fusion_prep")
+        preps.append(prep)
+        prev, ph, pw = prep, h, w
+    return preps
+
+
+class FusionLevel(torch.autograd.Function):
+    """One pyramid level of FusionModule.forward up to the 1x1 convolution
+    (reference: networks/fusion_module.py:105-127)."""
+
+    @staticmethod
+    def forward(ctx, feat_0, feat_n1, feat_p1, prep):
+        nat.require_device(feat_0, feat_n1, feat_p1, prep)
+        feat_0, feat_n1, feat_p1, prep = _c(feat_0), _c(feat_n1), _c(feat_p1), _c(prep)
+        B, Cc, h, w = feat_0.shape
+        if feat_n1.shape != feat_0.shape or feat_p1.shape != feat_0.shape or tuple(prep.shape) != (B, 9, h, w):
+            raise RuntimeError("fusion level: feature maps must share [B,C,h,w] and prep be [B,9,h,w]")
+        xs, ys = _linspace(w, feat_0.device), _linspace(h, feat_0.device)
+        out = torch.empty((B, 2 * (Cc + EMB_CH), h, w), dtype=torch.float32, device=feat_0.device)
+        nat.check(nat.lib().mvf_fusion_level_fwd(nat.ptr(feat_0), nat.ptr(feat_n1), nat.ptr(feat_p1),
+                                                 nat.ptr(prep), nat.ptr(xs), nat.ptr(ys), nat.ptr(out), B, Cc, h,
+                                                 w, _stream()), "fusion_level_fwd")
+        ctx.save_for_backward(prep, xs, ys)
+        ctx.dims = (B, Cc, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        prep, xs, ys = ctx.saved_tensors
+        B, Cc, h, w = ctx.dims
+        g = _c(g)
+        g0 = g[:, :Cc] if ctx.needs_input_grad[0] else None
+        gn = torch.zeros((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+        gp = torch.zeros((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+        nat.check(nat.lib().mvf_fusion_level_bwd(nat.ptr(g), nat.ptr(prep), nat.ptr(xs), nat.ptr(ys),
+                                                 nat.ptr(gn), nat.ptr(gp), B, Cc, h, w, _stream()),
+                  "fusion_level_bwd")
+        return g0, gn, gp, None
+
+
+def fusion_level(feat_0, feat_n1, feat_p1, prep):
+    return FusionLevel.apply(feat_0, feat_n1, feat_p1, prep)
+
+
 # ------------------------------------------------------------------ f2 SI-log depth loss
 class SILog(torch.autograd.Function):
     """Trainer.compute_SI_log_depth_loss; reference: train.py:924-941"""

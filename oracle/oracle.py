@@ -325,3 +325,107 @@ def set_threads(n):
     """OpenMP threads used by the oracle (bench.py's cpu_baseline calibrates this); returns
     the count in effect."""
     return int(lib().mvfo_set_threads(int(n)))
+
+
+# --------------------------------------------------------------------------- f1: FusionModule
+# reference: networks/fusion_module.py:65-130 (what enters the per-scale 1x1 convolutions).
+def resize_bilinear(x, oh, ow, scale_factor=None):
+    """F.interpolate(x, mode="bilinear", align_corners=False) as ATen's CPU kernel evaluates it:
+    src = scale*(dst+0.5)-0.5 clamped at 0 (scale = in/out for size=..., 1/scale_factor when a
+    scale factor was given), and out = wy0*(wx0*v00 + wx1*v01) + wy1*(wx0*v10 + wx1*v11)."""
+    x = _f(x)
+    H, W = x.shape[-2:]
+    f32 = np.float32
+
+    def axis(n_in, n_out):
+        scale = f32(1.0 / scale_factor) if scale_factor is not None else f32(n_in) / f32(n_out)
+        src = scale * (np.arange(n_out, dtype=f32) + f32(0.5)) - f32(0.5)
+        src = np.maximum(src, f32(0.0))
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(f32)).astype(f32)
+        return i0, i1, (f32(1.0) - l1).astype(f32), l1
+
+    y0, y1, wy0, wy1 = axis(H, oh)
+    x0, x1, wx0, wx1 = axis(W, ow)
+    top = wx0 * x[..., y0, :][..., x0] + wx1 * x[..., y0, :][..., x1]
+    bot = wx0 * x[..., y1, :][..., x0] + wx1 * x[..., y1, :][..., x1]
+    return (wy0[:, None] * top.astype(f32) + wy1[:, None] * bot.astype(f32)).astype(f32)
+
+
+def flow_embedding(x, num_freqs=10):
+    """Embedder.embed (fusion_module.py:7-37): [x, sin(2^k x), cos(2^k x) ...] on dim 1."""
+    x = _f(x)
+    parts = [x]
+    for k in range(num_freqs):
+        f = np.float32(2.0 ** k)
+        parts += [np.sin(x * f).astype(np.float32), np.cos(x * f).astype(np.float32)]
+    return np.concatenate(parts, 1)
+
+
+def embedding_flows(flow, levels, litemono=False):
+    """get_embedding_flow (fusion_module.py:65-78): cascaded half-resolution flows, values
+    halved with the resolution (LiteMono: the first level is halved twice)."""
+    x, outs = _f(flow), []
+    for i in range(levels):
+        x = resize_bilinear(x, x.shape[-2] // 2, x.shape[-1] // 2, 0.5) * np.float32(0.5)
+        if i == 0 and litemono:
+            x = resize_bilinear(x, x.shape[-2] // 2, x.shape[-1] // 2, 0.5) * np.float32(0.5)
+        outs.append(x.astype(np.float32))
+    return outs
+
+
+def _warp_flow(flow, H, W):
+    """flow_ of warp_features (fusion_module.py:80-90): direct resize, scaled with the size."""
+    fh, fw = flow.shape[-2:]
+    fl = resize_bilinear(flow, H, W)
+    fl = fl * np.array([W / fw, H / fh], np.float32).reshape(1, 2, 1, 1)
+    return np.ascontiguousarray(fl.astype(np.float32))
+
+
+def _linspace(n):
+    import torch
+    return torch.linspace(-1.0, 1.0, n).numpy()
+
+
+def fusion_forward(feats, flows, mask, litemono=False):
+    """feats = [pyramid_n1, pyramid_0, pyramid_p1], flows = [flow_0_n1, flow_0_p1] (full
+    resolution), mask [B,1,H,W] -> per level cat[f0, emb(0), m*[warp(fn1), emb(e_n1)] +
+    (1-m)*[warp(fp1), emb(e_p1)]]."""
+    L = len(feats[1])
+    e0 = embedding_flows(np.zeros_like(_f(flows[0])), L, litemono)
+    en = embedding_flows(flows[0], L, litemono)
+    ep = embedding_flows(flows[1], L, litemono)
+    outs = []
+    for i in range(L):
+        f0 = _f(feats[1][i])
+        B, Cc, H, W = f0.shape
+        xs, ys = _linspace(W), _linspace(H)
+        wn = flow_warp(feats[0][i], _warp_flow(flows[0], H, W), xs, ys)
+        wp = flow_warp(feats[2][i], _warp_flow(flows[1], H, W), xs, ys)
+        m = resize_bilinear(mask, H, W)
+        a = np.concatenate([wn, flow_embedding(en[i])], 1)
+        bq = np.concatenate([wp, flow_embedding(ep[i])], 1)
+        merged = (m * a + (np.float32(1.0) - m) * bq).astype(np.float32)
+        outs.append(np.concatenate([f0, flow_embedding(e0[i]), merged], 1))
+    return outs
+
+
+def fusion_backward(feats, flows, mask, gouts):
+    """Gradients of sum_i <out_i, gouts_i> w.r.t. the three feature pyramids (flows and mask
+    come from the frozen teacher and carry none)."""
+    L = len(feats[1])
+    g_n1, g_0, g_p1 = [], [], []
+    for i in range(L):
+        B, Cc, H, W = feats[1][i].shape
+        E = (gouts[i].shape[1] - 2 * Cc) // 2
+        xs, ys = _linspace(W), _linspace(H)
+        m = resize_bilinear(mask, H, W)
+        g = _f(gouts[i])
+        g_0.append(np.ascontiguousarray(g[:, :Cc]))
+        gw = g[:, Cc + E:2 * Cc + E]
+        g_n1.append(flow_warp_bwd(feats[0][i], _warp_flow(flows[0], H, W), xs, ys,
+                                  np.ascontiguousarray(m * gw))[0])
+        g_p1.append(flow_warp_bwd(feats[2][i], _warp_flow(flows[1], H, W), xs, ys,
+                                  np.ascontiguousarray((np.float32(1.0) - m) * gw))[0])
+    return g_n1, g_0, g_p1

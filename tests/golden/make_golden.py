@@ -441,9 +441,60 @@ def g8_silog():
     save("g8_silog", pred=pred, target=target, mask=mask, **out)
 
 
+# ----------------------------------------------------------------------------- G9 (fusion module, f1)
+def g9_fusion():
+    """FusionModule (networks/fusion_module.py:65-130): what enters the per-scale 1x1 convs --
+    cat[feat_0, emb(0), m*[warp(f_n1), emb(flow_n1)] + (1-m)*[warp(f_p1), emb(flow_p1)]] -- and the
+    gradients w.r.t. the three feature pyramids for a random upstream weight.  The reference's
+    own methods are called in the order of its forward(); its 1x1 convs are left out (they
+    stay a library convolution in this build)."""
+    sys.modules.pop("networks", None)
+    pkg = types.ModuleType("networks")
+    pkg.__path__ = [os.path.join(REF, "networks")]
+    sys.modules["networks"] = pkg
+    import importlib
+    fm = importlib.import_module("networks.fusion_module")
+    rng = np.random.default_rng(900)
+    cases = {"resnet": ("ResNet18", (1, 64, 64), [3, 3, 4, 6, 8], [2, 4, 8, 16, 32], 6.0),
+             "litemono": ("LiteMono", (2, 32, 64), [6, 8, 10], [4, 8, 16], 9.0),
+             "dhrnet": ("DHRNet", (1, 32, 96), [5, 3], [2, 4], 3.0)}
+    for name, (backbone, (B, H, W), chans, strides, fscale) in cases.items():
+        mod = fm.FusionModule(SimpleNamespace(backbone=backbone), np.array(chans))
+        feats = [[rng.standard_normal((B, c, H // s, W // s)).astype(np.float32) for c, s in zip(chans, strides)]
+                 for _ in range(3)]
+        flows = [(fscale * rng.standard_normal((B, 2, H, W))).astype(np.float32) for _ in range(2)]
+        # smooth the flows a little (3x3 box) so that neighbouring samples are correlated like a VFI flow
+        flows = [synth._box3(f) for f in flows]
+        mask = rng.random((B, 1, H, W)).astype(np.float32)
+        tf = [[t(f).clone().requires_grad_(True) for f in lvl] for lvl in feats]
+        tfl = [t(f) for f in flows]
+        w_n1 = mod.warp_features(tf[0], tfl[0])
+        w_p1 = mod.warp_features(tf[2], tfl[1])
+        e_0 = mod.get_embedding_flow(0.0 * tfl[0].clone().detach())
+        e_n1 = mod.get_embedding_flow(tfl[0].clone())
+        e_p1 = mod.get_embedding_flow(tfl[1].clone())
+        L = len(chans)
+        f00 = [torch.cat([tf[1][i], e_0[i]], 1) for i in range(L)]
+        fn = [torch.cat([w_n1[i], e_n1[i]], 1) for i in range(L)]
+        fp = [torch.cat([w_p1[i], e_p1[i]], 1) for i in range(L)]
+        outs = mod.merge_features([fn, f00, fp], t(mask))
+        wts = [rng.standard_normal(tuple(o.shape)).astype(np.float32) for o in outs]
+        sum((o * t(w)).sum() for o, w in zip(outs, wts)).backward()
+        arrs = dict(backbone=np.array(backbone), chans=np.array(chans), strides=np.array(strides),
+                    flow_n1=flows[0], flow_p1=flows[1], mask=mask)
+        for i in range(L):
+            for k, tag in enumerate(("n1", "0", "p1")):
+                arrs[f"feat_{tag}_{i}"] = feats[k][i]
+                arrs[f"grad_{tag}_{i}"] = tf[k][i].grad
+            arrs[f"out_{i}"] = outs[i]
+            arrs[f"weight_{i}"] = wts[i]
+            arrs[f"emb_n1_{i}"] = e_n1[i]
+        save("g9_fusion_" + name, **arrs)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_geometry, g2=g2_photometric, g3=g3_gradients, g4=g4_fullsize,
-               g5=g5_pose, g6=g6_ssim_smooth, g7=g7_flow_warp, g8=g8_silog)
+               g5=g5_pose, g6=g6_ssim_smooth, g7=g7_flow_warp, g8=g8_silog, g9=g9_fusion)
     for w in which:
         fns[w]()

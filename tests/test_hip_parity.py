@@ -675,3 +675,105 @@ def test_inkernel_noise_replayed_through_the_oracle(dev, shape, flags, S):
     assert abs(l1 - ref["loss"]) <= 1e-5 * abs(ref["loss"])
     assert_grad_close(gd1, ref["grad_disp"], TOL, "grad_disp vs oracle (replayed noise)")
     assert rel_err(gT1, ref["grad_T"]) <= TOL
+
+
+# ------------------------------------------------------------------ f1: fused fusion-module levels (G9)
+def _fusion_case(g):
+    L = len(g["chans"])
+    feats = [[g[f"feat_{tag}_{i}"] for i in range(L)] for tag in ("n1", "0", "p1")]
+    return L, feats, [g["flow_n1"], g["flow_p1"]], g["mask"], str(g["backbone"]) == "LiteMono"
+
+
+@pytest.mark.parametrize("case", ["resnet", "litemono", "dhrnet"])
+def test_fusion_levels_vs_golden(dev, case):
+    """mvf_fusion_prep + mvf_fusion_level_fwd/bwd against what the reference's FusionModule
+    methods produced (G9): the tensor entering each 1x1 convolution and the gradients of the
+    three feature pyramids.  Embedding bands multiply their argument by up to 2^9, so they get
+    5e-4 (see tests/test_oracle_golden.py::test_fusion_oracle_vs_golden); the rest 1e-5."""
+    from mono_vifi_amd import ops
+    g = load_golden("g9_fusion_" + case)
+    L, feats, flows, mask, lite = _fusion_case(g)
+    tf = [[T(f, dev, True) for f in lvl] for lvl in feats]
+    sizes = [tuple(f.shape[-2:]) for f in feats[1]]
+    preps = ops.fusion_prep(T(flows[0], dev), T(flows[1], dev), T(mask, dev), sizes, lite)
+    outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i]) for i in range(L)]
+    sum((o * T(g[f"weight_{i}"], dev)).sum() for i, o in enumerate(outs)).backward()
+    en = O.embedding_flows(flows[0], L, lite)
+    for i in range(L):
+        Cc = int(g["chans"][i])
+        want, got = g[f"out_{i}"], N(outs[i])
+        assert got.shape == want.shape
+        assert np.max(np.abs(N(preps[i])[:, 0:2] - en[i])) <= 1e-6                 # cascaded embedding flow
+        assert np.array_equal(got[:, :Cc + 42], want[:, :Cc + 42])                 # feat_0 and emb(0): exact
+        assert np.max(np.abs(got[:, Cc + 42:2 * Cc + 42] - want[:, Cc + 42:2 * Cc + 42])) <= 1e-5
+        assert np.max(np.abs(got - want)) <= 5e-4
+        assert rel_err(N(tf[0][i].grad), g[f"grad_n1_{i}"]) <= 1e-5
+        assert rel_err(N(tf[1][i].grad), g[f"grad_0_{i}"]) <= 1e-6
+        assert rel_err(N(tf[2][i].grad), g[f"grad_p1_{i}"]) <= 1e-5
+
+
+@pytest.mark.parametrize("pyr", ["resnet18_640x192", "dhrnet_512x192", "litemono_1024x320"])
+def test_fusion_levels_full_pyramids_vs_oracle(dev, pyr):
+    """The pyramids of BASELINE.json's configs (ResNet18 640x192, HRNet18 512x192 Cityscapes,
+    Lite-Mono 1024x320) against the oracle, forward and feature gradients."""
+    from mono_vifi_amd import ops
+    chans, strides, (H, W), lite = {
+        "resnet18_640x192": ([64, 64, 128, 256, 512], [2, 4, 8, 16, 32], (192, 640), False),
+        "dhrnet_512x192": ([64, 18, 36, 72, 144], [2, 4, 8, 16, 32], (192, 512), False),
+        "litemono_1024x320": ([48, 80, 128], [4, 8, 16], (320, 1024), True)}[pyr]
+    rng = np.random.default_rng(91)
+    B = 2
+    feats = [[rng.standard_normal((B, c, H // s, W // s)).astype(np.float32) for c, s in zip(chans, strides)]
+             for _ in range(3)]
+    from mono_vifi_amd import synthetic
+    flows = [synthetic._box3((8 * rng.standard_normal((B, 2, H, W))).astype(np.float32)) for _ in range(2)]
+    mask = rng.random((B, 1, H, W)).astype(np.float32)
+    want = O.fusion_forward(feats, flows, mask, lite)
+    wts = [rng.standard_normal(w.shape).astype(np.float32) for w in want]
+    gn, g0, gp = O.fusion_backward(feats, flows, mask, wts)
+    tf = [[T(f, dev, True) for f in lvl] for lvl in feats]
+    sizes = [tuple(f.shape[-2:]) for f in feats[1]]
+    preps = ops.fusion_prep(T(flows[0], dev), T(flows[1], dev), T(mask, dev), sizes, lite)
+    outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i]) for i in range(len(chans))]
+    sum((o * T(wts[i], dev)).sum() for i, o in enumerate(outs)).backward()
+    for i, Cc in enumerate(chans):
+        got = N(outs[i])
+        assert np.max(np.abs(got[:, :2 * Cc + 42] - want[i][:, :2 * Cc + 42])) <= 2e-5
+        assert np.max(np.abs(got - want[i])) <= 1e-3          # 2^9-amplified embedding bands
+        assert rel_err(N(tf[0][i].grad), gn[i]) <= 1e-5
+        assert rel_err(N(tf[1][i].grad), g0[i]) <= 1e-6
+        assert rel_err(N(tf[2][i].grad), gp[i]) <= 1e-5
+
+
+def test_fusion_module_fused_equals_op_by_op(dev):
+    """FusionModule on the device: the fused levels against the module's own op-by-op form
+    (warp kernel + torch interpolate / sin / cos / cat), outputs and parameter / feature grads."""
+    from types import SimpleNamespace
+    import mono_vifi_amd.networks.fusion_module as fm
+    torch.manual_seed(3)
+    chans = [64, 64, 128, 256, 512]
+    mod = fm.FusionModule(SimpleNamespace(backbone="ResNet18"), chans).to(dev)
+    B, H, W = 2, 192, 640
+    mk = lambda: [torch.randn(B, c, H >> (i + 1), W >> (i + 1), device=dev, requires_grad=True)  # noqa: E731
+                  for i, c in enumerate(chans)]
+    fl = [4 * torch.randn(B, 2, H, W, device=dev) for _ in range(2)]
+    mask = torch.rand(B, 1, H, W, device=dev)
+    res = {}
+    feats = [mk(), mk(), mk()]
+    for fused in (True, False):
+        fm.FUSED_LEVELS = fused
+        try:
+            for lvl in feats:
+                for f in lvl:
+                    f.grad = None
+            mod.zero_grad()
+            outs = mod(feats, fl, mask)
+            sum((o * o).sum() for o in outs).backward()
+            res[fused] = ([o.detach().clone() for o in outs], [f.grad.clone() for lvl in feats for f in lvl],
+                          [p.grad.clone() for p in mod.parameters()])
+        finally:
+            fm.FUSED_LEVELS = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())    # conv of 2^9-amplified bands
+    for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+        assert float((a - b).norm() / b.norm()) <= 2e-3

@@ -188,3 +188,32 @@ def test_require_device_rejects_foreign_and_mixed_devices(monkeypatch):
         _native.require_device(FakeT(0), FakeT(1))
     with pytest.raises(RuntimeError, match="current device"):
         _native.require_device(FakeT(1), FakeT(1))
+
+
+@pytest.mark.parametrize("case", ["resnet", "litemono", "dhrnet"])
+def test_fusion_oracle_vs_golden(case):
+    """f1: the oracle's restatement of FusionModule (what enters the 1x1 convolutions) against
+    what the reference's own methods produced (G9).  The sin/cos embedding multiplies its
+    argument by up to 2^9, so a 1-ulp difference in a down-sampled flow value moves the highest
+    bands by ~1e-4: those channels get 5e-4, everything else 1e-6."""
+    g = load_golden("g9_fusion_" + case)
+    L = len(g["chans"])
+    feats = [[g[f"feat_{tag}_{i}"] for i in range(L)] for tag in ("n1", "0", "p1")]
+    flows = [g["flow_n1"], g["flow_p1"]]
+    lite = str(g["backbone"]) == "LiteMono"
+    en = O.embedding_flows(g["flow_n1"], L, lite)
+    outs = O.fusion_forward(feats, flows, g["mask"], lite)
+    for i in range(L):
+        Cc = int(g["chans"][i])
+        assert np.max(np.abs(O.flow_embedding(en[i])[:, :2] - g[f"emb_n1_{i}"][:, :2])) <= 1e-6
+        assert np.max(np.abs(O.flow_embedding(en[i]) - g[f"emb_n1_{i}"])) <= 5e-4
+        want = g[f"out_{i}"]
+        assert outs[i].shape == want.shape
+        # f0, emb(0) exact; merged warps of white-noise features: a 1-ulp flow difference moves a sample by ~1e-6 px
+        assert np.max(np.abs(outs[i][:, :2 * Cc + 42] - want[:, :2 * Cc + 42])) <= 1e-5
+        assert np.max(np.abs(outs[i] - want)) <= 5e-4
+    gn, g0, gp = O.fusion_backward(feats, flows, g["mask"], [g[f"weight_{i}"] for i in range(L)])
+    for i in range(L):
+        assert rel_err(gn[i], g[f"grad_n1_{i}"]) <= 1e-5
+        assert rel_err(g0[i], g[f"grad_0_{i}"]) <= 1e-6
+        assert rel_err(gp[i], g[f"grad_p1_{i}"]) <= 1e-5
