@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 4
+#define MVF_ABI_VERSION 5
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -173,13 +173,16 @@ MVF_API int mvf_unit_bwd(const float *disp, const float *tgt, const float *const
  * noise == NULL (with auto-masking on): the tie-break draw of train.py:1023-1024 is generated
  * in the kernel from a counter-based generator keyed by noise_seed and the element index, and
  * written to noise_out (nullable, same layout as noise) so that it can be replayed.
+ * disp_mean_partials (nullable) [B,32]: the per-image partial sums of disp as mvf_disp_head_fwd
+ * emits them; NULL = computed here (one more small launch).
  * workspace: mvf_workspace_floats(B,H,W) floats. */
 MVF_API int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
                     const float *K, const float *inv_K, const float *noise, const float *mask_rec,
                     int S, int flags, float smoothness, float min_disp, float range, float eps,
                     float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
                     int32_t *idx_xy, float *g_disp_raw, float *g_T_raw, float *workspace, int B, int H,
-                    int W, uint64_t noise_seed, float *noise_out, void *stream);
+                    int W, uint64_t noise_seed, float *noise_out, const float *disp_mean_partials,
+                    void *stream);
 /* backward() of the above: g_disp = (g_disp_raw - shift_b) * (*g_loss), g_T = g_T_raw * (*g_loss),
  * shift_b = (smoothness * (stats[b,2] + stats[b,3]) / (H*W)) / stats[b,1]; g_loss device scalar.
  * In-place use (g_disp == g_disp_raw) is allowed. */
@@ -274,6 +277,23 @@ MVF_API int mvf_affine_restore_bwd(const float *g_out, const float *angle_deg, c
 MVF_API int mvf_reflect_pad1_fwd(const float *in, float *out, int planes, int H, int W, void *stream);
 MVF_API int mvf_reflect_pad1_bwd(const float *g_out, float *g_in, int planes, int H, int W, void *stream);
 
+/* ---- f4: step glue either side of the hot path ------------------
+ * Decoder stage glue (networks/monodepth2.py:84-90 with layers.py:121-138, 225-228): the padded
+ * input of upconv_1, out [B, C1+C2, 2h+2, 2w+2] = ReflectionPad2d(1)(cat([upsample_nearest_x2(x),
+ * skip], 1)), written once from x [B,C1,h,w] and skip [B,C2,2h,2w] (skip NULL when C2 == 0). */
+MVF_API int mvf_up2cat_pad_fwd(const float *x, const float *skip, float *out, int B, int C1, int C2, int h,
+                       int w, void *stream);
+/* adjoint: g_x [B,C1,h,w] and g_skip [B,C2,2h,2w] (either nullable), deterministic gathers; h, w >= 2 */
+MVF_API int mvf_up2cat_pad_bwd(const float *g_out, float *g_x, float *g_skip, int B, int C1, int C2, int h,
+                       int w, void *stream);
+/* Disparity head (networks/monodepth2.py:93 followed by layers.py:16-25): disp = sigmoid(logit),
+ * depth = 1/(min_disp + range*disp) (nullable), mean_partials (nullable) [B,32] = the per-image
+ * partial sums of disp that mvf_unit_fwdbwd otherwise computes itself.  logit [B,N]. */
+MVF_API int mvf_disp_head_fwd(const float *logit, float *disp, float *depth, float *mean_partials, int B, int N,
+                      float min_disp, float range, void *stream);
+/* g_logit = (g_disp - g_depth*range*depth^2) * disp*(1-disp); g_disp / g_depth nullable */
+MVF_API int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_depth, float *g_logit,
+                      int64_t n, float min_disp, float range, void *stream);
 /* ---- measurement hooks (bench.py) ------------------------------------------------------
  * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
  * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded

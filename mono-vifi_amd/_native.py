@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -47,9 +47,13 @@ _SIGNATURES = {
     "mvf_unit_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
                      _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     # disp,tgt,src**,T,K,invK,noise,mask, S,flags, smooth,min_disp,range,eps, loss,argmin,auto_mask,
-    # to_opt,stats,idx_xy,g_disp_raw,g_T_raw,ws, B,H,W, noise_seed,noise_out, stream
+    # to_opt,stats,idx_xy,g_disp_raw,g_T_raw,ws, B,H,W, noise_seed,noise_out,mean_partials, stream
     "mvf_unit_fwdbwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
-                        _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_uint64, _vp, _vp],
+                        _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_uint64, _vp, _vp, _vp],
+    "mvf_up2cat_pad_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvf_up2cat_pad_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvf_disp_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp],
+    "mvf_disp_head_bwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _vp],
     "mvf_unit_fwdbwd_scale": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_unit_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp,
                      _vp, _vp, _i, _i, _i, _vp],

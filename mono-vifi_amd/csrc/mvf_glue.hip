@@ -1,0 +1,223 @@
+// mvf_glue.hip -- SURVEY.md section 8f-4: step glue either side of the hot path.
+//
+// (1) Decoder glue.  Every stage of the depth decoder does
+//         x = upsample(upconv_0(x)) ; x = cat([x, skip], 1) ; x = upconv_1(x)     (networks/monodepth2.py:84-90)
+//     where upconv_1 is Conv3x3 = ReflectionPad2d(1) + conv (layers.py:121-138) and upsample is
+//     nearest x2 (layers.py:225-228).  As stock ops that is three full passes over the largest
+//     tensors of the step (nearest upsample, cat copy, reflection pad) forward and three
+//     backward; here the padded convolution input [B, C1+C2, 2h+2, 2w+2] is written ONCE from x
+//     [B,C1,h,w] and the skip feature [B,C2,2h,2w], and the adjoint is one gather pass per source
+//     (reflect-pad adjoint + 2x2 fold for x; reflect-pad adjoint for the skip) -- no atomics.
+// (2) Disparity head.  outputs[("disp", s)] = sigmoid(dispconv(x)) (monodepth2.py:93) followed by
+//     disp_to_depth (layers.py:16-25, called train.py:961 and by the depth-consistency losses):
+//     one pass emits disp, depth and the per-image mean partials of disp the unit kernel needs.
+// Bound: HBM streaming.  -ffp-contract=off (mvf_common.hpp); sigmoid as ATen writes it,
+// 1 / (1 + exp(-x)).
+#include "mvf_common.hpp"
+
+using namespace mvf;
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int PL = 8;            // planes per lane: index math once, PL independent loads in flight
+constexpr int NMEAN = 32;        // per-image mean partials (matches mvf_photo.hip / mvf_unit_fb.hip)
+
+MVF_DEV int reflect1(int v, int n)
+{
+    return (v < 0) ? -v : ((v >= n) ? 2 * (n - 1) - v : v);
+}
+
+// out[b, c, Y, X] = src(c)[reflect(Y-1), reflect(X-1)], src = nearest-x2 of x for c < C1, skip else.
+// grid (padded pixels, plane chunks of the concatenated channel axis, B)
+__global__ void __launch_bounds__(NT) k_up2cat_pad_fwd(const float *__restrict__ x,
+                                                       const float *__restrict__ skip,
+                                                       float *__restrict__ out, int C1, int C2, int h, int w)
+{
+    const int H = 2 * h, W = 2 * w, Hp = H + 2, Wp = W + 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= Hp * Wp) return;
+    const int Y = i / Wp, X = i - Y * Wp;
+    const int y = reflect1(Y - 1, H), xx = reflect1(X - 1, W);
+    const int b = blockIdx.z, C = C1 + C2;
+    const int c0 = blockIdx.y * PL;
+    float *dst = out + ((size_t)b * C + c0) * Hp * Wp + i;
+    const size_t n1 = (size_t)h * w, n2 = (size_t)H * W;
+    const size_t o1 = (size_t)(y >> 1) * w + (xx >> 1), o2 = (size_t)y * W + xx;
+    float v[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+        const int c = c0 + k;
+        v[k] = 0.0f;
+        if (c < C1) v[k] = x[((size_t)b * C1 + c) * n1 + o1];
+        else if (c < C) v[k] = skip[((size_t)b * C2 + (c - C1)) * n2 + o2];
+    }
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+        if (c0 + k < C) dst[(size_t)k * Hp * Wp] = v[k];
+}
+
+// adjoint of ReflectionPad2d(1) at (y, x) of an H x W plane: own copy + the reflected border copies
+MVF_DEV float pad_adjoint(const float *__restrict__ g, int y, int x, int H, int W)
+{
+    const int Wp = W + 2;
+    float v = g[(size_t)(y + 1) * Wp + x + 1];
+    const int ry = (y == 1) ? 0 : ((y == H - 2) ? H + 1 : -1);       // H >= 4: at most one reflected row
+    const int rx = (x == 1) ? 0 : ((x == W - 2) ? W + 1 : -1);
+    if (rx >= 0) v += g[(size_t)(y + 1) * Wp + rx];
+    if (ry >= 0) {
+        v += g[(size_t)ry * Wp + x + 1];
+        if (rx >= 0) v += g[(size_t)ry * Wp + rx];
+    }
+    return v;
+}
+
+// g_x[b,c,Y,X] = sum over the 2x2 children of pad_adjoint(g[b,c]) ; grid (h*w, plane chunks of C1, B)
+__global__ void __launch_bounds__(NT) k_up2cat_pad_bwd_x(const float *__restrict__ g,
+                                                         float *__restrict__ g_x, int C1, int C2, int h, int w)
+{
+    const int H = 2 * h, W = 2 * w;
+    const size_t PP = (size_t)(H + 2) * (W + 2);
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= h * w) return;
+    const int Y = i / w, X = i - Y * w;
+    const int b = blockIdx.z, C = C1 + C2, c0 = blockIdx.y * PL;
+    float v[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k) {
+        v[k] = 0.0f;
+        if (c0 + k < C1) {
+            const float *gp = g + ((size_t)b * C + c0 + k) * PP;
+            v[k] = (pad_adjoint(gp, 2 * Y, 2 * X, H, W) + pad_adjoint(gp, 2 * Y, 2 * X + 1, H, W)) +
+                   (pad_adjoint(gp, 2 * Y + 1, 2 * X, H, W) + pad_adjoint(gp, 2 * Y + 1, 2 * X + 1, H, W));
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+        if (c0 + k < C1) g_x[((size_t)b * C1 + c0 + k) * h * w + i] = v[k];
+}
+
+// g_skip[b,c,y,x] = pad_adjoint(g[b, C1 + c]) ; grid (H*W, plane chunks of C2, B)
+__global__ void __launch_bounds__(NT) k_up2cat_pad_bwd_skip(const float *__restrict__ g,
+                                                            float *__restrict__ g_skip, int C1, int C2, int h,
+                                                            int w)
+{
+    const int H = 2 * h, W = 2 * w;
+    const size_t PP = (size_t)(H + 2) * (W + 2);
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, x = i - y * W;
+    const int b = blockIdx.z, C = C1 + C2, c0 = blockIdx.y * PL;
+    float v[PL];
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+        v[k] = (c0 + k < C2) ? pad_adjoint(g + ((size_t)b * C + C1 + c0 + k) * PP, y, x, H, W) : 0.0f;
+#pragma unroll
+    for (int k = 0; k < PL; ++k)
+        if (c0 + k < C2) g_skip[((size_t)b * C2 + c0 + k) * H * W + i] = v[k];
+}
+
+// ---- disparity head: disp = sigmoid(logit), depth = 1 / (min_disp + range * disp), mean partials
+// grid (NMEAN, B): block (chunk, b) walks its slice of the image
+__global__ void __launch_bounds__(NT) k_disp_head_fwd(const float *__restrict__ logit,
+                                                      float *__restrict__ disp, float *__restrict__ depth,
+                                                      float *__restrict__ mean_part, int N, float min_disp,
+                                                      float range)
+{
+    __shared__ float scratch[NT / kWave];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int per = (N + NMEAN - 1) / NMEAN;
+    const int lo = chunk * per, hi = min(lo + per, N);
+    const size_t base = (size_t)b * N;
+    // same accumulation pattern as k_disp_mean (mvf_photo.hip): the unit kernels read these partials
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    auto one = [&](int i) {
+        const float d = 1.0f / (1.0f + expf(-logit[base + i]));
+        disp[base + i] = d;
+        if (depth) depth[base + i] = 1.0f / (min_disp + range * d);
+        return d;
+    };
+    int i = lo + threadIdx.x;
+    for (; i + 3 * NT < hi; i += 4 * NT) {
+        s0 += one(i);
+        s1 += one(i + NT);
+        s2 += one(i + 2 * NT);
+        s3 += one(i + 3 * NT);
+    }
+    for (; i < hi; i += NT) s0 += one(i);
+    const float r = block_sum<NT>((s0 + s1) + (s2 + s3), scratch);
+    if (threadIdx.x == 0 && mean_part) mean_part[b * NMEAN + chunk] = r;
+}
+
+// g_logit = (g_disp + g_depth * d depth/d disp) * disp * (1 - disp),  d depth/d disp = -range * depth^2
+__global__ void __launch_bounds__(NT) k_disp_head_bwd(const float *__restrict__ disp,
+                                                      const float *__restrict__ g_disp,
+                                                      const float *__restrict__ g_depth,
+                                                      float *__restrict__ g_logit, int64_t n, float min_disp,
+                                                      float range)
+{
+    int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (; i < n; i += stride) {
+        const float d = disp[i];
+        float g = g_disp ? g_disp[i] : 0.0f;
+        if (g_depth) {
+            const float dep = 1.0f / (min_disp + range * d);
+            g -= g_depth[i] * range * dep * dep;
+        }
+        g_logit[i] = g * d * (1.0f - d);
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvf_up2cat_pad_fwd(const float *x, const float *skip, float *out, int B, int C1, int C2, int h, int w,
+                       void *stream)
+{
+    if (B <= 0 || C1 <= 0 || h <= 0 || w <= 0) return 0;
+    if (!x || !out || C2 < 0 || (C2 > 0 && !skip)) return (int)hipErrorInvalidValue;
+    const int n = (2 * h + 2) * (2 * w + 2), C = C1 + C2;
+    hipLaunchKernelGGL(k_up2cat_pad_fwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((C + PL - 1) / PL), (unsigned)B),
+                       dim3(NT), 0, (hipStream_t)stream, x, skip, out, C1, C2, h, w);
+    return hip_check_launch();
+}
+
+int mvf_up2cat_pad_bwd(const float *g_out, float *g_x, float *g_skip, int B, int C1, int C2, int h, int w,
+                       void *stream)
+{
+    if (B <= 0 || C1 <= 0 || h <= 0 || w <= 0) return 0;
+    if (!g_out || C2 < 0 || h < 2 || w < 2) return (int)hipErrorInvalidValue;   // 2h, 2w >= 4
+    if (g_x)
+        hipLaunchKernelGGL(k_up2cat_pad_bwd_x, dim3((unsigned)((h * w + NT - 1) / NT), (unsigned)((C1 + PL - 1) / PL), (unsigned)B),
+                           dim3(NT), 0, (hipStream_t)stream, g_out, g_x, C1, C2, h, w);
+    if (g_skip && C2 > 0)
+        hipLaunchKernelGGL(k_up2cat_pad_bwd_skip, dim3((unsigned)((4 * h * w + NT - 1) / NT), (unsigned)((C2 + PL - 1) / PL), (unsigned)B),
+                           dim3(NT), 0, (hipStream_t)stream, g_out, g_skip, C1, C2, h, w);
+    return hip_check_launch();
+}
+
+int mvf_disp_head_fwd(const float *logit, float *disp, float *depth, float *mean_partials, int B, int N,
+                      float min_disp, float range, void *stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    if (!logit || !disp || B > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_disp_head_fwd, dim3(NMEAN, (unsigned)B), dim3(NT), 0, (hipStream_t)stream, logit, disp,
+                       depth, mean_partials, N, min_disp, range);
+    return hip_check_launch();
+}
+
+int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_depth, float *g_logit, int64_t n,
+                      float min_disp, float range, void *stream)
+{
+    if (n <= 0) return 0;
+    if (!disp || !g_logit) return (int)hipErrorInvalidValue;
+    int64_t blocks = (n + NT - 1) / NT;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_disp_head_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, disp, g_disp,
+                       g_depth, g_logit, n, min_disp, range);
+    return hip_check_launch();
+}
+
+}  // extern "C"

@@ -781,7 +781,7 @@ int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src
                     int S, int flags, float smoothness, float min_disp, float range, float eps,
                     float *loss, uint8_t *argmin, float *auto_mask, float *to_opt, float *stats,
                     int32_t *idx_xy, float *g_disp, float *g_T, float *workspace, int B, int H, int W,
-                    uint64_t noise_seed, float *noise_out, void *stream)
+                    uint64_t noise_seed, float *noise_out, const float *disp_mean_partials, void *stream)
 {
     if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
     if (!g_disp || !g_T || !loss || !stats || !workspace) return (int)hipErrorInvalidValue;
@@ -796,7 +796,7 @@ int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src
     a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
     const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
     // workspace: [B*NMEAN] mean partials | [B*ntiles*NPART] loss partials | [S*B*ntiles*12] grad_P
-    a.mean_ws = workspace;
+    a.mean_ws = disp_mean_partials ? disp_mean_partials : workspace;
     a.part = workspace + (size_t)B * NMEAN;
     a.gp_ws = a.part + (size_t)B * ntiles * NPART;
     a.noise = noise; a.argmin_out = argmin; a.auto_mask_out = auto_mask; a.to_opt_out = to_opt;
@@ -804,7 +804,7 @@ int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src
     a.seed0 = (uint32_t)noise_seed; a.seed1 = (uint32_t)(noise_seed >> 32);
     a.idx_xy = idx_xy;
     a.g_disp = g_disp;
-    mvf_photo::launch_disp_mean(disp, workspace, B, N, st);
+    if (!disp_mean_partials) mvf_photo::launch_disp_mean(disp, workspace, B, N, st);
     {
         ProfScope ps(MVF_PROF_UNIT_FWDBWD, st);
         const dim3 grid((unsigned)(ntiles * B));

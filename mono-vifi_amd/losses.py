@@ -89,7 +89,7 @@ class HotPathLosses:
                      and ops.unit_uses_fwdbwd(S, disp, T))
         noise = None if in_kernel else self._tie_break_noise(disp, S)
         cfg = (S, self._loss_flags(), float(o.disparity_smoothness), o.min_depth, o.max_depth,
-               1e-7, bool(want_auto_mask), False)
+               1e-7, bool(want_auto_mask), False, None, disp_tgt.get(("disp_mean_partials", 0)))
         loss, auto_mask, _, _, _ = ops.Unit.apply(disp, img_tgt, T, K, inv_K, mask_rec, noise, cfg,
                                                   *imgs_src)
         return loss, (auto_mask if want_auto_mask and not o.disable_automasking else None)

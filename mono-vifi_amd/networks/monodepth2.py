@@ -13,6 +13,11 @@ import torch.nn as nn
 from ..layers import Conv3x3, ConvBlock, upsample
 from .resnet import ResNetTrunk, pyramid_features
 
+# fp32 on the HIP device: the upsample + cat + reflection pad between the two convolutions of a
+# decoder stage is one kernel (ops.up2cat_pad) and sigmoid + disp_to_depth one epilogue
+# (ops.disp_head); False = the stock op-by-op form (also what CPU tensors take).
+FUSED_GLUE = True
+
 
 class DepthEncoder(nn.Module):
     def __init__(self, num_layers, pretrained=False):
@@ -53,14 +58,33 @@ class DepthDecoder(nn.Module):
     def _blk(self, *key):
         return self.decoder[self._index[key]]
 
-    def forward(self, input_features):
+    def forward(self, input_features, min_depth=0.1, max_depth=100.0):
+        """-> {("disp", s)}; on the fused path additionally ("depth", 0) and ("disp_mean_partials", 0)
+        (by-products of the disparity-head epilogue; the reference's keys are unchanged)."""
         self.outputs = {}
         x = input_features[-1]
+        fused = FUSED_GLUE and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
+        if fused:
+            from .. import ops
         for i in range(4, -1, -1):
-            x = upsample(self._blk("upconv", i, 0)(x))
-            if self.use_skips and i > 0:
-                x = torch.cat([x, input_features[i - 1]], 1)
-            x = self._blk("upconv", i, 1)(x)
+            x = self._blk("upconv", i, 0)(x)
+            skip = input_features[i - 1] if (self.use_skips and i > 0) else None
+            blk = self._blk("upconv", i, 1)
+            if fused and x.shape[-1] >= 2 and x.shape[-2] >= 2:
+                x = blk.nonlin(blk.conv.conv(ops.up2cat_pad(x, skip)))
+            else:
+                x = upsample(x)
+                if skip is not None:
+                    x = torch.cat([x, skip], 1)
+                x = blk(x)
             if i in self.scales:
-                self.outputs[("disp", i)] = self.sigmoid(self._blk("dispconv", i)(x))
+                logit = self._blk("dispconv", i)(x)
+                if fused and self.num_output_channels == 1:
+                    disp, depth, part = ops.disp_head(logit, min_depth, max_depth, want_depth=(i == 0))
+                    self.outputs[("disp", i)] = disp
+                    if i == 0:
+                        self.outputs[("depth", 0)] = depth
+                        self.outputs[("disp_mean_partials", 0)] = part
+                else:
+                    self.outputs[("disp", i)] = self.sigmoid(logit)
         return self.outputs

@@ -388,6 +388,10 @@ class Unit(torch.autograd.Function):
     def forward(ctx, disp, tgt, T, K, inv_K, mask_rec, noise, cfg, *src):
         S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx = cfg[:8]
         noise_out = cfg[8] if len(cfg) > 8 else None     # tests: receives the in-kernel draw
+        # [B,32] per-image partial sums of disp from the decoder's disparity-head epilogue
+        mean_part = _c(cfg[9]) if len(cfg) > 9 and cfg[9] is not None else None
+        if mean_part is not None and tuple(mean_part.shape) != (disp.shape[0], 32):
+            raise RuntimeError("disp_mean_partials must be [B,32]")
         src = [_c(t) for t in src]
         nat.require_device(disp, tgt, T, K, inv_K, mask_rec, noise, *src)
         disp, tgt, T, K, inv_K = _c(disp), _c(tgt), _c(T), _c(K), _c(inv_K)
@@ -417,7 +421,7 @@ class Unit(torch.autograd.Function):
                 nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K), nat.ptr(inv_K), nat.ptr(noise),
                 nat.ptr(mask_rec), S, flags, smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
                 nat.ptr(auto_mask), None, nat.ptr(stats), nat.ptr(idx), nat.ptr(g_disp), nat.ptr(g_T),
-                nat.ptr(ws), B, H, W, seed, nat.ptr(noise_out), _stream()), "unit_fwdbwd")
+                nat.ptr(ws), B, H, W, seed, nat.ptr(noise_out), nat.ptr(mean_part), _stream()), "unit_fwdbwd")
             ctx.save_for_backward(g_disp, g_T, stats)
             ctx.n_src = S
             ctx.smoothness = smoothness
@@ -768,3 +772,81 @@ class ReflectPad1(torch.autograd.Function):
 def reflect_pad1(x):
     return ReflectPad1.apply(x)
 
+
+
+# --------------------------------------------------------------------------- f4 step glue
+class Up2CatPad(torch.autograd.Function):
+    """ReflectionPad2d(1)(cat([upsample_nearest_x2(x), skip], 1)): the padded input of a decoder
+    stage's second convolution in one pass (reference: networks/monodepth2.py:84-90,
+    layers.py:121-138, 225-228).  skip may be None."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        nat.require_device(x, skip)
+        x, skip = _c(x), _c(skip)
+        B, C1, h, w = x.shape
+        C2 = 0 if skip is None else skip.shape[1]
+        if skip is not None and (skip.shape[0] != B or tuple(skip.shape[2:]) != (2 * h, 2 * w)):
+            raise RuntimeError(f"skip feature must be [B,C,{2 * h},{2 * w}], got {tuple(skip.shape)}")
+        if h < 2 or w < 2:
+            raise RuntimeError("decoder glue needs h, w >= 2")
+        out = torch.empty((B, C1 + C2, 2 * h + 2, 2 * w + 2), dtype=torch.float32, device=x.device)
+        nat.check(nat.lib().mvf_up2cat_pad_fwd(nat.ptr(x), nat.ptr(skip), nat.ptr(out), B, C1, C2, h, w,
+                                               _stream()), "up2cat_pad_fwd")
+        ctx.dims = (B, C1, C2, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, C1, C2, h, w = ctx.dims
+        g = _c(g)
+        gx = torch.empty((B, C1, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[0] else None
+        gs = (torch.empty((B, C2, 2 * h, 2 * w), dtype=torch.float32, device=g.device)
+              if C2 and ctx.needs_input_grad[1] else None)
+        nat.check(nat.lib().mvf_up2cat_pad_bwd(nat.ptr(g), nat.ptr(gx), nat.ptr(gs), B, C1, C2, h, w, _stream()),
+                  "up2cat_pad_bwd")
+        return gx, gs
+
+
+def up2cat_pad(x, skip=None):
+    return Up2CatPad.apply(x, skip)
+
+
+class DispHead(torch.autograd.Function):
+    """sigmoid (networks/monodepth2.py:93) fused with disp_to_depth (layers.py:16-25):
+    logit [B,1,H,W] -> disp, depth (or None), per-image mean partials of disp [B,32] for the unit
+    kernel (not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, logit, min_depth, max_depth, want_depth):
+        nat.require_device(logit)
+        logit = _c(logit)
+        B = logit.shape[0]
+        N = logit[0].numel()
+        md, rg = depth_consts(min_depth, max_depth)
+        disp = torch.empty_like(logit)
+        depth = torch.empty_like(logit) if want_depth else None
+        part = torch.empty((B, 32), dtype=torch.float32, device=logit.device)
+        nat.check(nat.lib().mvf_disp_head_fwd(nat.ptr(logit), nat.ptr(disp), nat.ptr(depth), nat.ptr(part), B, N,
+                                              md, rg, _stream()), "disp_head_fwd")
+        ctx.save_for_backward(disp)
+        ctx.consts = (md, rg)
+        ctx.mark_non_differentiable(part)
+        return disp, (depth if want_depth else torch.empty(0, device=logit.device)), part
+
+    @staticmethod
+    def backward(ctx, g_disp, g_depth, _g_part):
+        (disp,) = ctx.saved_tensors
+        md, rg = ctx.consts
+        g_disp = _c(g_disp)
+        g_depth = _c(g_depth) if (g_depth is not None and g_depth.numel() == disp.numel()) else None
+        g = torch.empty_like(disp)
+        nat.check(nat.lib().mvf_disp_head_bwd(nat.ptr(disp), nat.ptr(g_disp), nat.ptr(g_depth), nat.ptr(g),
+                                              disp.numel(), md, rg, _stream()), "disp_head_bwd")
+        return g, None, None, None
+
+
+def disp_head(logit, min_depth=0.1, max_depth=100.0, want_depth=True):
+    """-> (disp, depth | None, mean_partials)"""
+    disp, depth, part = DispHead.apply(logit, min_depth, max_depth, bool(want_depth))
+    return disp, (depth if want_depth else None), part

@@ -332,7 +332,12 @@ class Trainer(HotPathLosses):
 
     def _depth(self, decoder, feats):
         """decoder -> {("disp",0): fp32 disparity} (the hot path computes in fp32)."""
-        out = self._nets(lambda: self.models[decoder](feats))
+        m = self.models[decoder]
+        if isinstance(m, monodepth2.DepthDecoder):
+            # the disparity-head epilogue also emits depth and the per-image mean partials of disp
+            out = self._nets(lambda: m(feats, self.opt.min_depth, self.opt.max_depth))
+        else:
+            out = self._nets(lambda: m(feats))
         return {k: v.float() for k, v in out.items()}
 
     def _encode(self, name, img):
@@ -474,7 +479,10 @@ class Trainer(HotPathLosses):
         # ---- single-frame depths (plain and affine views share the decoder)
         dec = self._depth_many("depth", [feats_0, feats_pt, feats_nt] + feats_aff)
         disp_0, disp_pt, disp_nt = dec[0], dec[1], dec[2]
-        to_depth = lambda d: disp_to_depth(d[("disp", 0)], o.min_depth, o.max_depth)[1]  # noqa: E731
+        def to_depth(d):
+            # by-product of the decoder's disparity-head epilogue when it ran fused
+            dep = d.get(("depth", 0))
+            return dep if dep is not None else disp_to_depth(d[("disp", 0)], o.min_depth, o.max_depth)[1]
         depth_0, depth_pt, depth_nt = to_depth(disp_0), to_depth(disp_pt), to_depth(disp_nt)
 
         srcs = [img_n1, img_p1]

@@ -777,3 +777,96 @@ def test_fusion_module_fused_equals_op_by_op(dev):
         assert float((a - b).abs().max()) <= 2e-3 * float(b.abs().max())    # conv of 2^9-amplified bands
     for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
         assert float((a - b).norm() / b.norm()) <= 2e-3
+
+
+# ------------------------------------------------------------------ f4: step glue
+@pytest.mark.parametrize("shape", [(2, 5, 3, 2, 3), (3, 16, 7, 6, 20), (2, 4, 0, 5, 9), (12, 32, 64, 48, 160)])
+def test_up2cat_pad_vs_torch(dev, shape):
+    """Decoder stage glue (monodepth2.py:84-90 + layers.py:121-138, 225-228): one pass ==
+    ReflectionPad2d(1)(cat([upsample_nearest(x), skip])), bit-identical forward; the gather
+    adjoint against autograd of the stock ops."""
+    import torch.nn.functional as F
+    from mono_vifi_amd import ops
+    B, C1, C2, h, w = shape
+    torch.manual_seed(1)
+    x = torch.randn(B, C1, h, w, device=dev)
+    skip = torch.randn(B, C2, 2 * h, 2 * w, device=dev) if C2 else None
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    sa = skip.clone().requires_grad_(True) if C2 else None
+    sb = skip.clone().requires_grad_(True) if C2 else None
+    got = ops.up2cat_pad(xa, sa)
+    up = F.interpolate(xb, scale_factor=2, mode="nearest")
+    want = F.pad(torch.cat([up, sb], 1) if C2 else up, (1, 1, 1, 1), mode="reflect")
+    assert torch.equal(got, want)
+    wgt = torch.randn_like(want)
+    (got * wgt).sum().backward()
+    (want * wgt).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * float(xb.grad.abs().max())
+    if C2:
+        assert float((sa.grad - sb.grad).abs().max()) <= 1e-5 * float(sb.grad.abs().max())
+    xc = x.clone().requires_grad_(True)          # deterministic
+    (ops.up2cat_pad(xc, skip) * wgt).sum().backward()
+    assert torch.equal(xc.grad, xa.grad)
+
+
+def test_disp_head_vs_torch(dev):
+    """sigmoid + disp_to_depth epilogue (monodepth2.py:93, layers.py:16-25) and its mean partials."""
+    from mono_vifi_amd import layers, ops
+    torch.manual_seed(2)
+    logit = (3 * torch.randn(6, 1, 48, 160, device=dev))
+    la, lb = logit.clone().requires_grad_(True), logit.clone().requires_grad_(True)
+    disp, depth, part = ops.disp_head(la, 0.1, 100.0)
+    d2 = torch.sigmoid(lb)
+    _, dep2 = layers.disp_to_depth(d2, 0.1, 100.0)
+    assert float((disp - d2).abs().max()) <= 2e-7
+    assert float(((depth - dep2) / dep2).abs().max()) <= 2e-6
+    assert float((part.sum(1) / (48 * 160) - d2.mean((1, 2, 3))).abs().max()) <= 1e-6
+    wa, wb = torch.randn_like(disp), torch.randn_like(disp)
+    ((disp * wa).sum() + (depth * wb).sum()).backward()
+    ((d2 * wa).sum() + (dep2 * wb).sum()).backward()
+    assert float((la.grad - lb.grad).abs().max()) <= 1e-5 * float(lb.grad.abs().max())
+    # the partials are exactly what the unit kernel's own pre-pass computes: same loss bits
+    from mono_vifi_amd import synthetic
+    inp = synthetic.unit_inputs(31, 2, 48, 96, pose_scale=0.02)
+    T_np = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1)) for k in range(2)], 0)
+    lg = torch.logit(T(inp["disp"], dev).clamp(1e-4, 1 - 1e-4))
+    dsp, _, prt = ops.disp_head(lg, 0.1, 100.0)
+    res = []
+    for mp in (None, prt):
+        dd, Tt = dsp.detach().clone().requires_grad_(True), T(T_np, dev, True)
+        cfgt = (2, 0, 1e-3, 0.1, 100.0, 1e-7, True, False, None, mp)
+        loss = ops.Unit.apply(dd, T(inp["tgt"], dev), Tt, T(inp["K"], dev), T(inp["inv_K"], dev), None,
+                              T(inp["noise"], dev), cfgt, T(inp["src"][0], dev), T(inp["src"][1], dev))[0]
+        loss.backward()
+        res.append((float(loss.detach()), dd.grad.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+
+
+def test_decoder_fused_glue_equals_stock_ops(dev):
+    """DepthDecoder on the device: fused stage glue + disparity-head epilogue against the stock
+    op-by-op form (outputs, input-feature and parameter gradients)."""
+    import mono_vifi_amd.networks.monodepth2 as md
+    torch.manual_seed(5)
+    ch = [64, 64, 128, 256, 512]
+    dec = md.DepthDecoder(np.array(ch), range(4)).to(dev)
+    B, H, W = 2, 64, 96
+    feats = [torch.randn(B, c, H >> (i + 1), W >> (i + 1), device=dev, requires_grad=True) for i, c in enumerate(ch)]
+    res = {}
+    for fused in (True, False):
+        md.FUSED_GLUE = fused
+        try:
+            for f in feats:
+                f.grad = None
+            dec.zero_grad()
+            out = dec(feats)
+            sum((out[("disp", s)] ** 2).sum() for s in range(4)).backward()
+            res[fused] = ([out[("disp", s)].detach().clone() for s in range(4)], [f.grad.clone() for f in feats],
+                          [p.grad.clone() for p in dec.parameters()], out.get(("depth", 0)))
+        finally:
+            md.FUSED_GLUE = True
+    for a, b in zip(res[True][0], res[False][0]):
+        assert float((a - b).abs().max()) <= 1e-6
+    for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+        assert float((a - b).norm() / b.norm()) <= 1e-4
+    from mono_vifi_amd import layers
+    assert float(((res[True][3] - layers.disp_to_depth(res[True][0][0], 0.1, 100.0)[1]) / res[True][3]).abs().max()) <= 1e-6

@@ -11,7 +11,7 @@ if [ "$1" = build ]; then
     name=${spec%%:*}; flags=${spec#*:}
     d=$R/mono-vifi_amd/lib/var_$name; mkdir -p $d
     ( cd $R/mono-vifi_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -shared \
-        -fvisibility=hidden -Wno-unused-function $flags -o $d/libmvf_hotpath.so mvf_geom.hip mvf_photo.hip mvf_unit_fb.hip mvf_fusion.hip mvf_affine.hip ) &
+        -fvisibility=hidden -Wno-unused-function $flags -o $d/libmvf_hotpath.so mvf_geom.hip mvf_photo.hip mvf_unit_fb.hip mvf_fusion.hip mvf_glue.hip mvf_affine.hip ) &
   done
   wait
   ls $R/mono-vifi_amd/lib/var_*/libmvf_hotpath.so
