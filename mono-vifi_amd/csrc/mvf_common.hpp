@@ -286,6 +286,14 @@ MVF_DEV void scatter_taps_linked(float *__restrict__ gi, int W, const Tap &t, fl
 // as  q = x*c ; r = fma(-d,q,x) ; q' = fma(r,c,q)  with c = RN(1/d): bit-identical to the IEEE
 // quotient for EVERY finite float (exhaustively verified by oracle/check_constdiv.c, run by
 // tests/test_constdiv.py) at 3 instructions instead of ~10.
+// MVF_FAST_SSIM (opt-in build, NOT the default and NOT parity mode): the window / channel means
+// by reciprocal multiplies and the SSIM quotient by v_rcp -- the tolerance-mode arithmetic
+// SURVEY.md section 7 ("SSIM exactness vs speed") asks to be measured beside exact mode.  The
+// integer sampling indices stay exact; argmin / auto-mask may flip where candidates nearly tie.
+#ifdef MVF_FAST_SSIM
+MVF_DEV float div9(float x) { return x * (1.0f / 9.0f); }
+MVF_DEV float div3(float x) { return x * (1.0f / 3.0f); }
+#else
 MVF_DEV float div9(float x)
 {
     constexpr float c = 1.0f / 9.0f;
@@ -300,6 +308,7 @@ MVF_DEV float div3(float x)
     float r = fmaf(-3.0f, q, x);
     return fmaf(r, c, q);
 }
+#endif
 
 // packed pairs: two IEEE fp32 operations per lane per instruction (v_pk_*_f32)
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -316,6 +325,10 @@ MVF_DEV f2 mk2(float a, float b)
 }
 MVF_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 MVF_DEV f2 pk_abs(f2 a) { return __builtin_elementwise_abs(a); }
+#ifdef MVF_FAST_SSIM
+MVF_DEV f2 div9(f2 x) { return x * f2s(1.0f / 9.0f); }
+MVF_DEV f2 div3(f2 x) { return x * f2s(1.0f / 3.0f); }
+#else
 MVF_DEV f2 div9(f2 x)
 {
     const f2 c = f2s(1.0f / 9.0f);
@@ -330,6 +343,7 @@ MVF_DEV f2 div3(f2 x)
     f2 r = pk_fma(f2s(-3.0f), q, x);
     return pk_fma(r, c, q);
 }
+#endif
 
 // ---- correctly rounded fp32 division without the range guards --------------------------
 // The compiler lowers `n / d` to v_div_scale x2, v_rcp, Newton step, quotient, two residual
@@ -367,6 +381,24 @@ MVF_DEV f2 div_core(f2 n, f2 d, f2 r1)
     f2 q1 = pk_fma(rem, r1, q);
     f2 rem1 = pk_fma(-d, q1, n);
     return pk_fma(rem1, r1, q1);
+}
+// reciprocal and quotient of the SSIM formula (n/d with d > 0, O(1)): exact mode = the
+// guard-free IEEE core; MVF_FAST_SSIM = v_rcp and one multiply
+MVF_DEV f2 ssim_recip(f2 d)
+{
+#ifdef MVF_FAST_SSIM
+    return mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+#else
+    return recip_refined(d);
+#endif
+}
+MVF_DEV f2 ssim_quot(f2 n, f2 d, f2 r1)
+{
+#ifdef MVF_FAST_SSIM
+    return n * r1;
+#else
+    return div_core(n, d, r1);
+#endif
 }
 // exponent of |x| within [-60, 60] (finite, normal, far from over/underflow in the core)
 MVF_DEV bool div_safe(float x)

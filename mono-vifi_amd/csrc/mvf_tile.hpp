@@ -197,7 +197,7 @@ MVF_DEV f2 ssim_raw_pk(f2 mu_x, f2 mu_y, f2 exx, f2 eyy, f2 exy)
     f2 d = (mu_x * mu_x + mu_y * mu_y + f2s(kC1)) * (sigma_x + sigma_y + f2s(kC2));
     // d >= C1*(C2 - rounding) > 0 and |n|, d = O(1) for images in [0,1]: the guard-free
     // division core gives the correctly rounded quotient (see mvf_common.hpp)
-    return (f2s(1.0f) - div_core(n, d, recip_refined(d))) / 2.0f;
+    return (f2s(1.0f) - ssim_quot(n, d, ssim_recip(d))) / 2.0f;
 }
 
 MVF_DEV f2 clamp01_pk(f2 v) { return mk2(clamp01(v.x), clamp01(v.y)); }
@@ -209,8 +209,8 @@ MVF_DEV void ssim_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &dmux, f2
     f2 A1 = 2.0f * mx * my + f2s(kC1), A2 = 2.0f * sigma_xy + f2s(kC2);
     f2 B1 = mx * mx + my * my + f2s(kC1), B2 = sigma_x + sigma_y + f2s(kC2);
     f2 n = A1 * A2, d = B1 * B2;
-    const f2 r1 = recip_refined(d);       // shared by n/d and 1/d
-    f2 raw = (f2s(1.0f) - div_core(n, d, r1)) / 2.0f;
+    const f2 r1 = ssim_recip(d);          // shared by n/d and 1/d
+    f2 raw = (f2s(1.0f) - ssim_quot(n, d, r1)) / 2.0f;
     f2 live = mk2((raw.x >= 0.0f && raw.x <= 1.0f) ? 1.0f : 0.0f,
                   (raw.y >= 0.0f && raw.y <= 1.0f) ? 1.0f : 0.0f);
     f2 inv_d = div_core(f2s(1.0f), d, r1);

@@ -90,8 +90,8 @@ MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val,
     f2 n = A1 * A2, d = B1 * B2;
     // d >= C1*(C2 - rounding) > 0 and |n|, d = O(1) for images in [0,1]: the guard-free
     // division core gives the correctly rounded quotient (see mvf_common.hpp)
-    const f2 r1 = recip_refined(d);
-    const f2 q = div_core(n, d, r1);
+    const f2 r1 = ssim_recip(d);
+    const f2 q = ssim_quot(n, d, r1);
     const f2 raw = (f2s(1.0f) - q) / 2.0f;
     val = clamp01_pk(raw);
     const f2 live = mk2((raw.x >= 0.0f && raw.x <= 1.0f) ? 1.0f : 0.0f,

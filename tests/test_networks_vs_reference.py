@@ -200,3 +200,64 @@ def test_litemono(ref, hw):
         for a, b in zip(fa, fb):
             assert torch.allclose(a, b, atol=2e-5), float((a - b).abs().max())
         assert torch.allclose(their_dec(fa)[("disp", 0)], dec(fb)[("disp", 0)], atol=1e-6)
+
+
+def test_resume_from_a_checkpoint_written_in_the_reference_layout(ref, tmp_path):
+    """ckpt.pth written the way the reference's Trainer.save_model does (train.py:1108-1136) --
+    state dicts of the REFERENCE's own modules, plus what only its files contain: the dead
+    ImageNet ``fc`` head under the ResNet encoders, and an optimizer state over its parameter
+    list (aliased encoder_mf parameters twice, fc included) -- resumed by this build's Trainer
+    (train.py:1138-1159 semantics): every weight this build owns is taken over, foreign keys
+    are ignored, epoch / batch / step are restored, and the non-interchangeable optimizer state
+    restarts with a warning instead of raising."""
+    from types import SimpleNamespace
+    from mono_vifi_amd.options import default_options
+    from mono_vifi_amd.trainer import Trainer
+    opts = default_options(batch_size=2, height=64, width=96, use_affine=True, num_workers=0, synthetic_len=16,
+                           log_dir=str(tmp_path), exp_name="foreign", log_frequency=10 ** 9,
+                           save_frequency=10 ** 9, resume=True)
+    torch.manual_seed(11)
+    ch = np.array([64, 64, 128, 256, 512])
+    theirs = {"depth": ref["monodepth2"].DepthDecoder(ch, range(opts.num_scales)),
+              "depth_mf": ref["monodepth2"].DepthDecoder(ch, range(opts.num_scales)),
+              "pose": ref["posenet"].PoseDecoder(ch, 1, 2),
+              "fusion_module": ref["fusion_module"].FusionModule(SimpleNamespace(backbone="ResNet18"), ch)}
+    # the torchvision-built encoders cannot be instantiated here (torchvision is absent): their
+    # state dicts are written with torchvision's key names (what this build's trunks use), random
+    # values, plus the fc head every reference checkpoint carries
+    probe = Trainer(default_options(batch_size=2, height=64, width=96, use_affine=True, num_workers=0,
+                                    synthetic_len=16, log_dir=str(tmp_path), exp_name="probe",
+                                    log_frequency=10 ** 9, save_frequency=10 ** 9))
+    ckpt, params = {}, []
+    for name in ("encoder", "pose_encoder"):
+        sd = {k: torch.randn_like(v) if v.is_floating_point() else v.clone()
+              for k, v in probe.models[name].state_dict().items()}
+        sd["encoder.fc.weight"], sd["encoder.fc.bias"] = torch.randn(1000, 512), torch.randn(1000)
+        ckpt[name] = sd
+        params += [torch.nn.Parameter(v.clone()) for v in sd.values() if v.is_floating_point()]
+    ckpt["encoder_mf"] = ckpt["encoder"]                      # shared_encoder: the same module saved twice
+    for name, m in theirs.items():
+        ckpt[name] = m.state_dict()
+        params += list(m.parameters())
+    params += [p for p in params[:20]]                          # the reference appends aliased parameters again
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, [15], 0.1)
+    ckpt.update(height=64, width=96, use_stereo=False, epoch=3, step_in_total=1234, batch_idx=17,
+                optimizer=opt.state_dict(), lr_scheduler=sched.state_dict())
+    os.makedirs(os.path.join(str(tmp_path), "foreign"), exist_ok=True)
+    torch.save(ckpt, os.path.join(str(tmp_path), "foreign", "ckpt.pth"))
+
+    t = Trainer(opts)
+    assert (t.ep_start, t.batch_start, t.step) == (3, 17, 1234)
+    for name, m in theirs.items():
+        mine = t.models[name].state_dict()
+        assert list(mine) == list(m.state_dict())
+        for k, v in m.state_dict().items():
+            assert torch.equal(mine[k].cpu(), v), (name, k)
+    for name in ("encoder", "pose_encoder"):
+        mine = t.models[name].state_dict()
+        assert "encoder.fc.weight" not in mine
+        for k, v in mine.items():
+            assert torch.equal(v.cpu(), ckpt[name][k]), (name, k)
+    assert t.models["encoder_mf"] is t.models["encoder"]
+    assert len(t.model_optimizer.state_dict()["state"]) == 0      # restarted, not crashed

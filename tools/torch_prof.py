@@ -32,3 +32,21 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_sh
     torch.cuda.synchronize()
 print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=args.rows,
                                                            max_name_column_width=40, max_shapes_column_width=70))
+if os.environ.get("MVF_PROF_STACKS"):
+    # python stacks of the large device copies / cats / adds
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof2:
+        step()
+        torch.cuda.synchronize()
+    seen = {}
+    for ev in prof2.events():
+        if ev.name in ("aten::copy_", "aten::cat", "aten::add", "aten::add_", "aten::sum") and ev.input_shapes:
+            dt = getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0)
+            if dt < 40:
+                continue
+            st = [s for s in (ev.stack or []) if "mono-vifi_amd" in s or "mono_vifi_amd" in s][:3]
+            key = (ev.name, str(ev.input_shapes[:2]), tuple(st))
+            seen.setdefault(key, [0, 0.0])
+            seen[key][0] += 1
+            seen[key][1] += dt
+    for k, (n, t) in sorted(seen.items(), key=lambda kv: -kv[1][1])[:40]:
+        print(f"{t / 1e3:8.3f} ms x{n:3d} {k[0]:12s} {k[1]:60s} {' <- '.join(s.split('/')[-1] for s in k[2])}")
