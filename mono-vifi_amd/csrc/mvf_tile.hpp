@@ -9,10 +9,26 @@
 
 using namespace mvf;
 
+// Geometry knobs, set by the including translation unit BEFORE the include (each .hip is its own
+// anonymous-namespace instance): region width and pixels per lane.  64 x 16 / 4 px (256 lanes,
+// ~75 KB LDS in the forward+backward kernel: 2 workgroups per CU) or 32 x 16 / 2 px (256 lanes,
+// ~40 KB: 3-4 workgroups per CU, half the per-lane register state).
+#ifndef MVF_TILE_TW
+#define MVF_TILE_TW 64
+#endif
+#ifndef MVF_TILE_PX
+#define MVF_TILE_PX 4
+#endif
+#ifndef MVF_TILE_TH
+#define MVF_TILE_TH 16
+#endif
+
 namespace {
 
-constexpr int TW = 64, TH = 16;          // compute region
-constexpr int PX = 4;                    // pixels per lane (one row segment)
+constexpr int TW = MVF_TILE_TW, TH = MVF_TILE_TH; // compute region
+constexpr int PX = MVF_TILE_PX;          // pixels per lane (one row segment)
+constexpr int RW = PX + 2;               // plane columns a lane's 3x3 windows span
+static_assert(PX == 4 || PX == 2, "row loaders below handle 4 or 2 pixels per lane");
 constexpr int NT = (TW / PX) * TH;       // 256 lanes
 constexpr int PW = TW + 2;               // staged plane width (1-px halo)
 constexpr int PH = TH + 2;
@@ -22,7 +38,7 @@ constexpr int RPLANE = TH * LDW;         // floats per region-sized LDS plane
 constexpr int NMEAN = 32;                // partial sums per image of the disp mean
 constexpr int NPART = 4;                 // floats per tile partial (photo, sx, sy, pad)
 
-static_assert(NT == 256, "tile engine assumes 256 lanes");
+static_assert(NT % kWave == 0 && TW / PX == 16, "whole waves; 16 lanes per region row (DPP rows)");
 
 // XCD-aware tile order.  The dispatcher places workgroup i on XCD i % 8 (private 4 MiB L2
 // each).  Re-number so that each XCD owns one contiguous run of tiles (neighbouring tiles of
@@ -113,29 +129,38 @@ MVF_DEV void stage_planes3(float *__restrict__ lds, const float *__restrict__ im
 constexpr int PPLANE = PH * LDW;   // f2 elements per staged pair plane
 constexpr int RPPLANE = TH * LDW;  // f2 elements per region-sized pair plane
 
-// 6 consecutive floats of an LDS plane row, starting at a 16-B aligned column
+// RW = PX+2 consecutive floats of an LDS plane row, starting at column PX*seg (16-B aligned for
+// PX = 4, 8-B aligned for PX = 2)
 struct Row6 {
-    float v[6];
+    float v[RW];
 };
 MVF_DEV Row6 load_row6(const float *__restrict__ p)
 {
     Row6 r;
-    float4 a = *reinterpret_cast<const float4 *>(p);
-    float2 b = *reinterpret_cast<const float2 *>(p + 4);
-    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y;
+    if constexpr (PX == 4) {
+        float4 a = *reinterpret_cast<const float4 *>(p);
+        float2 b = *reinterpret_cast<const float2 *>(p + 4);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y;
+    } else {
+        float2 a = *reinterpret_cast<const float2 *>(p), b = *reinterpret_cast<const float2 *>(p + 2);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
+    }
     return r;
 }
-// 6 consecutive pairs of a pair-plane row (48 B, 16-B aligned)
+// RW consecutive pairs of a pair-plane row (16-B aligned)
 struct Row6P {
-    f2 v[6];
+    f2 v[RW];
 };
 MVF_DEV Row6P load_row6p(const f2 *__restrict__ p)
 {
     Row6P r;
     const float4 *q = reinterpret_cast<const float4 *>(p);
-    float4 a = q[0], b = q[1], c = q[2];
-    r.v[0] = mk2(a.x, a.y); r.v[1] = mk2(a.z, a.w); r.v[2] = mk2(b.x, b.y);
-    r.v[3] = mk2(b.z, b.w); r.v[4] = mk2(c.x, c.y); r.v[5] = mk2(c.z, c.w);
+    float4 a = q[0], b = q[1];
+    r.v[0] = mk2(a.x, a.y); r.v[1] = mk2(a.z, a.w); r.v[2] = mk2(b.x, b.y); r.v[3] = mk2(b.z, b.w);
+    if constexpr (PX == 4) {
+        float4 c = q[2];
+        r.v[4] = mk2(c.x, c.y); r.v[5] = mk2(c.z, c.w);
+    }
     return r;
 }
 
@@ -156,9 +181,9 @@ MVF_DEV void window_xp(const f2 *__restrict__ xs, const float *__restrict__ ys, 
     for (int r = 0; r < 3; ++r) {
         Row6P x = load_row6p(xs + r * LDW);
         Row6 y = load_row6(ys + r * LDW);
-        f2 xx[6], xy[6], yy[6];
+        f2 xx[RW], xy[RW], yy[RW];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < RW; ++i) {
             xx[i] = x.v[i] * x.v[i];
             xy[i] = x.v[i] * f2s(y.v[i]);
             yy[i] = mk2(y.v[i], y.v[i] * y.v[i]);

@@ -24,6 +24,28 @@
 //   8  smoothness (value and gradient), store, ONE reduction of all 27 tile partials
 // Compiled with -ffp-contract=off (arithmetic contract in mvf_common.hpp): everything that
 // feeds an integer (sampling indices, argmin) follows the reference's evaluation order.
+// Region geometry of this kernel (mvf_tile.hpp): 32 x 16 pixels, 2 per lane.  Compared with the
+// 64 x 16 / 4-px geometry of the separate forward / backward kernels the workgroup needs 40 KB
+// of LDS instead of 75 KB and half the per-lane register state (128 VGPRs), so FOUR workgroups
+// share a CU instead of two (4 waves per SIMD).  The kernel is bound by exposed latency (plane
+// staging, tap gathers, 14 barriers per tile): measured at B12 640x192, 1 / 2 workgroups per CU
+// with the 64x16 geometry 252 / 158 us, 3 / 4 with this one 148 / 138 us although it executes
+// 14 % more VALU instructions (more halo per output pixel, less product sharing per lane).
+#ifndef MVF_FB_TW
+#define MVF_FB_TW 32
+#endif
+#ifndef MVF_FB_PX
+#define MVF_FB_PX 2
+#endif
+#ifndef MVF_FB_WAVES
+#define MVF_FB_WAVES (MVF_FB_PX == 2 ? 4 : 2)      // launch bound: waves per SIMD the register budget must allow
+#endif
+#ifndef MVF_FB_TH
+#define MVF_FB_TH 16
+#endif
+#define MVF_TILE_TW MVF_FB_TW
+#define MVF_TILE_PX MVF_FB_PX
+#define MVF_TILE_TH MVF_FB_TH
 #include "mvf_tile.hpp"
 
 namespace {
@@ -174,26 +196,27 @@ MVF_DEV void warp_slots(const WarpCtx &k, int slot0)
     warp_finish<U>(k, w);
 }
 
-// positions first .. NSTAGE-1 (position `first`-1 and below were handled by the caller)
+// positions first .. NSTAGE-1 (position 0 may have been started by the caller), two at a time;
+// waves whose lanes all lie beyond the plane at a position skip it (wave-uniform)
 MVF_DEV void warp_pair_into_lds_fb(const WarpCtx &k, int first)
 {
-    static_assert(NSTAGE == 5, "slot schedule below assumes 5 plane positions per lane");
-    // wave-uniform: is any lane of this wave inside the plane at the last position?
-    const bool tail = (((int)threadIdx.x & ~(kWave - 1)) + (NSTAGE - 1) * NT) < PH * PW;
-    if (first == 0) {
-        warp_slots<2>(k, 0);
-        warp_slots<2>(k, 2);
-        if (tail) warp_slots<1>(k, 4);
-    } else {            // position 0 was prefetched
-        warp_slots<2>(k, 1);
-        if (tail) warp_slots<2>(k, 3);
-        else warp_slots<1>(k, 3);
+#ifndef MVF_FB_WARP_U
+#define MVF_FB_WARP_U (MVF_FB_PX == 2 ? 1 : 2)     // plane positions per batch: 24 tap pairs in flight each
+#endif
+    const int wave_base = (int)threadIdx.x & ~(kWave - 1);
+    auto live = [&](int q) { return q < NSTAGE && (wave_base + q * NT) < PH * PW; };
+#pragma unroll
+    for (int q0 = 0; q0 < NSTAGE + 1; q0 += MVF_FB_WARP_U) {
+        const int q = q0 + first;
+        if (q >= NSTAGE) break;
+        if (MVF_FB_WARP_U == 2 && live(q + 1)) warp_slots<2>(k, q);
+        else if (live(q)) warp_slots<1>(k, q);
     }
 }
 
 // =============================================================================== the kernel
 template <int S, bool AVG>     // AVG: --avg_reprojection (both sources carry gradient)
-__global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
+__global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 {
     static_assert(S == 1 || S == 2, "one source pair");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -233,34 +256,6 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
     const bool rowin = (y >= 0) && (y < H);
     const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
 
-    // mask and tie-break noise of this lane's region pixels: in flight with the plane loads
-    float mraw[PX];            // mask value (1 without a mask), 0 outside the image
-    f2 nz[PX];
-#pragma unroll
-    for (int j = 0; j < PX; ++j) {
-        const int x = x0 + j;
-        const bool in = rowin && (x >= 0) && (x < W);
-        const size_t pix = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-        const size_t pi = (size_t)b * N + pix;
-        mraw[j] = in ? ((a.mask) ? a.mask[pi] : 1.0f) : 0.0f;
-        nz[j] = f2s(0.0f);
-        if (automask && in) {
-            if (a.noise) {
-                if (avg) nz[j] = f2s(a.noise[pi]);
-                else nz[j] = mk2(a.noise[((size_t)b * S) * N + pix], hasb ? a.noise[((size_t)b * S + 1) * N + pix] : 0.0f);
-            } else {
-                nz[j] = normal_pair(a.seed0, a.seed1, (uint32_t)pi);
-                if (a.noise_out) {
-                    if (avg) a.noise_out[pi] = nz[j].x;
-                    else {
-                        a.noise_out[((size_t)b * S) * N + pix] = nz[j].x;
-                        if (hasb) a.noise_out[((size_t)b * S + 1) * N + pix] = nz[j].y;
-                    }
-                }
-            }
-        }
-    }
-
     // ---- 1: target, disparity (and the identity pair) -> LDS
     if (automask) {
         stage_first(tgtP, dispP, pairP, a.tgt + (size_t)b * 3 * N, a.disp + (size_t)b * N,
@@ -287,6 +282,11 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
         k.idx_a = a.idx_xy ? a.idx_xy + ((size_t)b) * N * 2 : nullptr;
         k.idx_b = a.idx_xy ? a.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
     }
+    // (pays at 2 workgroups / CU with the 64x16 geometry; with 32x16 the 48 tap registers it
+    // pins across the identity pass push the kernel over the 3-waves/SIMD register budget)
+#if MVF_FB_PX == 2
+#define MVF_FB_NO_PREFETCH 1
+#endif
 #ifndef MVF_FB_NO_PREFETCH
     WarpBatch<1> pre;
     if (automask) warp_issue<1>(wk_ctx, 0, pre);
@@ -362,6 +362,36 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
         for (int j = 0; j < PX; ++j) {
             f2 l1 = div3(ab[j]);
             vw[j] = no_ssim ? l1 : 0.85f * div3(ss[j]) + 0.15f * l1;
+        }
+    }
+
+    // mask and tie-break noise of this lane's region pixels.  Fetched / drawn here rather than in
+    // the prologue: six registers less across the warp and SSIM phases (128-VGPR budget of 4
+    // waves per SIMD); with 4 workgroups per CU the one exposed load latency is covered
+    float mraw[PX];            // mask value (1 without a mask), 0 outside the image
+    f2 nz[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int x = x0 + j;
+        const bool in = rowin && (x >= 0) && (x < W);
+        const size_t pix = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        const size_t pi = (size_t)b * N + pix;
+        mraw[j] = in ? ((a.mask) ? a.mask[pi] : 1.0f) : 0.0f;
+        nz[j] = f2s(0.0f);
+        if (automask && in) {
+            if (a.noise) {
+                if (avg) nz[j] = f2s(a.noise[pi]);
+                else nz[j] = mk2(a.noise[((size_t)b * S) * N + pix], hasb ? a.noise[((size_t)b * S + 1) * N + pix] : 0.0f);
+            } else {
+                nz[j] = normal_pair(a.seed0, a.seed1, (uint32_t)pi);
+                if (a.noise_out) {
+                    if (avg) a.noise_out[pi] = nz[j].x;
+                    else {
+                        a.noise_out[((size_t)b * S) * N + pix] = nz[j].x;
+                        if (hasb) a.noise_out[((size_t)b * S + 1) * N + pix] = nz[j].y;
+                    }
+                }
+            }
         }
     }
 
@@ -474,8 +504,9 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
                     for (int j = 0; j < PX; ++j) hs[pl][j] = (cf[j] + cf[j + 1]) + cf[j + 2];
                 }
                 float4 *cp = reinterpret_cast<float4 *>(coefP + pl * RPPLANE + roff);
-                cp[0] = make_float4(hs[pl][0].x, hs[pl][0].y, hs[pl][1].x, hs[pl][1].y);
-                cp[1] = make_float4(hs[pl][2].x, hs[pl][2].y, hs[pl][3].x, hs[pl][3].y);
+#pragma unroll
+                for (int j = 0; j < PX; j += 2)
+                    cp[j / 2] = make_float4(hs[pl][j].x, hs[pl][j].y, hs[pl][j + 1].x, hs[pl][j + 1].y);
             }
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
@@ -510,9 +541,13 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
             for (int pl = 0; pl < 3; ++pl) {
                 const float4 *up = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff - LDW);
                 const float4 *dn = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff + LDW);
-                const float4 u0 = up[0], u1 = up[1], d0 = dn[0], d1 = dn[1];
-                const f2 uu[PX] = {mk2(u0.x, u0.y), mk2(u0.z, u0.w), mk2(u1.x, u1.y), mk2(u1.z, u1.w)};
-                const f2 dd[PX] = {mk2(d0.x, d0.y), mk2(d0.z, d0.w), mk2(d1.x, d1.y), mk2(d1.z, d1.w)};
+                f2 uu[PX], dd[PX];
+#pragma unroll
+                for (int j = 0; j < PX; j += 2) {
+                    const float4 u = up[j / 2], d = dn[j / 2];
+                    uu[j] = mk2(u.x, u.y); uu[j + 1] = mk2(u.z, u.w);
+                    dd[j] = mk2(d.x, d.y); dd[j + 1] = mk2(d.z, d.w);
+                }
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
                     const f2 t = myu * uu[j] + hs[pl][j] + myd * dd[j];
@@ -545,7 +580,7 @@ __global__ void __launch_bounds__(NT, 2) k_unit_fb(FbArgs a)
     const float cxs = a.smoothness / (float)((double)a.B * H * (W - 1));
     const float cys = a.smoothness / (float)((double)a.B * (H - 1) * W);
 #ifndef MVF_FB_UNROLL7
-#define MVF_FB_UNROLL7 4
+#define MVF_FB_UNROLL7 2
 #endif
 #pragma unroll MVF_FB_UNROLL7
     for (int k = 0; k < (TW * TH) / NT; ++k) {
