@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 5
+#define MVF_ABI_VERSION 6
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -294,6 +294,17 @@ MVF_API int mvf_disp_head_fwd(const float *logit, float *disp, float *depth, flo
 /* g_logit = (g_disp - g_depth*range*depth^2) * disp*(1-disp); g_disp / g_depth nullable */
 MVF_API int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_depth, float *g_logit,
                       int64_t n, float min_disp, float range, void *stream);
+/* On-device colour augmentation of the data pipeline (datasets/mono_dataset.py:102-184, 214-256:
+ * do_flip, do_color_aug with one torchvision ColorJitter draw per sample applied to all of its
+ * frames).  img [samples*frames,3,H,W] (frame-minor), factors [samples,4] = {brightness, contrast,
+ * saturation, hue}, order [samples,4] = the permutation of {0 brightness, 1 contrast, 2 saturation,
+ * 3 hue}, apply / flip [samples] int32 flags.  out_raw (nullable) = the flipped frames, out_aug =
+ * flipped + jittered.  workspace: mvf_color_jitter_workspace_floats(samples*frames) floats. */
+MVF_API size_t mvf_color_jitter_workspace_floats(int images);
+MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32_t *order, const int32_t *apply,
+                     const int32_t *flip, float *out_raw, float *out_aug, float *workspace, int samples,
+                     int frames, int H, int W, void *stream);
+
 /* ---- measurement hooks (bench.py) ------------------------------------------------------
  * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
  * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded

@@ -169,6 +169,117 @@ __global__ void __launch_bounds__(NT) k_disp_head_bwd(const float *__restrict__ 
     }
 }
 
+// ---- on-device colour augmentation -------------------------------------------------------------
+// MonoDataset.__getitem__ / preprocess (datasets/mono_dataset.py:102-184, 214-256): with
+// probability 1/2 a sample's frames are flipped horizontally, and with probability 1/2 all of its
+// frames get ONE torchvision ColorJitter draw (brightness, contrast, saturation in [0.8,1.2], hue
+// in [-0.1,0.1], the four adjustments in a random order).  The reference does this per item on the
+// host with PIL; here the draw (factors, order, flags) is a few numbers per sample and the pixels
+// are touched on the device: a reduction pass for the grey-level mean the contrast step blends
+// with (it depends on the adjustments ordered before it), then one streaming pass.
+// torchvision is on neither box: the adjustments restate its published float-tensor algorithms
+// (_blend / rgb_to_grayscale / _rgb2hsv / _hsv2rgb) -- parity unpinned for this glue.
+struct Rgb {
+    float r, g, b;
+};
+MVF_DEV float clamp1(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
+MVF_DEV float grey(const Rgb &c) { return 0.2989f * c.r + 0.587f * c.g + 0.114f * c.b; }
+MVF_DEV Rgb blend(const Rgb &a, const Rgb &o, float ratio)
+{
+    const float q = 1.0f - ratio;
+    return {clamp1(ratio * a.r + q * o.r), clamp1(ratio * a.g + q * o.g), clamp1(ratio * a.b + q * o.b)};
+}
+MVF_DEV Rgb adjust_hue(const Rgb &c, float f)
+{
+    const float maxc = fmaxf(c.r, fmaxf(c.g, c.b)), minc = fminf(c.r, fminf(c.g, c.b));
+    const bool eq = maxc == minc;
+    const float cr = maxc - minc;
+    const float sat = cr / (eq ? 1.0f : maxc);
+    const float dv = eq ? 1.0f : cr;
+    const float rc = (maxc - c.r) / dv, gc = (maxc - c.g) / dv, bc = (maxc - c.b) / dv;
+    float h = 0.0f;
+    if (maxc == c.r) h = bc - gc;
+    else if (maxc == c.g) h = 2.0f + rc - bc;
+    else h = 4.0f + gc - rc;
+    h = fmodf(h / 6.0f + 1.0f, 1.0f);
+    h = h + f;
+    h = h - floorf(h);                       // python-style % 1.0
+    const float h6 = h * 6.0f, fi = floorf(h6), fr = h6 - fi;
+    const int i = ((int)fi) % 6;
+    const float v = maxc;
+    const float p = clamp1(v * (1.0f - sat)), q = clamp1(v * (1.0f - sat * fr)), t = clamp1(v * (1.0f - sat * (1.0f - fr)));
+    switch (i) {
+    case 0: return {v, t, p};
+    case 1: return {q, v, p};
+    case 2: return {p, v, t};
+    case 3: return {p, q, v};
+    case 4: return {t, p, v};
+    default: return {v, p, q};
+    }
+}
+// adjustments order[0..n) of one sample; `mean` is consumed by the contrast step
+MVF_DEV Rgb jitter_chain(Rgb c, const float *__restrict__ fac, const int *__restrict__ order, int n, float mean)
+{
+    for (int k = 0; k < n; ++k) {
+        const int op = order[k];
+        if (op == 0) c = blend(c, {0.0f, 0.0f, 0.0f}, fac[0]);
+        else if (op == 1) c = blend(c, {mean, mean, mean}, fac[1]);
+        else if (op == 2) { const float g = grey(c); c = blend(c, {g, g, g}, fac[2]); }
+        else c = adjust_hue(c, fac[3]);
+    }
+    return c;
+}
+
+constexpr int JIT_NB = 64;     // reduction blocks per image
+
+// partial sums of the grey level of (image after the adjustments ordered before contrast)
+__global__ void __launch_bounds__(NT) k_jitter_mean(const float *__restrict__ img, const float *__restrict__ fac,
+                                                    const int *__restrict__ order, const int *__restrict__ apply,
+                                                    float *__restrict__ part, int N, int F)
+{
+    __shared__ float scratch[NT / kWave];
+    const int n = blockIdx.y, s = n / F;           // image, sample
+    float acc = 0.0f;
+    if (apply[s]) {
+        int pre = 0;
+        while (pre < 4 && order[s * 4 + pre] != 1) ++pre;
+        const float *p = img + (size_t)n * 3 * N;
+        for (int i = blockIdx.x * NT + threadIdx.x; i < N; i += JIT_NB * NT) {
+            Rgb c = {p[i], p[N + i], p[2 * (size_t)N + i]};
+            acc += grey(jitter_chain(c, fac + s * 4, order + s * 4, pre, 0.0f));
+        }
+    }
+    const float r = block_sum<NT>(acc, scratch);
+    if (threadIdx.x == 0) part[(size_t)n * JIT_NB + blockIdx.x] = r;
+}
+
+// out_raw (nullable) = flipped copy; out_aug = flipped + jittered (copy when apply == 0)
+__global__ void __launch_bounds__(NT) k_jitter_apply(const float *__restrict__ img, const float *__restrict__ fac,
+                                                     const int *__restrict__ order, const int *__restrict__ apply,
+                                                     const int *__restrict__ flip, const float *__restrict__ part,
+                                                     float *__restrict__ out_raw, float *__restrict__ out_aug, int H,
+                                                     int W, int F)
+{
+    __shared__ float smean;
+    const int N = H * W, n = blockIdx.y, s = n / F;
+    if (threadIdx.x == 0) {
+        double m = 0.0;
+        for (int k = 0; k < JIT_NB; ++k) m += (double)part[(size_t)n * JIT_NB + k];
+        smean = (float)(m / (double)N);
+    }
+    __syncthreads();
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    const int y = i / W, x = i - y * W;
+    const int sx = flip[s] ? W - 1 - x : x;
+    const float *p = img + (size_t)n * 3 * N + (size_t)y * W + sx;
+    Rgb c = {p[0], p[N], p[2 * (size_t)N]};
+    const size_t o = (size_t)n * 3 * N + i;
+    if (out_raw) { out_raw[o] = c.r; out_raw[o + N] = c.g; out_raw[o + 2 * (size_t)N] = c.b; }
+    if (apply[s]) c = jitter_chain(c, fac + s * 4, order + s * 4, 4, smean);
+    out_aug[o] = c.r; out_aug[o + N] = c.g; out_aug[o + 2 * (size_t)N] = c.b;
+}
+
 }  // namespace
 
 extern "C" {
@@ -217,6 +328,24 @@ int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_dep
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_disp_head_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, disp, g_disp,
                        g_depth, g_logit, n, min_disp, range);
+    return hip_check_launch();
+}
+
+size_t mvf_color_jitter_workspace_floats(int images) { return (size_t)images * JIT_NB; }
+
+int mvf_color_jitter(const float *img, const float *factors, const int32_t *order, const int32_t *apply,
+                     const int32_t *flip, float *out_raw, float *out_aug, float *workspace, int samples,
+                     int frames, int H, int W, void *stream)
+{
+    if (samples <= 0 || frames <= 0 || H <= 0 || W <= 0) return 0;
+    if (!img || !factors || !order || !apply || !flip || !out_aug || !workspace || samples * frames > 65535)
+        return (int)hipErrorInvalidValue;
+    const int n = samples * frames, N = H * W;
+    hipLaunchKernelGGL(k_jitter_mean, dim3(JIT_NB, (unsigned)n), dim3(NT), 0, (hipStream_t)stream, img, factors,
+                       order, apply, workspace, N, frames);
+    hipLaunchKernelGGL(k_jitter_apply, dim3((unsigned)((N + NT - 1) / NT), (unsigned)n), dim3(NT), 0,
+                       (hipStream_t)stream, img, factors, order, apply, flip, workspace, out_raw, out_aug, H, W,
+                       frames);
     return hip_check_launch();
 }
 

@@ -16,9 +16,15 @@ from . import synthetic
 
 
 class SyntheticTripletDataset(Dataset):
-    def __init__(self, height, width, length=39810, use_affine=True, seed=1234):
+    """``device_augment`` (default): an item carries the three raw frames, the intrinsics, the
+    affine metadata and the per-item augmentation DRAW (flip / jitter flags, ColorJitter factors
+    and order: mono-vifi_amd/augment.py); the pixels are flipped, jittered and affine-warped on
+    the device by ``Trainer.process_batch``.  False: the host builds every view (round-1 form)."""
+
+    def __init__(self, height, width, length=39810, use_affine=True, seed=1234, device_augment=True):
         self.height, self.width, self.length = height, width, length
         self.use_affine, self.seed = use_affine, seed
+        self.device_augment = bool(device_augment)
 
     def __len__(self):
         return self.length
@@ -26,6 +32,12 @@ class SyntheticTripletDataset(Dataset):
     def __getitem__(self, index):
         b = synthetic.training_batch(self.seed * 1000003 + index, 1, self.height, self.width)
         item = {}
+        if self.device_augment:
+            from . import augment
+            draw = augment.draw_params(np.random.default_rng(self.seed * 7919 + index), 1)
+            b = {k: v for k, v in b.items()
+                 if not (isinstance(k, tuple) and k[0] in ("color_aug", "color_affine", "color_affine_aug"))}
+            b.update(draw)
         for k, v in b.items():
             t = torch.from_numpy(np.ascontiguousarray(v[0]))
             item[k] = t

@@ -850,3 +850,27 @@ def disp_head(logit, min_depth=0.1, max_depth=100.0, want_depth=True):
     """-> (disp, depth | None, mean_partials)"""
     disp, depth, part = DispHead.apply(logit, min_depth, max_depth, bool(want_depth))
     return disp, (depth if want_depth else None), part
+
+
+def color_jitter(img, factors, order, apply, flip, frames=1, want_raw=False):
+    """Flip + torchvision-style ColorJitter for a batch on the device (reference: the per-item
+    host work of datasets/mono_dataset.py:214-256).  img [samples*frames,3,H,W] with the frames of
+    a sample adjacent; factors [samples,4], order [samples,4] int32, apply / flip [samples] int32.
+    -> (flipped frames | None, flipped + jittered frames).  No gradient (input data)."""
+    nat.require_device(img, factors, order, apply, flip)
+    img = _c(img.detach())
+    n, ch, H, W = img.shape
+    if ch != 3 or n % frames:
+        raise RuntimeError("color_jitter expects [samples*frames,3,H,W]")
+    S = n // frames
+    factors = factors.to(torch.float32).contiguous()
+    order, apply, flip = (t.to(torch.int32).contiguous() for t in (order, apply, flip))
+    if tuple(factors.shape) != (S, 4) or tuple(order.shape) != (S, 4) or apply.numel() != S or flip.numel() != S:
+        raise RuntimeError("color_jitter: factors / order must be [samples,4], apply / flip [samples]")
+    raw = torch.empty_like(img) if want_raw else None
+    aug = torch.empty_like(img)
+    ws = torch.empty(nat.lib().mvf_color_jitter_workspace_floats(n), dtype=torch.float32, device=img.device)
+    nat.check(nat.lib().mvf_color_jitter(nat.ptr(img), nat.ptr(factors), nat.ptr(order), nat.ptr(apply),
+                                         nat.ptr(flip), nat.ptr(raw), nat.ptr(aug), nat.ptr(ws), S, frames, H, W,
+                                         _stream()), "color_jitter")
+    return raw, aug

@@ -106,6 +106,9 @@ def build_parser():
     p.add_argument("--fused_units", type=_str2bool, default=True,
                    help="fused unit kernels (warped images in LDS) instead of the staged "
                         "generate_images_pred + compute_losses_base pair")
+    p.add_argument("--device_augment", type=_str2bool, default=True,
+                   help="flip / ColorJitter / affine views of a batch on the device (augment.py) instead "
+                        "of per item on the host (reference: datasets/mono_dataset.py:102-184)")
     p.add_argument("--inkernel_noise", type=_str2bool, default=True,
                    help="auto-mask tie-break noise (train.py:1023-1024) drawn inside the unit kernel "
                         "from a counter-based generator instead of a torch.randn tensor per unit")

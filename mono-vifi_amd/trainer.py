@@ -101,7 +101,9 @@ class Trainer(HotPathLosses):
                 "only --synthetic True is available: the KITTI/Cityscapes loaders of the "
                 "reference need data and libraries neither box has (DESIGN.md section 9)")
         train_dataset = datasets.SyntheticTripletDataset(o.height, o.width, o.synthetic_len,
-                                                         o.use_affine, o.seed)
+                                                         o.use_affine, o.seed,
+                                                         device_augment=o.device_augment and
+                                                         torch.cuda.is_available())
         self.num_steps_per_epoch = len(train_dataset) // o.world_size // o.batch_size
         self.num_total_steps = self.num_steps_per_epoch * o.num_epochs
         if o.world_size > 1:
@@ -425,6 +427,11 @@ class Trainer(HotPathLosses):
         for key, ipt in inputs.items():
             if torch.is_tensor(ipt):
                 inputs[key] = ipt.to(self.device, non_blocking=True)
+        if ("color_aug", 0, 0) not in inputs:
+            # the loader delivered raw frames + the augmentation draw: flip / ColorJitter / affine
+            # views happen here, on the device (reference: datasets/mono_dataset.py:102-184)
+            from . import augment
+            augment.augment_on_device(inputs, use_affine=o.use_affine)
         B = inputs[("color", 0, 0)].shape[0]
         embt = torch.full((B, 1, 1, 1), 0.5, device=self.device)
         img_n1, img_p1, img_0 = inputs[("color", -1, 0)], inputs[("color", 1, 0)], inputs[("color", 0, 0)]

@@ -429,3 +429,62 @@ def fusion_backward(feats, flows, mask, gouts):
         g_p1.append(flow_warp_bwd(feats[2][i], _warp_flow(flows[1], H, W), xs, ys,
                                   np.ascontiguousarray((np.float32(1.0) - m) * gw))[0])
     return g_n1, g_0, g_p1
+
+
+# --------------------------------------------------------------------------- f4: colour augmentation
+def color_jitter(img, factors, order, apply, flip, frames=1):
+    """Flip + ColorJitter of datasets/mono_dataset.py:214-256 on float images, restating
+    torchvision's published float-tensor algorithms (_blend, rgb_to_grayscale, _rgb2hsv, _hsv2rgb;
+    parity unpinned: torchvision is absent).  img [samples*frames,3,H,W] -> (raw flipped, augmented)."""
+    f32 = np.float32
+    img = _f(img)
+    raw = img.copy()
+    out = img.copy()
+
+    def grey(c):
+        return (f32(0.2989) * c[0] + f32(0.587) * c[1] + f32(0.114) * c[2]).astype(f32)
+
+    def blend(a, o, r):
+        return np.clip(f32(r) * a + (f32(1.0) - f32(r)) * o, 0, 1).astype(f32)
+
+    def hue(c, f):
+        r, g, b = c
+        maxc, minc = np.maximum(r, np.maximum(g, b)), np.minimum(r, np.minimum(g, b))
+        eq = maxc == minc
+        cr = (maxc - minc).astype(f32)
+        sat = (cr / np.where(eq, f32(1), maxc)).astype(f32)
+        dv = np.where(eq, f32(1), cr).astype(f32)
+        rc, gc, bc = ((maxc - r) / dv).astype(f32), ((maxc - g) / dv).astype(f32), ((maxc - b) / dv).astype(f32)
+        h = np.where(maxc == r, bc - gc, np.where(maxc == g, f32(2) + rc - bc, f32(4) + gc - rc)).astype(f32)
+        h = np.fmod(h / f32(6) + f32(1), f32(1)).astype(f32)
+        h = (h + f32(f)).astype(f32)
+        h = (h - np.floor(h)).astype(f32)
+        h6 = (h * f32(6)).astype(f32)
+        fi = np.floor(h6)
+        fr = (h6 - fi).astype(f32)
+        i = fi.astype(np.int64) % 6
+        v = maxc
+        p = np.clip(v * (f32(1) - sat), 0, 1).astype(f32)
+        q = np.clip(v * (f32(1) - sat * fr), 0, 1).astype(f32)
+        t = np.clip(v * (f32(1) - sat * (f32(1) - fr)), 0, 1).astype(f32)
+        a1 = np.choose(i, [v, q, p, p, t, v])
+        a2 = np.choose(i, [t, v, v, q, p, p])
+        a3 = np.choose(i, [p, p, t, v, v, q])
+        return np.stack([a1, a2, a3], 0).astype(f32)
+
+    for n in range(img.shape[0]):
+        s = n // frames
+        c = img[n, :, :, ::-1].copy() if flip[s] else img[n].copy()
+        raw[n] = c
+        if apply[s]:
+            for op in order[s]:
+                if op == 0:
+                    c = blend(c, np.zeros_like(c), factors[s][0])
+                elif op == 1:
+                    c = blend(c, f32(np.mean(grey(c), dtype=np.float64)), factors[s][1])
+                elif op == 2:
+                    c = blend(c, grey(c)[None], factors[s][2])
+                else:
+                    c = hue(c, factors[s][3])
+        out[n] = c
+    return raw, out

@@ -870,3 +870,55 @@ def test_decoder_fused_glue_equals_stock_ops(dev):
         assert float((a - b).norm() / b.norm()) <= 1e-4
     from mono_vifi_amd import layers
     assert float(((res[True][3] - layers.disp_to_depth(res[True][0][0], 0.1, 100.0)[1]) / res[True][3]).abs().max()) <= 1e-6
+
+
+# ------------------------------------------------------------------ f4: on-device augmentation
+def test_color_jitter_vs_oracle(dev):
+    """mvf_color_jitter (flip + ColorJitter of datasets/mono_dataset.py:214-256 for a batch on the
+    device) against the oracle's restatement of torchvision's float algorithm: every adjustment
+    order, with / without jitter, with / without flip, three frames per sample sharing a draw."""
+    import itertools
+    from mono_vifi_amd import augment, ops
+    rng = np.random.default_rng(51)
+    perms = list(itertools.permutations(range(4)))
+    S, F, H, W = len(perms) + 2, 3, 20, 36
+    img = rng.random((S * F, 3, H, W)).astype(np.float32)
+    img[0, :, :4] = 0.5                      # grey pixels: max == min in the hue conversion
+    p = augment.draw_params(rng, S)
+    p["aug_order"][:len(perms)] = np.array(perms, np.int32)
+    p["aug_apply"][:len(perms)] = 1
+    p["aug_apply"][len(perms)] = 0
+    raw_w, aug_w = O.color_jitter(img, p["aug_factors"], p["aug_order"], p["aug_apply"], p["aug_flip"], F)
+    raw, aug = ops.color_jitter(T(img, dev), T(p["aug_factors"], dev), T(p["aug_order"], dev),
+                                T(p["aug_apply"], dev), T(p["aug_flip"], dev), frames=F, want_raw=True)
+    assert np.array_equal(N(raw), raw_w)
+    err = np.abs(N(aug) - aug_w)
+    # the hue step is discontinuous where two channels tie for the maximum: allow a handful of pixels
+    assert np.mean(err > 2e-5) <= 1e-4 and float(np.median(err)) <= 1e-6
+    assert np.array_equal(N(aug)[len(perms) * F:(len(perms) + 1) * F], raw_w[len(perms) * F:(len(perms) + 1) * F])
+
+
+def test_augment_on_device_fills_the_batch_contract(dev):
+    """augment_on_device turns raw frames + the per-sample draw into the keys process_batch reads
+    (SURVEY.md section 3.4): color / color_aug / color_affine / color_affine_aug per frame."""
+    from mono_vifi_amd import augment, ops, synthetic
+    B, H, W = 3, 64, 96
+    b = synthetic.training_batch(9, B, H, W)
+    rng = np.random.default_rng(2)
+    inputs = {("color", f, 0): T(b[("color", f, 0)], dev) for f in (-1, 0, 1)}
+    inputs.update({k: T(v, dev) for k, v in augment.draw_params(rng, B).items()})
+    inputs["angle"], inputs["box"] = T(b["angle"], dev), T(b["box"].astype(np.int32), dev)
+    src = {f: inputs[("color", f, 0)].clone() for f in (-1, 0, 1)}
+    out = augment.augment_on_device(inputs, use_affine=True)
+    flip = N(inputs["aug_flip"]).astype(bool)
+    for f in (-1, 0, 1):
+        want = torch.where(T(flip, dev).view(B, 1, 1, 1), src[f].flip(-1), src[f])
+        assert torch.equal(out[("color", f, 0)], want)
+        for key in ("color_aug", "color_affine", "color_affine_aug"):
+            t = out[(key, f, 0)]
+            assert tuple(t.shape) == (B, 3, H, W) and bool(torch.isfinite(t).all())
+            assert float(t.min()) >= 0.0 and float(t.max()) <= 1.0
+        same = N(inputs["aug_apply"]) == 0
+        assert torch.equal(out[("color_aug", f, 0)][T(same, dev)], out[("color", f, 0)][T(same, dev)])
+        ref_aff = ops.affine_transform(out[("color", f, 0)], inputs["angle"], inputs["box"])
+        assert torch.equal(out[("color_affine", f, 0)], ref_aff)
