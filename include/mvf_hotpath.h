@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 6
+#define MVF_ABI_VERSION 7
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -237,6 +237,14 @@ MVF_API int mvf_fusion_level_fwd(const float *feat_0, const float *feat_n1, cons
  * caller: scatter-add).  grad of feat_0 is g_out[:, :C] itself; flows and mask carry no gradient. */
 MVF_API int mvf_fusion_level_bwd(const float *g_out, const float *prep, const float *xs, const float *ys,
                          float *g_feat_n1, float *g_feat_p1, int B, int C, int h, int w, void *stream);
+/* The same gradients WITHOUT float atomics (bit-reproducible): an inverse tap list per destination
+ * pixel is built from the flows (count / scan / fill / sort, integer work only) and every channel
+ * gathers through it in a fixed order.  g_feat_* are overwritten (no zero-initialisation needed).
+ * workspace: mvf_fusion_bwd_workspace_ints(B,h,w) int32. */
+MVF_API size_t mvf_fusion_bwd_workspace_ints(int B, int h, int w);
+MVF_API int mvf_fusion_level_bwd_gather(const float *g_out, const float *prep, const float *xs, const float *ys,
+                                float *g_feat_n1, float *g_feat_p1, int32_t *workspace, int B, int C, int h,
+                                int w, void *stream);
 
 /* ---- f2: Trainer.compute_SI_log_depth_loss (train.py:924-941) ----
  * pred, target [B,1,H,W] (N = H*W), mask nullable [B,1,H,W] (same shape; any batch size).

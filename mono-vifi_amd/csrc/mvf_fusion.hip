@@ -198,6 +198,166 @@ __global__ void __launch_bounds__(NT) k_fusion_level_bwd(const float *__restrict
     }
 }
 
+// ---- deterministic backward: the scatter turned into a gather through an inverse tap list --------
+// grad_feat[b,c,q] = sum over output pixels p whose bilinear taps touch q of  w(p->q) * m(p) * g[b,c,p].
+// Which p touch q depends only on the flow (not on the channel), so the inverse map is built once
+// per level and source -- a CSR list per destination pixel: count (integer atomics: order-free),
+// exclusive scan, fill, then each (short) list is sorted by p -- and every channel then GATHERS
+// through it in that fixed order: no float atomics, bit-reproducible, and the 64..512 channels of
+// a level read g the way the forward warp reads its features.
+// ws ints per level: cnt [2][B][N] | off [2][B][N+1] | entries (p, w bits) [2][B][4N][2]
+struct InvWs {
+    int *cnt, *off;
+    int2 *ent;
+};
+MVF_DEV InvWs inv_ws(int *ws, int B, int N)
+{
+    InvWs r;
+    r.cnt = ws;
+    r.off = ws + (size_t)2 * B * N;
+    r.ent = reinterpret_cast<int2 *>(r.off + (size_t)2 * B * (N + 1));
+    return r;
+}
+// the (up to) four destination cells of output pixel (b, i) for source s, zero-weight taps dropped
+struct Dest {
+    int cell[4];
+    float w[4];
+    int n;
+};
+MVF_DEV Dest dest_of(const float *__restrict__ prep, const float *__restrict__ xs, const float *__restrict__ ys,
+                     int b, int s, int i, int h, int w)
+{
+    const int n = h * w, y = i / w, x = i - y * w;
+    const float *pp = prep + (size_t)b * PREP * n + i;
+    const Tap t = flow_tap_xy(pp[(size_t)(4 + 2 * s) * n], pp[(size_t)(5 + 2 * s) * n], xs, ys, x, y, h, w);
+    const float m = pp[8 * (size_t)n];
+    const float sc = (s == 0) ? m : 1.0f - m;            // merge weight of this source
+    const float fw = t.wx, fe = 1.0f - fw, fn = t.wy, fs = 1.0f - fn;
+    const float wt[4] = {fs * fe, fs * fw, fn * fe, fn * fw};
+    const int cl[4] = {t.y0 * w + t.x0, t.y0 * w + t.x1, t.y1 * w + t.x0, t.y1 * w + t.x1};
+    Dest d;
+    d.n = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // border clamping can map two taps to one cell (x1 == x0 at the right edge): the clamped
+        // tap always carries weight 0 there and is dropped, so a pixel lists a cell at most once
+        if (wt[k] != 0.0f) { d.cell[d.n] = cl[k]; d.w[d.n] = wt[k] * sc; ++d.n; }
+    }
+    return d;
+}
+
+// grid (pixel blocks, B, 2 sources)
+__global__ void __launch_bounds__(NT) k_inv_count(const float *__restrict__ prep, const float *__restrict__ xs,
+                                                  const float *__restrict__ ys, int *__restrict__ ws, int B, int h, int w)
+{
+    const int n = h * w, i = blockIdx.x * NT + threadIdx.x, b = blockIdx.y, s = blockIdx.z;
+    if (i >= n) return;
+    const InvWs W = inv_ws(ws, B, n);
+    const Dest d = dest_of(prep, xs, ys, b, s, i, h, w);
+    int *cnt = W.cnt + ((size_t)s * B + b) * n;
+    for (int k = 0; k < d.n; ++k) atomicAdd(cnt + d.cell[k], 1);
+}
+
+// exclusive scan of the counts of one (source, image) per block; off has N+1 entries.  Every lane
+// owns a contiguous run of cells (local sums), ONE block-level scan of the 1024 run totals follows
+__global__ void __launch_bounds__(1024) k_inv_scan(int *__restrict__ ws, int B, int n)
+{
+    __shared__ int sh[1024];
+    const InvWs W = inv_ws(ws, B, n);
+    const int *cnt = W.cnt + (size_t)blockIdx.x * n;
+    int *off = W.off + (size_t)blockIdx.x * (n + 1);
+    const int per = (n + 1023) / 1024;
+    const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+    int tot = 0;
+    for (int i = lo; i < hi; ++i) tot += cnt[i];
+    sh[threadIdx.x] = tot;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {                   // Hillis-Steele inclusive scan of the run totals
+        const int t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int run = sh[threadIdx.x] - tot;                        // exclusive prefix of this lane's run
+    for (int i = lo; i < hi; ++i) {
+        off[i] = run;
+        run += cnt[i];
+    }
+    if (threadIdx.x == 1023) off[n] = sh[1023];
+}
+
+__global__ void __launch_bounds__(NT) k_inv_fill(const float *__restrict__ prep, const float *__restrict__ xs,
+                                                 const float *__restrict__ ys, int *__restrict__ ws, int B, int h, int w)
+{
+    const int n = h * w, i = blockIdx.x * NT + threadIdx.x, b = blockIdx.y, s = blockIdx.z;
+    if (i >= n) return;
+    const InvWs W = inv_ws(ws, B, n);
+    const Dest d = dest_of(prep, xs, ys, b, s, i, h, w);
+    const size_t sb = (size_t)s * B + b;
+    int *cur = W.cnt + sb * n;                              // zeroed again by the caller: the cursor
+    const int *off = W.off + sb * (n + 1);
+    int2 *ent = W.ent + sb * 4 * n;
+    for (int k = 0; k < d.n; ++k) {
+        const int slot = off[d.cell[k]] + atomicAdd(cur + d.cell[k], 1);
+        ent[slot] = make_int2(i, __float_as_int(d.w[k]));
+    }
+}
+
+// every destination cell sorts its list by source pixel (insertion sort; lists average 4 entries)
+__global__ void __launch_bounds__(NT) k_inv_sort(int *__restrict__ ws, int B, int n)
+{
+    const int q = blockIdx.x * NT + threadIdx.x;
+    if (q >= n) return;
+    const InvWs W = inv_ws(ws, B, n);
+    const size_t sb = blockIdx.y;
+    const int *off = W.off + sb * (n + 1);
+    int2 *ent = W.ent + sb * 4 * n;
+    const int lo = off[q], hi = off[q + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+        const int2 v = ent[a];
+        int c = a - 1;
+        while (c >= lo && ent[c].x > v.x) { ent[c + 1] = ent[c]; --c; }
+        ent[c + 1] = v;
+    }
+}
+
+// grid (pixel blocks, channel chunks, B): both sources per lane
+__global__ void __launch_bounds__(NT) k_fusion_level_bwd_gather(const float *__restrict__ g_out,
+                                                                const int *__restrict__ ws,
+                                                                float *__restrict__ g_fn1,
+                                                                float *__restrict__ g_fp1, int B, int C, int h, int w)
+{
+    const int n = h * w, q = blockIdx.x * NT + threadIdx.x, b = blockIdx.z;
+    if (q >= n) return;
+    const InvWs W = inv_ws(const_cast<int *>(ws), B, n);
+    const int CT = 2 * (C + EMB);
+    const int c0 = blockIdx.y * CCH, nc = min(CCH, C - c0);
+    const float *gb = g_out + ((size_t)b * CT + C + EMB + c0) * n;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        float *dst = (s == 0) ? g_fn1 : g_fp1;
+        if (!dst) continue;
+        const size_t sb = (size_t)s * B + b;
+        const int *off = W.off + sb * (n + 1);
+        const int2 *ent = W.ent + sb * 4 * n;
+        const int lo = off[q], hi = off[q + 1];
+        float acc[CCH];
+#pragma unroll
+        for (int k = 0; k < CCH; ++k) acc[k] = 0.0f;
+        for (int e = lo; e < hi; ++e) {
+            const int2 v = ent[e];
+            const float wgt = __int_as_float(v.y);
+            const float *gp = gb + v.x;
+#pragma unroll
+            for (int k = 0; k < CCH; ++k)
+                if (k < nc) acc[k] += wgt * gp[(size_t)k * n];
+        }
+#pragma unroll
+        for (int k = 0; k < CCH; ++k)
+            if (k < nc) dst[((size_t)b * C + c0 + k) * n + q] = acc[k];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -241,6 +401,37 @@ int mvf_fusion_level_bwd(const float *g_out, const float *prep, const float *xs,
     const int nchunk = (C + CCH - 1) / CCH;
     hipLaunchKernelGGL(k_fusion_level_bwd, dim3((unsigned)((h * w + NT - 1) / NT), (unsigned)nchunk, (unsigned)B),
                        dim3(NT), 0, (hipStream_t)stream, g_out, prep, xs, ys, g_feat_n1, g_feat_p1, C, h, w);
+    return hip_check_launch();
+}
+
+size_t mvf_fusion_bwd_workspace_ints(int B, int h, int w)
+{
+    const size_t n = (size_t)h * w;
+    return (size_t)2 * B * n + (size_t)2 * B * (n + 1) + (size_t)2 * B * 4 * n * 2 + 16;
+}
+
+int mvf_fusion_level_bwd_gather(const float *g_out, const float *prep, const float *xs, const float *ys,
+                                float *g_feat_n1, float *g_feat_p1, int32_t *workspace, int B, int C, int h, int w,
+                                void *stream)
+{
+    if (B <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+    if (!g_out || !prep || !xs || !ys || !workspace || B > 32767) return (int)hipErrorInvalidValue;
+    if (!g_feat_n1 && !g_feat_p1) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = h * w;
+    const dim3 gp((unsigned)((n + NT - 1) / NT), (unsigned)B, 2);
+    const size_t cnt_bytes = (size_t)2 * B * n * sizeof(int);
+    hipError_t e = hipMemsetAsync(workspace, 0, cnt_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_inv_count, gp, dim3(NT), 0, st, prep, xs, ys, workspace, B, h, w);
+    hipLaunchKernelGGL(k_inv_scan, dim3((unsigned)(2 * B)), dim3(1024), 0, st, workspace, B, n);
+    e = hipMemsetAsync(workspace, 0, cnt_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_inv_fill, gp, dim3(NT), 0, st, prep, xs, ys, workspace, B, h, w);
+    hipLaunchKernelGGL(k_inv_sort, dim3((unsigned)((n + NT - 1) / NT), (unsigned)(2 * B)), dim3(NT), 0, st, workspace, B, n);
+    const int nchunk = (C + CCH - 1) / CCH;
+    hipLaunchKernelGGL(k_fusion_level_bwd_gather, dim3((unsigned)((n + NT - 1) / NT), (unsigned)nchunk, (unsigned)B),
+                       dim3(NT), 0, st, g_out, workspace, g_feat_n1, g_feat_p1, B, C, h, w);
     return hip_check_launch();
 }
 

@@ -568,6 +568,7 @@ def flow_warp_indices(img_shape, flow):
 
 # ------------------------------------------------------------------ f1 fusion module
 EMB_CH = 42     # Embedder: 2 * (1 + 2 * 10) channels (reference fusion_module.py:43-52)
+FUSION_BWD_GATHER = True     # False: the atomic scatter (mvf_fusion_level_bwd); tests compare both
 
 
 def fusion_prep(flow_n1, flow_p1, mask, sizes, litemono=False):
@@ -622,6 +623,15 @@ class FusionLevel(torch.autograd.Function):
         B, Cc, h, w = ctx.dims
         g = _c(g)
         g0 = g[:, :Cc] if ctx.needs_input_grad[0] else None
+        if FUSION_BWD_GATHER:
+            # deterministic: inverse tap lists (integer work) + a gather per channel, no float atomics
+            gn = torch.empty((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
+            gp = torch.empty((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+            ws = torch.empty(nat.lib().mvf_fusion_bwd_workspace_ints(B, h, w), dtype=torch.int32, device=g.device)
+            nat.check(nat.lib().mvf_fusion_level_bwd_gather(nat.ptr(g), nat.ptr(prep), nat.ptr(xs), nat.ptr(ys),
+                                                            nat.ptr(gn), nat.ptr(gp), nat.ptr(ws), B, Cc, h, w,
+                                                            _stream()), "fusion_level_bwd_gather")
+            return g0, gn, gp, None
         gn = torch.zeros((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
         gp = torch.zeros((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
         nat.check(nat.lib().mvf_fusion_level_bwd(nat.ptr(g), nat.ptr(prep), nat.ptr(xs), nat.ptr(ys),

@@ -684,8 +684,23 @@ def _fusion_case(g):
     return L, feats, [g["flow_n1"], g["flow_p1"]], g["mask"], str(g["backbone"]) == "LiteMono"
 
 
+@pytest.fixture
+def fusion_bwd(request):
+    """Backward route of the fused fusion levels: "gather" (deterministic inverse-tap-list gather,
+    the default) or "scatter" (float atomics)."""
+    from mono_vifi_amd import ops
+    old = ops.FUSION_BWD_GATHER
+    ops.FUSION_BWD_GATHER = request.param == "gather"
+    yield request.param
+    ops.FUSION_BWD_GATHER = old
+
+
+BOTH_FUSION_BWD = pytest.mark.parametrize("fusion_bwd", ["gather", "scatter"], indirect=True)
+
+
+@BOTH_FUSION_BWD
 @pytest.mark.parametrize("case", ["resnet", "litemono", "dhrnet"])
-def test_fusion_levels_vs_golden(dev, case):
+def test_fusion_levels_vs_golden(dev, case, fusion_bwd):
     """mvf_fusion_prep + mvf_fusion_level_fwd/bwd against what the reference's FusionModule
     methods produced (G9): the tensor entering each 1x1 convolution and the gradients of the
     three feature pyramids.  Embedding bands multiply their argument by up to 2^9, so they get
@@ -712,8 +727,9 @@ def test_fusion_levels_vs_golden(dev, case):
         assert rel_err(N(tf[2][i].grad), g[f"grad_p1_{i}"]) <= 1e-5
 
 
+@BOTH_FUSION_BWD
 @pytest.mark.parametrize("pyr", ["resnet18_640x192", "dhrnet_512x192", "litemono_1024x320"])
-def test_fusion_levels_full_pyramids_vs_oracle(dev, pyr):
+def test_fusion_levels_full_pyramids_vs_oracle(dev, pyr, fusion_bwd):
     """The pyramids of BASELINE.json's configs (ResNet18 640x192, HRNet18 512x192 Cityscapes,
     Lite-Mono 1024x320) against the oracle, forward and feature gradients."""
     from mono_vifi_amd import ops
@@ -736,6 +752,12 @@ def test_fusion_levels_full_pyramids_vs_oracle(dev, pyr):
     preps = ops.fusion_prep(T(flows[0], dev), T(flows[1], dev), T(mask, dev), sizes, lite)
     outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i]) for i in range(len(chans))]
     sum((o * T(wts[i], dev)).sum() for i, o in enumerate(outs)).backward()
+    if fusion_bwd == "gather":       # bit-reproducible: a second backward gives the same bits
+        tf2 = [[T(f, dev, True) for f in lvl] for lvl in feats]
+        outs2 = [ops.fusion_level(tf2[1][i], tf2[0][i], tf2[2][i], preps[i]) for i in range(len(chans))]
+        sum((o * T(wts[i], dev)).sum() for i, o in enumerate(outs2)).backward()
+        for i in range(len(chans)):
+            assert torch.equal(tf[0][i].grad, tf2[0][i].grad) and torch.equal(tf[2][i].grad, tf2[2][i].grad)
     for i, Cc in enumerate(chans):
         got = N(outs[i])
         assert np.max(np.abs(got[:, :2 * Cc + 42] - want[i][:, :2 * Cc + 42])) <= 2e-5
