@@ -306,6 +306,10 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     }
 
     // ---- 3: fused warp of the source pair
+#ifdef MVF_ABL_NOWARP    // timing ablation: the raw sources instead of the warped pair
+    stage_pair3(pairP, wk_ctx.sa, wk_ctx.sb, N, H, W, py0, px0);
+    if (false)
+#endif
 #ifndef MVF_FB_NO_PREFETCH
     if (automask) {
         warp_finish<1>(wk_ctx, pre);
