@@ -476,10 +476,29 @@ MVF_DEV float refl_mult(int p, int q, int n)
 }
 
 // ------------------------------------------------------------------------------- reductions
-MVF_DEV float wave_sum(float v)
+// Wavefront sum on the DPP path (no LDS crossbar): four row-shift steps leave each 16-lane row's
+// total in its last lane, two row broadcasts fold the rows; the total is valid in LANE 63 only.
+// (hipcc lowers __shfl_down to ds_bpermute: 6 LDS operations per value; a workgroup reduction of
+// 27 values was 162 of them.)  The empty asm keeps each DPP move a separate instruction.
+MVF_DEV float dpp_add(float v, int ctrl_is /*0: shr1, 1: shr2, 2: shr4, 3: shr8, 4: bcast15, 5: bcast31*/)
+{
+    int r;
+    const int x = __builtin_bit_cast(int, v);
+    switch (ctrl_is) {
+    case 0: r = __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); break;
+    case 1: r = __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); break;
+    case 2: r = __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); break;
+    case 3: r = __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); break;
+    case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); break;
+    default: r = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); break;
+    }
+    asm volatile("" : "+v"(r));
+    return v + __builtin_bit_cast(float, r);
+}
+MVF_DEV float wave_sum(float v)      // result in lane 63
 {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int k = 0; k < 6; ++k) v = dpp_add(v, k);
     return v;
 }
 
@@ -491,7 +510,7 @@ MVF_DEV float block_sum(float v, float *scratch)
     v = wave_sum(v);
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     __syncthreads();
-    if (lane == 0) scratch[wid] = v;
+    if (lane == 63) scratch[wid] = v;
     __syncthreads();
     float r = 0.0f;
     if (threadIdx.x == 0) {
@@ -513,7 +532,7 @@ MVF_DEV float block_sum_many(const float (&v)[NV], float *scratch)
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         float s = wave_sum(v[q]);
-        if (lane == 0) scratch[wid * NV + q] = s;
+        if (lane == 63) scratch[wid * NV + q] = s;
     }
     __syncthreads();
     float r = 0.0f;
