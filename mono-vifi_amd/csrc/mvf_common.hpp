@@ -479,7 +479,7 @@ MVF_DEV float refl_mult(int p, int q, int n)
 // Wavefront sum on the DPP path (no LDS crossbar): four row-shift steps leave each 16-lane row's
 // total in its last lane, two row broadcasts fold the rows; the total is valid in LANE 63 only.
 // (hipcc lowers __shfl_down to ds_bpermute: 6 LDS operations per value; a workgroup reduction of
-// 27 values was 162 of them.)  The empty asm keeps each DPP move a separate instruction.
+// 27 values was 162 of them.)  The compiler folds each move into its add (v_add_f32_dpp).
 MVF_DEV float dpp_add(float v, int ctrl_is /*0: shr1, 1: shr2, 2: shr4, 3: shr8, 4: bcast15, 5: bcast31*/)
 {
     int r;
@@ -492,7 +492,9 @@ MVF_DEV float dpp_add(float v, int ctrl_is /*0: shr1, 1: shr2, 2: shr4, 3: shr8,
     case 4: r = __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); break;
     default: r = __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); break;
     }
+#ifdef MVF_PIN_DPP
     asm volatile("" : "+v"(r));
+#endif
     return v + __builtin_bit_cast(float, r);
 }
 MVF_DEV float wave_sum(float v)      // result in lane 63
