@@ -300,7 +300,7 @@ def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n):
     # minimum traffic (inputs read once), plus the optional planes the launches were given
     noise_px = 0 if args.noise == "kernel" else NOISE_BYTES_PER_PX
     fb_px = FB_BYTES_PER_PX + noise_px + MASK_BYTES_PER_PX * MASKED_UNITS_PER_STEP / UNITS_PER_STEP
-    r_fb = roof(fb_ms, fb_n, fb_px, "k_photo_fwdbwd<fused>")
+    r_fb = roof(fb_ms, fb_n, fb_px, "k_unit_fb<2>")
     if r_fb:
         survey = (FWD_BYTES_PER_PX + BWD_BYTES_PER_PX) * px / (fb_ms / fb_n / 1e3) / 1e9
         r_fb["frac_survey_8d"] = round(survey / HBM_PEAK_GBS, 4)
