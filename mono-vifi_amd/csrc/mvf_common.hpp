@@ -522,25 +522,29 @@ MVF_DEV float block_sum(float v, float *scratch)
     return r;
 }
 
-// sum NV per-lane values over the workgroup with TWO barriers in total: wave shuffles,
-// one LDS row per wave, then lane q < NV folds the waves.  Result for value q is returned
-// in lane q of the workgroup (threadIdx.x == q); `scratch` holds >= (NT/64)*NV floats.
+// sum NV per-lane values over the workgroup with TWO barriers in total: four DPP row-shift steps
+// leave every 16-lane row's sum in its last lane, those lanes park it in LDS (one slot per row),
+// then lane q < NV folds the rows of all waves in a fixed order.  Result for value q is returned in
+// lane q of the workgroup (threadIdx.x == q); `scratch` holds >= (NT/16)*NV floats.
 template <int NT, int NV>
 MVF_DEV float block_sum_many(const float (&v)[NV], float *scratch)
 {
-    constexpr int NW = NT / kWave;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int NR = NT / 16;                     // 16-lane rows in the workgroup
+    const int row = threadIdx.x >> 4;
+    const bool last = (threadIdx.x & 15) == 15;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
-        float s = wave_sum(v[q]);
-        if (lane == 63) scratch[wid * NV + q] = s;
+        float s = v[q];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s = dpp_add(s, k);
+        if (last) scratch[row * NV + q] = s;
     }
     __syncthreads();
     float r = 0.0f;
     if (threadIdx.x < NV) {
 #pragma unroll
-        for (int i = 0; i < NW; ++i) r += scratch[i * NV + threadIdx.x];
+        for (int i = 0; i < NR; ++i) r += scratch[i * NV + threadIdx.x];
     }
     return r;
 }

@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(NT) k_silog_partial(const float *__restrict__ 
                                                       const float *__restrict__ mask,
                                                       float *__restrict__ ws, int N)
 {
-    __shared__ float scratch[3 * (NT / kWave)];
+    __shared__ float scratch[3 * (NT / 16)];
     int b = blockIdx.y;
     const float *p = pred + (size_t)b * N, *t = target + (size_t)b * N;
     const float *m = mask ? mask + (size_t)b * N : nullptr;

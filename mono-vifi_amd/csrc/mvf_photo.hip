@@ -946,7 +946,7 @@ __global__ void __launch_bounds__(256) k_smooth_bwd(const float *__restrict__ di
 }
 
 inline size_t fwd_smem() { return FWD_POSE * sizeof(float) + sizeof(PoseLds) + 128 * sizeof(float); }
-inline size_t bwd_smem() { return BWD_POSE * sizeof(float) + sizeof(PoseLds) + 128 * sizeof(float); }
+inline size_t bwd_smem() { return BWD_POSE * sizeof(float) + sizeof(PoseLds) + 24 * (NT / 16) * sizeof(float); }
 
 template <bool FUSED>
 void launch_fwd_kernel(const FwdArgs &a, dim3 grid, hipStream_t st)

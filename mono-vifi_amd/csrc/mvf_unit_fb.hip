@@ -71,11 +71,11 @@ struct FbArgs {
 // planes (A,B,G) | pose | scratch
 constexpr int FB_TGT = 0, FB_PAIR = 3 * PLANE, FB_DISP = FB_PAIR + 6 * PLANE,
               FB_COEF = FB_DISP + PLANE, FB_POSE = FB_COEF + 6 * RPLANE;
-constexpr int FB_SCRATCH = (NT / kWave) * NRED;
+static_assert((NT / 16) * NRED <= 6 * RPLANE, "the final reduction parks its row sums in the (then free) coefficient planes");
 #ifndef MVF_FB_EXTRA_LDS
 #define MVF_FB_EXTRA_LDS 0     // occupancy experiments: pad the workgroup's LDS
 #endif
-inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(PoseLds) + FB_SCRATCH * sizeof(float) + MVF_FB_EXTRA_LDS; }
+inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(PoseLds) + MVF_FB_EXTRA_LDS; }
 
 // ---- counter-based tie-break noise ------------------------------------------------------
 // train.py:1023-1024 draws torch.randn(identity_reprojection_loss.shape) * 1e-5 per call.  With
@@ -123,6 +123,119 @@ MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val,
     dmux = kn * (2.0f * my * (A2 - A1)) + kd * (2.0f * mx * (B2 - B1));
     dexy = kn * 2.0f * A1;
     dexx2 = kd * B1 * 2.0f;
+}
+
+// ---- target statistics computed ONCE per pixel and channel ------------------------------------------
+// The window means of the target (mu_y, E[y*y]) are the same for the identity pair and for the
+// warped pair.  The identity pass stashes them, lane-privately, in the coefficient planes (free
+// until the adjoint: each lane writes and later reads only the entries of its own pixels, so no
+// barrier is involved), and the warped pass reads them back instead of re-accumulating 9 taps of
+// y and y*y per pixel and channel.  Exact mode is untouched: same sums in the same order.
+struct Stats4X {
+    f2 sx[PX], sxx[PX], sxy[PX];
+    f2 xc[PX];
+    float yc[PX];
+};
+MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X &o)
+{
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Row6P x = load_row6p(xs + r * LDW);
+        Row6 y = load_row6(ys + r * LDW);
+        f2 xx[RW], xy[RW];
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            xx[i] = x.v[i] * x.v[i];
+            xy[i] = x.v[i] * f2s(y.v[i]);
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (r == 0 && d == 0) {
+                    o.sx[j] = x.v[j];
+                    o.sxx[j] = xx[j];
+                    o.sxy[j] = xy[j];
+                } else {
+                    o.sx[j] = o.sx[j] + x.v[j + d];
+                    o.sxx[j] = o.sxx[j] + xx[j + d];
+                    o.sxy[j] = o.sxy[j] + xy[j + d];
+                }
+            }
+            if (r == 1) {
+                o.xc[j] = x.v[j + 1];
+                o.yc[j] = y.v[j + 1];
+            }
+        }
+    }
+}
+MVF_DEV void stash_tstats(f2 *__restrict__ statP, const f2 my[PX])
+{
+    float4 *p = reinterpret_cast<float4 *>(statP);
+#pragma unroll
+    for (int j = 0; j < PX; j += 2) p[j / 2] = make_float4(my[j].x, my[j].y, my[j + 1].x, my[j + 1].y);
+}
+MVF_DEV void fetch_tstats(const f2 *__restrict__ statP, f2 my[PX])
+{
+    const float4 *p = reinterpret_cast<const float4 *>(statP);
+#pragma unroll
+    for (int j = 0; j < PX; j += 2) {
+        const float4 v = p[j / 2];
+        my[j] = mk2(v.x, v.y);
+        my[j + 1] = mk2(v.z, v.w);
+    }
+}
+// window means of the target alone (no auto-masking: there is no identity pass to ride on)
+MVF_DEV void target_stats(const float *__restrict__ ys, f2 my[PX])
+{
+    f2 sy[PX];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Row6 y = load_row6(ys + r * LDW);
+#pragma unroll
+        for (int j = 0; j < PX; ++j)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const f2 yy = mk2(y.v[j + d], y.v[j + d] * y.v[j + d]);
+                sy[j] = (r == 0 && d == 0) ? yy : sy[j] + yy;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) my[j] = div9(sy[j]);
+}
+// identity candidates (reference: train.py:973-985 on the raw sources), stashing the target means
+MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restrict__ tgt, int off,
+                             bool no_ssim, f2 out[PX], f2 *__restrict__ statP, int roff)
+{
+    f2 ab[PX], ss[PX];
+#pragma unroll
+    for (int j = 0; j < PX; ++j) ab[j] = ss[j] = f2s(0.0f);
+#pragma unroll 1
+    for (int c = 0; c < 3; ++c) {
+        if (no_ssim) {
+            Row6P x = load_row6p(pair + c * PPLANE + off + LDW);
+            Row6 y = load_row6(tgt + c * PLANE + off + LDW);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(y.v[j + 1]) - x.v[j + 1]);
+        } else {
+            Stats4P s;
+            window_xp(pair + c * PPLANE + off, tgt + c * PLANE + off, s);
+            f2 my[PX];
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                my[j] = div9(s.sy[j]);     // (mu_y, E[y*y])
+                f2 raw = ssim_raw_pk(div9(s.sx[j]), f2s(my[j].x), div9(s.sxx[j]), f2s(my[j].y), div9(s.sxy[j]));
+                ss[j] = ss[j] + clamp01_pk(raw);
+                ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
+            }
+            stash_tstats(statP + c * RPPLANE + roff, my);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        f2 l1 = div3(ab[j]);
+        out[j] = no_ssim ? l1 : 0.85f * div3(ss[j]) + 0.15f * l1;
+    }
 }
 
 // warp of the source pair into the pair planes: plane positions tid + k*NT, k < NSTAGE.  Full
@@ -225,7 +338,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     float *dispP = smem + FB_DISP;
     f2 *coefP = reinterpret_cast<f2 *>(smem + FB_COEF);
     PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + FB_POSE);
-    float *scratch = smem + FB_POSE + sizeof(PoseLds) / 4;
+    float *scratch = smem + FB_COEF;       // the coefficient planes are free when the final reduction runs
 
     const TileId tid = tile_of_block(a.tiles_x, a.tiles_y, a.B);
     const int H = a.H, W = a.W, b = tid.b;
@@ -298,11 +411,18 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     for (int j = 0; j < PX; ++j) vid[j] = f2s(0.0f);
     if (automask) {
 #ifndef MVF_ABL_NOID     // timing ablation: identity candidates not evaluated
-        reproj4p(pairP, tgtP, off, no_ssim, vid);
+        reproj_identity(pairP, tgtP, off, no_ssim, vid, coefP, roff);
 #else
         for (int j = 0; j < PX; ++j) vid[j] = pairP[off + LDW + 1 + j];
 #endif
         __syncthreads();                       // identity pair consumed
+    } else if (!no_ssim) {
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            f2 my[PX];
+            target_stats(tgtP + c * PLANE + off, my);
+            stash_tstats(coefP + c * RPPLANE + roff, my);
+        }
     }
 
     // ---- 3: fused warp of the source pair
@@ -349,11 +469,13 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
                 for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(yv.v[j + 1]) - x.v[j + 1]);
             } else {
-                Stats4P s;
-                window_xp(pairP + c * PPLANE + off, tgtP + c * PLANE + off, s);
+                Stats4X s;
+                window_x(pairP + c * PPLANE + off, tgtP + c * PLANE + off, s);
+                f2 tm[PX];                 // (mu_y, E[y*y]) stashed by the identity / target pass
+                fetch_tstats(coefP + c * RPPLANE + roff, tm);
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    f2 my = div9(s.sy[j]);     // (mu_y, E[y*y])
+                    const f2 my = tm[j];
                     f2 val;
                     ssim_val_partials_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
                                          div9(s.sxy[j]), val, pm[0][j], px2[0][j], pg[0][j]);
@@ -534,7 +656,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             f2 df = f2s(yq[j]) - xq[j];
             f2 sg = mk2((df.x > 0.0f) ? -1.0f : ((df.x < 0.0f) ? 1.0f : 0.0f),
                         (df.y > 0.0f) ? -1.0f : ((df.y < 0.0f) ? 1.0f : 0.0f));
-            gw[j] = wk[j] * (no_ssim ? 1.0f : 0.15f) * sg / 3.0f;
+            gw[j] = wk[j] * ((no_ssim ? 1.0f : 0.15f) * (1.0f / 3.0f)) * sg;
         }
 #ifdef MVF_ABL_NOGATHER
         if (false) {

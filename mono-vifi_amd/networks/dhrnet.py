@@ -7,6 +7,7 @@ finer ones through nearest upsampling + 1x1 conv blocks and summation, then two 
 and a single-scale sigmoid disparity head.  Blocks are registered in ``decoder`` in the
 reference's order so checkpoints load."""
 import numpy as np
+import torch
 import torch.nn as nn
 
 from ..layers import Conv3x3, ConvBlock, ConvBlock1x1, upsample
@@ -57,7 +58,9 @@ class DepthDecoder(nn.Module):
     def _m(self, *key):
         return self.decoder[self._index[key]]
 
-    def forward(self, input_features):
+    takes_depth_range = True
+
+    def forward(self, input_features, min_depth=0.1, max_depth=100.0):
         self.outputs = {}
         feats = {s: input_features[s] for s in range(1, 5)}
         for level, top in ((0, 4), (1, 3), (2, 2)):
@@ -75,5 +78,14 @@ class DepthDecoder(nn.Module):
         x = d3_0 + self._m("mix", 3, 1, 0)(upsample(d3_1, 2))
         x = upsample(self._m("par", 4, 0)(x), 2)
         x = self._m("par", 5, 0)(x)
-        self.outputs[("disp", 0)] = self.sigmoid(self._m("dispconv", 0)(x))
+        logit = self._m("dispconv", 0)(x)
+        if logit.is_cuda and logit.dtype == torch.float32 and self.num_output_channels == 1 \
+                and not torch.is_autocast_enabled():
+            # sigmoid + disp_to_depth + the unit kernel's mean partials in one pass (ops.disp_head)
+            from .. import ops
+            disp, depth, part = ops.disp_head(logit, min_depth, max_depth)
+            self.outputs[("disp", 0)], self.outputs[("depth", 0)] = disp, depth
+            self.outputs[("disp_mean_partials", 0)] = part
+        else:
+            self.outputs[("disp", 0)] = self.sigmoid(logit)
         return self.outputs

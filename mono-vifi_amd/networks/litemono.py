@@ -324,7 +324,9 @@ class DepthDecoder(nn.Module):
             if m.bias is not None:
                 nn.init.constant_(m.bias, 0)
 
-    def forward(self, input_features):
+    takes_depth_range = True
+
+    def forward(self, input_features, min_depth=0.1, max_depth=100.0):
         self.outputs = {}
         x = input_features[-1]
         for i in range(2, -1, -1):
@@ -334,5 +336,12 @@ class DepthDecoder(nn.Module):
             x = self.decoder[self._index[("upconv", i, 1)]](x)
             if i in self.scales:
                 f = upsample(self.decoder[self._index[("dispconv", i)]](x), mode="bilinear")
-                self.outputs[("disp", i)] = self.sigmoid(f)
+                if i == 0 and f.is_cuda and f.dtype == torch.float32 and self.num_output_channels == 1 \
+                        and not torch.is_autocast_enabled():
+                    from .. import ops
+                    disp, depth, part = ops.disp_head(f, min_depth, max_depth)
+                    self.outputs[("disp", 0)], self.outputs[("depth", 0)] = disp, depth
+                    self.outputs[("disp_mean_partials", 0)] = part
+                else:
+                    self.outputs[("disp", i)] = self.sigmoid(f)
         return self.outputs

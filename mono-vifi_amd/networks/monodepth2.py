@@ -58,6 +58,8 @@ class DepthDecoder(nn.Module):
     def _blk(self, *key):
         return self.decoder[self._index[key]]
 
+    takes_depth_range = True
+
     def forward(self, input_features, min_depth=0.1, max_depth=100.0):
         """-> {("disp", s)}; on the fused path additionally ("depth", 0) and ("disp_mean_partials", 0)
         (by-products of the disparity-head epilogue; the reference's keys are unchanged)."""

@@ -335,7 +335,7 @@ class Trainer(HotPathLosses):
     def _depth(self, decoder, feats):
         """decoder -> {("disp",0): fp32 disparity} (the hot path computes in fp32)."""
         m = self.models[decoder]
-        if isinstance(m, monodepth2.DepthDecoder):
+        if getattr(m, "takes_depth_range", False):
             # the disparity-head epilogue also emits depth and the per-image mean partials of disp
             out = self._nets(lambda: m(feats, self.opt.min_depth, self.opt.max_depth))
         else:
