@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 7
+#define MVF_ABI_VERSION 8
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -302,6 +302,20 @@ MVF_API int mvf_disp_head_fwd(const float *logit, float *disp, float *depth, flo
 /* g_logit = (g_disp - g_depth*range*depth^2) * disp*(1-disp); g_disp / g_depth nullable */
 MVF_API int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_depth, float *g_logit,
                       int64_t n, float min_disp, float range, void *stream);
+/* Convolution epilogue: out = act(x + bias[c] (+ res)) in one pass over [N,C,HW] (x may alias out).
+ * Replaces the bias add_ + activation (+ residual add) that follow every biased convolution:
+ * decoder ConvBlock (layers.py:106-118: ELU), IFRNet convrelu / ResBlock (networks/IFRNet.py:128-157:
+ * PReLU, block input added before the last one), transposed convolutions / 1x1 merges (bias only).
+ * act: 0 none, 1 ELU(alpha=1), 2 ReLU, 3 PReLU with slope [slope_n], slope_n == C or 1.
+ * bias, slope, res nullable. */
+MVF_API int mvf_bias_act_fwd(const float *x, const float *bias, const float *slope, const float *res, float *out,
+                     int N, int C, int HW, int act, int slope_n, void *stream);
+/* adjoint from the RESULT (act 0..2): g_x = g * act'(out) (act none: g_x is g, not written; out / g_x
+ * nullable) and g_bias[c] = sum of g_x over n, hw -- one pass + a fold of fixed-order partials
+ * (deterministic).  workspace: mvf_bias_act_workspace_floats(N, C, HW) floats. */
+MVF_API size_t mvf_bias_act_workspace_floats(int N, int C, int HW);
+MVF_API int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias, float *workspace, int N,
+                     int C, int HW, int act, void *stream);
 /* On-device colour augmentation of the data pipeline (datasets/mono_dataset.py:102-184, 214-256:
  * do_flip, do_color_aug with one torchvision ColorJitter draw per sample applied to all of its
  * frames).  img [samples*frames,3,H,W] (frame-minor), factors [samples,4] = {brightness, contrast,

@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -54,6 +54,9 @@ _SIGNATURES = {
     "mvf_up2cat_pad_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_disp_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp],
     "mvf_disp_head_bwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _vp],
+    "mvf_bias_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvf_bias_act_workspace_floats": [_i, _i, _i],
+    "mvf_bias_act_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_color_jitter_workspace_floats": [_i],
     "mvf_color_jitter": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_unit_fwdbwd_scale": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -85,7 +88,7 @@ _SIGNATURES = {
  PROF_UNIT_FWDBWD) = range(7)
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,
-            "mvf_color_jitter_workspace_floats": C.c_size_t}
+            "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t}
 
 EXPORTS = tuple(_SIGNATURES)
 

@@ -169,6 +169,139 @@ __global__ void __launch_bounds__(NT) k_disp_head_bwd(const float *__restrict__ 
     }
 }
 
+// ---- convolution epilogue: bias + activation (+ residual) --------------------------------------
+// Every biased convolution of the step is `conv -> + bias[c] -> activation` (decoder ConvBlock:
+// layers.py:106-118 ELU; IFRNet convrelu / ResBlock: networks/IFRNet.py:128-157 PReLU, with the
+// block input added before the last PReLU; transposed convolutions and 1x1 merges: bias only).
+// As stock ops the bias is a strided broadcast add_ (one full pass), the activation another, and
+// in backward the bias gradient a separate reduction over the activation's gradient.  Here the
+// convolution runs without bias and one pass does  out = act(x + bias[c] (+ res));  backward one
+// pass does  g_x = g * act'(out)  AND the per-channel partial sums of g_x (deterministic: fixed
+// split, partials folded in index order by k_bias_grad_finish).
+// act: 0 none, 1 ELU(alpha=1), 2 ReLU, 3 PReLU (slope per channel, or one slope if slope_n == 1).
+// ELU as ATen writes it: x > 0 ? x : expm1(x); its derivative from the result: out > 0 ? 1 : out + 1.
+enum { ACT_NONE = 0, ACT_ELU = 1, ACT_RELU = 2, ACT_PRELU = 3 };
+
+MVF_DEV float act_apply(float v, int act, float slope)
+{
+    switch (act) {
+    case ACT_ELU: return (v > 0.0f) ? v : expm1f(v);
+    case ACT_RELU: return fmaxf(v, 0.0f);
+    case ACT_PRELU: return (v > 0.0f) ? v : slope * v;
+    default: return v;
+    }
+}
+
+// one block = one run of a (sample, channel) plane; HW4 = HW / 4 when the planes are float4-able
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_bias_act_fwd(const float *__restrict__ x, const float *__restrict__ bias,
+                                                     const float *__restrict__ slope,
+                                                     const float *__restrict__ res, float *__restrict__ out,
+                                                     int C, int HW, int chunks, int act, int slope_n)
+{
+    constexpr int U = 4;
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
+    const int c = plane % C;
+    const float bv = bias ? bias[c] : 0.0f;
+    const float sv = (act == ACT_PRELU) ? slope[slope_n == 1 ? 0 : c] : 0.0f;
+    const size_t base = (size_t)plane * HW;
+    if (VEC) {
+        const int n4 = HW >> 2;
+        const float4 *xp = reinterpret_cast<const float4 *>(x + base);
+        const float4 *rp = res ? reinterpret_cast<const float4 *>(res + base) : nullptr;
+        float4 *op = reinterpret_cast<float4 *>(out + base);
+        const int i0 = chunk * (NT * U) + threadIdx.x;
+        float4 v[U], r[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = i0 + k * NT;
+            if (i < n4) {
+                v[k] = xp[i];
+                if (rp) r[k] = rp[i];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const int i = i0 + k * NT;
+            if (i >= n4) continue;
+            float4 t = v[k];
+            t.x += bv; t.y += bv; t.z += bv; t.w += bv;
+            if (rp) { t.x += r[k].x; t.y += r[k].y; t.z += r[k].z; t.w += r[k].w; }
+            op[i] = make_float4(act_apply(t.x, act, sv), act_apply(t.y, act, sv), act_apply(t.z, act, sv),
+                                act_apply(t.w, act, sv));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < U * 4; ++k) {
+            const int i = chunk * (NT * U * 4) + k * NT + threadIdx.x;
+            if (i < HW) {
+                float t = x[base + i] + bv;
+                if (res) t += res[base + i];
+                out[base + i] = act_apply(t, act, sv);
+            }
+        }
+    }
+}
+
+// block (c, s): the s-th of `nsplit` equal runs of channel c's N*HW elements (n-major).
+// g_x = g * act'(out) (not written for act none: it IS g), part[s][c] = sum of g_x over the run.
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_bias_act_bwd(const float *__restrict__ g, const float *__restrict__ out,
+                                                     float *__restrict__ gx, float *__restrict__ part, int N, int C,
+                                                     int HW, int act, int nsplit)
+{
+    __shared__ float scratch[NT / 16];
+    const int c = blockIdx.x % C, s = blockIdx.x / C;
+    const int per_plane = VEC ? (HW >> 2) : HW;
+    const int64_t total = (int64_t)N * per_plane;
+    const int64_t per = (total + nsplit - 1) / nsplit;
+    const int64_t lo = (int64_t)s * per, hi = (lo + per < total) ? lo + per : total;
+    float acc = 0.0f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
+        const int n = (int)(i / per_plane), q = (int)(i - (int64_t)n * per_plane);
+        const size_t o = ((size_t)n * C + c) * HW;
+        if (VEC) {
+            float4 gv = reinterpret_cast<const float4 *>(g + o)[q];
+            if (act != ACT_NONE) {
+                const float4 ov = reinterpret_cast<const float4 *>(out + o)[q];
+                if (act == ACT_ELU) {
+                    gv.x = (ov.x > 0.0f) ? gv.x : gv.x * (ov.x + 1.0f);
+                    gv.y = (ov.y > 0.0f) ? gv.y : gv.y * (ov.y + 1.0f);
+                    gv.z = (ov.z > 0.0f) ? gv.z : gv.z * (ov.z + 1.0f);
+                    gv.w = (ov.w > 0.0f) ? gv.w : gv.w * (ov.w + 1.0f);
+                } else {
+                    gv.x = (ov.x > 0.0f) ? gv.x : 0.0f;
+                    gv.y = (ov.y > 0.0f) ? gv.y : 0.0f;
+                    gv.z = (ov.z > 0.0f) ? gv.z : 0.0f;
+                    gv.w = (ov.w > 0.0f) ? gv.w : 0.0f;
+                }
+                reinterpret_cast<float4 *>(gx + o)[q] = gv;
+            }
+            acc += (gv.x + gv.y) + (gv.z + gv.w);
+        } else {
+            float gv = g[o + q];
+            if (act != ACT_NONE) {
+                const float ov = out[o + q];
+                gv = (ov > 0.0f) ? gv : ((act == ACT_ELU) ? gv * (ov + 1.0f) : 0.0f);
+                gx[o + q] = gv;
+            }
+            acc += gv;
+        }
+    }
+    const float r = block_sum<NT>(acc, scratch);
+    if (threadIdx.x == 0) part[(size_t)s * C + c] = r;
+}
+
+__global__ void __launch_bounds__(NT) k_bias_grad_finish(const float *__restrict__ part, float *__restrict__ gb,
+                                                         int C, int nsplit)
+{
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.0f;
+    for (int s = 0; s < nsplit; ++s) a += part[(size_t)s * C + c];
+    gb[c] = a;
+}
+
 // ---- on-device colour augmentation -------------------------------------------------------------
 // MonoDataset.__getitem__ / preprocess (datasets/mono_dataset.py:102-184, 214-256): with
 // probability 1/2 a sample's frames are flipped horizontally, and with probability 1/2 all of its
@@ -328,6 +461,58 @@ int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_dep
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(k_disp_head_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, disp, g_disp,
                        g_depth, g_logit, n, min_disp, range);
+    return hip_check_launch();
+}
+
+static int bias_act_nsplit(int N, int C, int HW)
+{
+    // >= 2048 blocks when the tensor allows it, runs of at least 4096 elements
+    int64_t total = (int64_t)N * HW;
+    int64_t s = (2048 + C - 1) / C;
+    const int64_t smax = (total + 4095) / 4096;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+size_t mvf_bias_act_workspace_floats(int N, int C, int HW) { return (size_t)bias_act_nsplit(N, C, HW) * C; }
+
+int mvf_bias_act_fwd(const float *x, const float *bias, const float *slope, const float *res, float *out, int N,
+                     int C, int HW, int act, int slope_n, void *stream)
+{
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    if (!x || !out || act < 0 || act > 3 || (act == ACT_PRELU && (!slope || (slope_n != 1 && slope_n != C))))
+        return (int)hipErrorInvalidValue;
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)res) & 15) == 0);
+    const int per_block = NT * 4 * 4;
+    const int chunks = (HW + per_block - 1) / per_block;
+    const int64_t blocks = (int64_t)N * C * chunks;
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (vec)
+        hipLaunchKernelGGL(k_bias_act_fwd<true>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, x, bias,
+                           slope, res, out, C, HW, chunks, act, slope_n);
+    else
+        hipLaunchKernelGGL(k_bias_act_fwd<false>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, x, bias,
+                           slope, res, out, C, HW, chunks, act, slope_n);
+    return hip_check_launch();
+}
+
+int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias, float *workspace, int N, int C,
+                     int HW, int act, void *stream)
+{
+    if (N <= 0 || C <= 0 || HW <= 0) return 0;
+    if (!g || !g_bias || !workspace || act < 0 || act > 2 || (act != ACT_NONE && (!out || !g_x)))
+        return (int)hipErrorInvalidValue;
+    const int nsplit = bias_act_nsplit(N, C, HW);
+    const bool vec = (HW & 3) == 0 && ((((uintptr_t)g | (uintptr_t)out | (uintptr_t)g_x) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(k_bias_act_bwd<true>, dim3((unsigned)(C * nsplit)), dim3(NT), 0, (hipStream_t)stream, g,
+                           out, g_x, workspace, N, C, HW, act, nsplit);
+    else
+        hipLaunchKernelGGL(k_bias_act_bwd<false>, dim3((unsigned)(C * nsplit)), dim3(NT), 0, (hipStream_t)stream, g,
+                           out, g_x, workspace, N, C, HW, act, nsplit);
+    hipLaunchKernelGGL(k_bias_grad_finish, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream,
+                       workspace, g_bias, C, nsplit);
     return hip_check_launch();
 }
 

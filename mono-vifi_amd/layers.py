@@ -150,12 +150,45 @@ class Conv3x3(nn.Module):
         self.pad = nn.ReflectionPad2d(1) if use_refl else nn.ZeroPad2d(1)
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), 3)
 
-    def forward(self, x):
+    def forward(self, x, act="none"):
+        """``act`` = "elu": the ConvBlock's activation rides in the convolution's epilogue."""
         if self.use_refl and x.is_cuda and x.dtype == torch.float32:
             # fp32 on the HIP device: gather kernels (deterministic backward, no atomics);
             # other dtypes / hosts keep the stock module (the networks are plain PyTorch)
-            return self.conv(ops.reflect_pad1(x))
-        return self.conv(self.pad(x))
+            return conv_bias_act(self.conv, ops.reflect_pad1(x), act)
+        return conv_bias_act(self.conv, self.pad(x), act)
+
+
+# fp32 on the HIP device: a biased convolution runs without its bias and ONE epilogue pass does
+# bias + activation (+ residual) (ops.bias_act); backward one pass does the activation's adjoint
+# and the bias gradient.  False = the stock op-by-op form (also what CPU tensors / autocast take).
+FUSED_EPILOGUE = True
+
+
+def conv_bias_act(conv, x, act="none", act_module=None, res=None):
+    """``act(conv(x) + res)`` for an ``nn.Conv2d`` / ``nn.ConvTranspose2d`` ``conv``; ``act`` in
+    {"none", "elu", "relu", "prelu"} (``act_module``: the ``nn.PReLU`` holding the slopes)."""
+    slope = act_module.weight if act == "prelu" else None
+    need_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or
+                                             (slope is not None and slope.requires_grad))
+    fused = (FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and
+             conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled() and
+             getattr(conv, "padding_mode", "zeros") == "zeros" and not (act == "prelu" and need_grad))
+    if fused:
+        if isinstance(conv, nn.ConvTranspose2d):
+            y = F.conv_transpose2d(x, conv.weight, None, conv.stride, conv.padding, conv.output_padding,
+                                   conv.groups, conv.dilation)
+        else:
+            y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+        return ops.bias_act(y, conv.bias, act, slope, res, inplace=True)
+    y = conv(x)
+    if res is not None:
+        y = y + res
+    if act == "none":
+        return y
+    if act_module is not None:
+        return act_module(y)
+    return {"elu": F.elu, "relu": F.relu}[act](y)
 
 
 class ConvBlock(nn.Module):
@@ -167,7 +200,7 @@ class ConvBlock(nn.Module):
         self.nonlin = nn.ELU()
 
     def forward(self, x):
-        return self.nonlin(self.conv(x))
+        return self.conv(x, act="elu")
 
 
 class Conv1x1(nn.Module):
@@ -178,7 +211,7 @@ class Conv1x1(nn.Module):
         self.conv = nn.Conv2d(int(in_channels), int(out_channels), kernel_size=1, stride=1)
 
     def forward(self, x):
-        return self.conv(x)
+        return conv_bias_act(self.conv, x, "none")
 
 
 class ConvBlock1x1(nn.Module):
@@ -190,7 +223,7 @@ class ConvBlock1x1(nn.Module):
         self.nonlin = nn.ELU()
 
     def forward(self, x):
-        return self.nonlin(self.conv(x))
+        return conv_bias_act(self.conv.conv, x, "elu")
 
 
 def compute_depth_errors(gt, pred):

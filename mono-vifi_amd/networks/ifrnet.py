@@ -10,6 +10,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..layers import conv_bias_act
+
 
 def _hip_flow_warp(img, flow):
     from .. import ops
@@ -33,8 +35,16 @@ def resize(x, scale_factor):
     return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False)
 
 
+class ConvPReLU(nn.Sequential):
+    """conv + PReLU with the reference's ``nn.Sequential`` state-dict keys (``0.*``, ``1.weight``);
+    bias and PReLU ride in one epilogue pass when no gradient is needed (frozen teacher)."""
+
+    def forward(self, x):
+        return conv_bias_act(self[0], x, "prelu", self[1])
+
+
 def convrelu(cin, cout, k=3, stride=1, pad=1):
-    return nn.Sequential(nn.Conv2d(cin, cout, k, stride, pad), nn.PReLU(cout))
+    return ConvPReLU(nn.Conv2d(cin, cout, k, stride, pad), nn.PReLU(cout))
 
 
 class ResBlock(nn.Module):
@@ -56,7 +66,7 @@ class ResBlock(nn.Module):
         out = torch.cat([out[:, :-s], self.conv2(out[:, -s:])], 1)
         out = self.conv3(out)
         out = torch.cat([out[:, :-s], self.conv4(out[:, -s:])], 1)
-        return self.prelu(x + self.conv5(out))
+        return conv_bias_act(self.conv5, out, "prelu", self.prelu, res=x)
 
 
 class Encoder(nn.Module):
@@ -86,13 +96,17 @@ class Decoder(nn.Module):
         self.convblock = nn.Sequential(convrelu(cin, mid), ResBlock(mid, side),
                                        nn.ConvTranspose2d(mid, cout, 4, 2, 1, bias=True))
 
+    def _run(self, x):
+        x = self.convblock[1](self.convblock[0](x))
+        return conv_bias_act(self.convblock[2], x, "none")
+
     def forward(self, *args):
         if self.top:
             f0, f1, embt = args
             _, _, h, w = f0.shape
-            return self.convblock(torch.cat([f0, f1, embt.repeat(1, 1, h, w)], 1))
+            return self._run(torch.cat([f0, f1, embt.repeat(1, 1, h, w)], 1))
         ft_, f0, f1, up0, up1 = args
-        return self.convblock(torch.cat([ft_, warp(f0, up0), warp(f1, up1), up0, up1], 1))
+        return self._run(torch.cat([ft_, warp(f0, up0), warp(f1, up1), up0, up1], 1))
 
 
 _SCALES = {

@@ -10,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from ..layers import Conv3x3, ConvBlock, upsample
+from ..layers import Conv3x3, ConvBlock, conv_bias_act, upsample
 from .resnet import ResNetTrunk, pyramid_features
 
 # fp32 on the HIP device: the upsample + cat + reflection pad between the two convolutions of a
@@ -73,7 +73,7 @@ class DepthDecoder(nn.Module):
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             blk = self._blk("upconv", i, 1)
             if fused and x.shape[-1] >= 2 and x.shape[-2] >= 2:
-                x = blk.nonlin(blk.conv.conv(ops.up2cat_pad(x, skip)))
+                x = conv_bias_act(blk.conv.conv, ops.up2cat_pad(x, skip), "elu")
             else:
                 x = upsample(x)
                 if skip is not None:

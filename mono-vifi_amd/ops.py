@@ -862,6 +862,71 @@ def disp_head(logit, min_depth=0.1, max_depth=100.0, want_depth=True):
     return disp, (depth if want_depth else None), part
 
 
+_ACT_CODES = {"none": 0, "elu": 1, "relu": 2, "prelu": 3}
+
+
+class BiasAct(torch.autograd.Function):
+    """out = act(x + bias[c] (+ res)) over [N,C,...] in one pass -- the epilogue of a biased
+    convolution run without its bias (decoder ConvBlock: reference layers.py:106-118; IFRNet
+    convrelu / ResBlock: networks/IFRNet.py:128-157).  Backward (act none / elu / relu): one pass
+    gives g_x = g * act'(out) and the bias gradient (deterministic partial sums)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, slope, res, act, inplace):
+        nat.require_device(x, *[t for t in (bias, slope, res) if t is not None])
+        if x.dim() < 2:
+            raise RuntimeError("bias_act expects [N, C, ...]")
+        xc = _c(x)
+        N, C = xc.shape[0], xc.shape[1]
+        HW = xc[0, 0].numel() if xc.dim() > 2 else 1
+        if bias is not None and bias.numel() != C:
+            raise RuntimeError(f"bias_act: bias has {bias.numel()} entries for {C} channels")
+        if res is not None and res.shape != x.shape:
+            raise RuntimeError("bias_act: residual shape differs from x")
+        sl_n = 0
+        if act == 3:
+            if slope is None or slope.numel() not in (1, C):
+                raise RuntimeError("bias_act: PReLU needs 1 or C slopes")
+            sl_n = slope.numel()
+        if inplace and xc is x:
+            out = x
+            ctx.mark_dirty(x)
+        else:
+            out = torch.empty_like(xc)
+        nat.check(nat.lib().mvf_bias_act_fwd(nat.ptr(xc), nat.ptr(_c(bias) if bias is not None else None),
+                                             nat.ptr(_c(slope) if slope is not None else None),
+                                             nat.ptr(_c(res) if res is not None else None), nat.ptr(out), N, C, HW,
+                                             act, sl_n, _stream()), "bias_act_fwd")
+        ctx.act, ctx.has_bias, ctx.has_res = act, bias is not None, res is not None
+        ctx.save_for_backward(out if act in (1, 2) else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if ctx.act == 3:
+            raise NotImplementedError("bias_act: PReLU epilogue is forward-only (frozen teacher); "
+                                      "layers.conv_bias_act keeps the stock ops when a gradient is needed")
+        (out,) = ctx.saved_tensors
+        g = _c(g)
+        N, C = g.shape[0], g.shape[1]
+        HW = g[0, 0].numel() if g.dim() > 2 else 1
+        gx = torch.empty_like(g) if ctx.act != 0 else g
+        gb = None
+        if ctx.has_bias or ctx.act != 0:
+            gb = torch.empty(C, dtype=torch.float32, device=g.device)
+            ws = torch.empty(nat.lib().mvf_bias_act_workspace_floats(N, C, HW), dtype=torch.float32, device=g.device)
+            nat.check(nat.lib().mvf_bias_act_bwd(nat.ptr(g), nat.ptr(out), nat.ptr(gx if ctx.act != 0 else None),
+                                                 nat.ptr(gb), nat.ptr(ws), N, C, HW, ctx.act, _stream()),
+                      "bias_act_bwd")
+        return gx, (gb if ctx.has_bias else None), None, (gx if ctx.has_res else None), None, None
+
+
+def bias_act(x, bias=None, act="none", slope=None, res=None, inplace=False):
+    """act(x + bias[c] (+ res)); act in {"none", "elu", "relu", "prelu"}.  `inplace` overwrites x
+    (safe for the fresh output of a convolution: its backward does not read its own result)."""
+    return BiasAct.apply(x, bias, slope, res, _ACT_CODES[act], bool(inplace))
+
+
 def color_jitter(img, factors, order, apply, flip, frames=1, want_raw=False):
     """Flip + torchvision-style ColorJitter for a batch on the device (reference: the per-item
     host work of datasets/mono_dataset.py:214-256).  img [samples*frames,3,H,W] with the frames of

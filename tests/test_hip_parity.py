@@ -874,8 +874,9 @@ def test_decoder_fused_glue_equals_stock_ops(dev):
     B, H, W = 2, 64, 96
     feats = [torch.randn(B, c, H >> (i + 1), W >> (i + 1), device=dev, requires_grad=True) for i, c in enumerate(ch)]
     res = {}
+    from mono_vifi_amd import layers as L
     for fused in (True, False):
-        md.FUSED_GLUE = fused
+        md.FUSED_GLUE = L.FUSED_EPILOGUE = fused
         try:
             for f in feats:
                 f.grad = None
@@ -885,13 +886,97 @@ def test_decoder_fused_glue_equals_stock_ops(dev):
             res[fused] = ([out[("disp", s)].detach().clone() for s in range(4)], [f.grad.clone() for f in feats],
                           [p.grad.clone() for p in dec.parameters()], out.get(("depth", 0)))
         finally:
-            md.FUSED_GLUE = True
+            md.FUSED_GLUE = L.FUSED_EPILOGUE = True
     for a, b in zip(res[True][0], res[False][0]):
         assert float((a - b).abs().max()) <= 1e-6
     for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
         assert float((a - b).norm() / b.norm()) <= 1e-4
     from mono_vifi_amd import layers
     assert float(((res[True][3] - layers.disp_to_depth(res[True][0][0], 0.1, 100.0)[1]) / res[True][3]).abs().max()) <= 1e-6
+
+
+@pytest.mark.parametrize("act", ["none", "elu", "relu", "prelu"])
+def test_bias_act_vs_torch(dev, act):
+    """Convolution epilogue out = act(x + bias[c] (+ res)) (layers.py:106-118, IFRNet.py:128-157)
+    against the stock ops in fp64; backward (act'(out) and the bias gradient) against autograd of
+    the stock ops.  Shapes: float4-able planes, odd planes, a plane smaller than a block."""
+    import torch.nn.functional as F
+    from mono_vifi_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(9)
+    for shape, with_res, one_slope in (((3, 5, 12, 20), False, False), ((2, 7, 9, 13), True, True),
+                                       ((4, 16, 96, 160), True, False), ((2, 3, 1, 1), False, False)):
+        Nn, C = shape[0], shape[1]
+        x = (2 * torch.randn(shape, generator=g)).to(dev)
+        b = torch.randn(C, generator=g).to(dev)
+        r = torch.randn(shape, generator=g).to(dev) if with_res else None
+        sl = (0.25 * torch.rand(1 if one_slope else C, generator=g) + 0.05).to(dev) if act == "prelu" else None
+
+        def stock(x_, b_, r_):
+            v = x_ + b_.view(1, C, 1, 1)
+            if r_ is not None:
+                v = v + r_
+            if act == "elu":
+                return F.elu(v)
+            if act == "relu":
+                return F.relu(v)
+            if act == "prelu":
+                return F.prelu(v, sl.to(v.dtype))
+            return v
+        want = stock(x.double(), b.double(), None if r is None else r.double())
+        got = ops.bias_act(x, b, act, sl, r)
+        assert float((got.double() - want).abs().max()) <= 2e-6, (act, shape)
+        # in place on x
+        x2 = x.clone()
+        got2 = ops.bias_act(x2, b, act, sl, r, inplace=True)
+        assert got2.data_ptr() == x2.data_ptr() and torch.equal(got2, got)
+        if act == "prelu":
+            xr = x.clone().requires_grad_(True)
+            with pytest.raises(NotImplementedError):
+                ops.bias_act(xr, b, act, sl, r).sum().backward()
+            continue
+        xa, ba = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        xb, bb = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        ra = None if r is None else r.clone().requires_grad_(True)
+        rb = None if r is None else r.clone().requires_grad_(True)
+        w = torch.randn(shape, generator=g).to(dev)
+        (ops.bias_act(xa, ba, act, None, ra) * w).sum().backward()
+        (stock(xb, bb, rb) * w).sum().backward()
+        assert float((xa.grad - xb.grad).abs().max()) <= 1e-6 * max(1.0, float(xb.grad.abs().max())), (act, shape)
+        assert float((ba.grad - bb.grad).abs().max()) <= 2e-5 * max(1.0, float(bb.grad.abs().max())), (act, shape)
+        if r is not None:
+            assert torch.equal(ra.grad, xa.grad) and float((ra.grad - rb.grad).abs().max()) <= 1e-6 * max(1.0, float(rb.grad.abs().max()))
+        # deterministic bias gradient
+        xc, bc = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        (ops.bias_act(xc, bc, act, None, None if r is None else r) * w).sum().backward()
+        assert torch.equal(bc.grad, ba.grad)
+
+
+def test_ifrnet_epilogue_equals_stock_ops(dev):
+    """The frozen teacher with bias + PReLU (+ residual) in one epilogue pass per convolution
+    against the stock op-by-op modules (reference: networks/IFRNet.py:128-157, 373-441)."""
+    from mono_vifi_amd import layers as L
+    from mono_vifi_amd.networks import ifrnet
+    torch.manual_seed(4)
+    net = ifrnet.IFRNet("small").to(dev).eval()
+    for m in net.modules():
+        if isinstance(m, torch.nn.PReLU):
+            m.weight.data.uniform_(0.05, 0.4)
+    a, b = torch.rand(2, 3, 64, 128, device=dev), torch.rand(2, 3, 64, 128, device=dev)
+    embt = torch.full((2, 1, 1, 1), 0.5, device=dev)
+    out = {}
+    with torch.no_grad():
+        for fused in (True, False):
+            L.FUSED_EPILOGUE = fused
+            try:
+                out[fused] = net(a, b, embt)
+            finally:
+                L.FUSED_EPILOGUE = True
+    for u, v in zip(out[True], out[False]):
+        assert float((u - v).abs().max()) <= 1e-5 * max(1.0, float(v.abs().max()))
+    # with a gradient required the stock modules run (PReLU epilogue is forward-only)
+    a.requires_grad_(True)
+    net(a, b, embt)[0].sum().backward()
+    assert a.grad is not None and bool(torch.isfinite(a.grad).all())
 
 
 # ------------------------------------------------------------------ f4: on-device augmentation
