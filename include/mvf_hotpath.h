@@ -212,6 +212,11 @@ MVF_API int mvf_flow_warp_bwd(const float *img, const float *flow, const float *
                       const float *g_out, float *g_img, float *g_flow, float *workspace, int B, int C,
                       int H, int W, void *stream);
 MVF_API size_t mvf_flow_warp_workspace_floats(int B, int C, int H, int W);
+/* Deterministic g_img of IFRNet.warp (networks/IFRNet.py:7-15): the scatter of mvf_flow_warp_bwd
+ * turned into a gather through sorted inverse tap lists (no float atomics, bit-reproducible).
+ * g_img [B,C,H,W] is fully written.  workspace: mvf_fusion_bwd_workspace_ints(B, H, W) int32. */
+MVF_API int mvf_flow_warp_bwd_gather(const float *flow, const float *xs, const float *ys, const float *g_out,
+                             float *g_img, int32_t *workspace, int B, int C, int H, int W, void *stream);
 
 /* ---- f1: FusionModule (networks/fusion_module.py:65-130) -----------
  * The tensor that enters the 1x1 convolution of one pyramid level,
@@ -312,7 +317,8 @@ MVF_API int mvf_bias_act_fwd(const float *x, const float *bias, const float *slo
                      int N, int C, int HW, int act, int slope_n, void *stream);
 /* adjoint from the RESULT (act 0..2): g_x = g * act'(out) (act none: g_x is g, not written; out / g_x
  * nullable) and g_bias[c] = sum of g_x over n, hw -- one pass + a fold of fixed-order partials
- * (deterministic).  workspace: mvf_bias_act_workspace_floats(N, C, HW) floats. */
+ * (deterministic).  g_bias NULL: only g_x (workspace unused).  workspace:
+ * mvf_bias_act_workspace_floats(N, C, HW) floats. */
 MVF_API size_t mvf_bias_act_workspace_floats(int N, int C, int HW);
 MVF_API int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias, float *workspace, int N,
                      int C, int HW, int act, void *stream);

@@ -67,6 +67,7 @@ _SIGNATURES = {
     "mvf_flow_warp_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_flow_warp_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_flow_warp_workspace_floats": [_i, _i, _i, _i],
+    "mvf_flow_warp_bwd_gather": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_fusion_prep_floats": [_i, _i, _i],
     "mvf_fusion_prep": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "mvf_fusion_level_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

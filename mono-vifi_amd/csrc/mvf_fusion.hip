@@ -224,13 +224,16 @@ struct Dest {
     float w[4];
     int n;
 };
+// FLOW: `prep` is a plain flow field [B,2,h,w] (standalone IFRNet.warp: one source, weight 1)
+template <bool FLOW>
 MVF_DEV Dest dest_of(const float *__restrict__ prep, const float *__restrict__ xs, const float *__restrict__ ys,
                      int b, int s, int i, int h, int w)
 {
     const int n = h * w, y = i / w, x = i - y * w;
-    const float *pp = prep + (size_t)b * PREP * n + i;
-    const Tap t = flow_tap_xy(pp[(size_t)(4 + 2 * s) * n], pp[(size_t)(5 + 2 * s) * n], xs, ys, x, y, h, w);
-    const float m = pp[8 * (size_t)n];
+    const float *pp = prep + (size_t)b * (FLOW ? 2 : PREP) * n + i;
+    const Tap t = FLOW ? flow_tap_xy(pp[0], pp[n], xs, ys, x, y, h, w)
+                       : flow_tap_xy(pp[(size_t)(4 + 2 * s) * n], pp[(size_t)(5 + 2 * s) * n], xs, ys, x, y, h, w);
+    const float m = FLOW ? 1.0f : pp[8 * (size_t)n];
     const float sc = (s == 0) ? m : 1.0f - m;            // merge weight of this source
     const float fw = t.wx, fe = 1.0f - fw, fn = t.wy, fs = 1.0f - fn;
     const float wt[4] = {fs * fe, fs * fw, fn * fe, fn * fw};
@@ -246,14 +249,15 @@ MVF_DEV Dest dest_of(const float *__restrict__ prep, const float *__restrict__ x
     return d;
 }
 
-// grid (pixel blocks, B, 2 sources)
+// grid (pixel blocks, B, 2 sources | 1 for FLOW)
+template <bool FLOW>
 __global__ void __launch_bounds__(NT) k_inv_count(const float *__restrict__ prep, const float *__restrict__ xs,
                                                   const float *__restrict__ ys, int *__restrict__ ws, int B, int h, int w)
 {
     const int n = h * w, i = blockIdx.x * NT + threadIdx.x, b = blockIdx.y, s = blockIdx.z;
     if (i >= n) return;
     const InvWs W = inv_ws(ws, B, n);
-    const Dest d = dest_of(prep, xs, ys, b, s, i, h, w);
+    const Dest d = dest_of<FLOW>(prep, xs, ys, b, s, i, h, w);
     int *cnt = W.cnt + ((size_t)s * B + b) * n;
     for (int k = 0; k < d.n; ++k) atomicAdd(cnt + d.cell[k], 1);
 }
@@ -286,13 +290,14 @@ __global__ void __launch_bounds__(1024) k_inv_scan(int *__restrict__ ws, int B, 
     if (threadIdx.x == 1023) off[n] = sh[1023];
 }
 
+template <bool FLOW>
 __global__ void __launch_bounds__(NT) k_inv_fill(const float *__restrict__ prep, const float *__restrict__ xs,
                                                  const float *__restrict__ ys, int *__restrict__ ws, int B, int h, int w)
 {
     const int n = h * w, i = blockIdx.x * NT + threadIdx.x, b = blockIdx.y, s = blockIdx.z;
     if (i >= n) return;
     const InvWs W = inv_ws(ws, B, n);
-    const Dest d = dest_of(prep, xs, ys, b, s, i, h, w);
+    const Dest d = dest_of<FLOW>(prep, xs, ys, b, s, i, h, w);
     const size_t sb = (size_t)s * B + b;
     int *cur = W.cnt + sb * n;                              // zeroed again by the caller: the cursor
     const int *off = W.off + sb * (n + 1);
@@ -358,6 +363,56 @@ __global__ void __launch_bounds__(NT) k_fusion_level_bwd_gather(const float *__r
     }
 }
 
+// standalone IFRNet.warp: g_img[b,c,q] = sum over the (sorted) list of q of w * g_out[b,c,p].
+// grid (pixel blocks, channel chunks, B)
+__global__ void __launch_bounds__(NT) k_flow_warp_bwd_gather(const float *__restrict__ g_out,
+                                                             const int *__restrict__ ws, float *__restrict__ g_img,
+                                                             int B, int C, int h, int w)
+{
+    const int n = h * w, q = blockIdx.x * NT + threadIdx.x, b = blockIdx.z;
+    if (q >= n) return;
+    const InvWs W = inv_ws(const_cast<int *>(ws), B, n);
+    const int c0 = blockIdx.y * CCH, nc = min(CCH, C - c0);
+    const float *gb = g_out + ((size_t)b * C + c0) * n;
+    const int *off = W.off + (size_t)b * (n + 1);
+    const int2 *ent = W.ent + (size_t)b * 4 * n;
+    const int lo = off[q], hi = off[q + 1];
+    float acc[CCH];
+#pragma unroll
+    for (int k = 0; k < CCH; ++k) acc[k] = 0.0f;
+    for (int e = lo; e < hi; ++e) {
+        const int2 v = ent[e];
+        const float wgt = __int_as_float(v.y);
+        const float *gp = gb + v.x;
+#pragma unroll
+        for (int k = 0; k < CCH; ++k)
+            if (k < nc) acc[k] += wgt * gp[(size_t)k * n];
+    }
+#pragma unroll
+    for (int k = 0; k < CCH; ++k)
+        if (k < nc) g_img[((size_t)b * C + c0 + k) * n + q] = acc[k];
+}
+
+// count / scan / fill / sort of the inverse tap lists (see above); FLOW: one source
+template <bool FLOW>
+int build_inverse_lists(const float *field, const float *xs, const float *ys, int32_t *workspace, int B, int h, int w,
+                        hipStream_t st)
+{
+    const int n = h * w;
+    const dim3 gp((unsigned)((n + NT - 1) / NT), (unsigned)B, FLOW ? 1 : 2);
+    const size_t cnt_bytes = (size_t)2 * B * n * sizeof(int);
+    hipError_t e = hipMemsetAsync(workspace, 0, cnt_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_inv_count<FLOW>, gp, dim3(NT), 0, st, field, xs, ys, workspace, B, h, w);
+    hipLaunchKernelGGL(k_inv_scan, dim3((unsigned)((FLOW ? 1 : 2) * B)), dim3(1024), 0, st, workspace, B, n);
+    e = hipMemsetAsync(workspace, 0, cnt_bytes, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_inv_fill<FLOW>, gp, dim3(NT), 0, st, field, xs, ys, workspace, B, h, w);
+    hipLaunchKernelGGL(k_inv_sort, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((FLOW ? 1 : 2) * B)), dim3(NT), 0, st,
+                       workspace, B, n);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -419,19 +474,27 @@ int mvf_fusion_level_bwd_gather(const float *g_out, const float *prep, const flo
     if (!g_feat_n1 && !g_feat_p1) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int n = h * w;
-    const dim3 gp((unsigned)((n + NT - 1) / NT), (unsigned)B, 2);
-    const size_t cnt_bytes = (size_t)2 * B * n * sizeof(int);
-    hipError_t e = hipMemsetAsync(workspace, 0, cnt_bytes, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_inv_count, gp, dim3(NT), 0, st, prep, xs, ys, workspace, B, h, w);
-    hipLaunchKernelGGL(k_inv_scan, dim3((unsigned)(2 * B)), dim3(1024), 0, st, workspace, B, n);
-    e = hipMemsetAsync(workspace, 0, cnt_bytes, st);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_inv_fill, gp, dim3(NT), 0, st, prep, xs, ys, workspace, B, h, w);
-    hipLaunchKernelGGL(k_inv_sort, dim3((unsigned)((n + NT - 1) / NT), (unsigned)(2 * B)), dim3(NT), 0, st, workspace, B, n);
+    const int err = build_inverse_lists<false>(prep, xs, ys, workspace, B, h, w, st);
+    if (err) return err;
     const int nchunk = (C + CCH - 1) / CCH;
     hipLaunchKernelGGL(k_fusion_level_bwd_gather, dim3((unsigned)((n + NT - 1) / NT), (unsigned)nchunk, (unsigned)B),
                        dim3(NT), 0, st, g_out, workspace, g_feat_n1, g_feat_p1, B, C, h, w);
+    return hip_check_launch();
+}
+
+int mvf_flow_warp_bwd_gather(const float *flow, const float *xs, const float *ys, const float *g_out, float *g_img,
+                             int32_t *workspace, int B, int C, int H, int W, void *stream)
+{
+    if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    if (!flow || !xs || !ys || !g_out || !g_img || !workspace || B > 32767 || H < 2 || W < 2)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int n = H * W;
+    const int err = build_inverse_lists<true>(flow, xs, ys, workspace, B, H, W, st);
+    if (err) return err;
+    const int nchunk = (C + CCH - 1) / CCH;
+    hipLaunchKernelGGL(k_flow_warp_bwd_gather, dim3((unsigned)((n + NT - 1) / NT), (unsigned)nchunk, (unsigned)B),
+                       dim3(NT), 0, st, g_out, workspace, g_img, B, C, H, W);
     return hip_check_launch();
 }
 

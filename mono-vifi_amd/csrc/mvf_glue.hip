@@ -192,38 +192,36 @@ MVF_DEV float act_apply(float v, int act, float slope)
     }
 }
 
-// one block = one run of a (sample, channel) plane; HW4 = HW / 4 when the planes are float4-able
+// flat over the tensor: lane i handles float4 (VEC) or scalar element i, i + NT, ...; the channel of an
+// element is (i / plane) % C (one integer divide per access: the pass is HBM-bound)
 template <bool VEC>
 __global__ void __launch_bounds__(NT) k_bias_act_fwd(const float *__restrict__ x, const float *__restrict__ bias,
                                                      const float *__restrict__ slope,
                                                      const float *__restrict__ res, float *__restrict__ out,
-                                                     int C, int HW, int chunks, int act, int slope_n)
+                                                     int C, int per_plane, int64_t total, int act, int slope_n)
 {
     constexpr int U = 4;
-    const int plane = blockIdx.x / chunks, chunk = blockIdx.x - plane * chunks;
-    const int c = plane % C;
-    const float bv = bias ? bias[c] : 0.0f;
-    const float sv = (act == ACT_PRELU) ? slope[slope_n == 1 ? 0 : c] : 0.0f;
-    const size_t base = (size_t)plane * HW;
+    const int64_t i0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x;
     if (VEC) {
-        const int n4 = HW >> 2;
-        const float4 *xp = reinterpret_cast<const float4 *>(x + base);
-        const float4 *rp = res ? reinterpret_cast<const float4 *>(res + base) : nullptr;
-        float4 *op = reinterpret_cast<float4 *>(out + base);
-        const int i0 = chunk * (NT * U) + threadIdx.x;
+        const float4 *xp = reinterpret_cast<const float4 *>(x);
+        const float4 *rp = res ? reinterpret_cast<const float4 *>(res) : nullptr;
+        float4 *op = reinterpret_cast<float4 *>(out);
         float4 v[U], r[U];
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const int i = i0 + k * NT;
-            if (i < n4) {
+            const int64_t i = i0 + k * NT;
+            if (i < total) {
                 v[k] = xp[i];
                 if (rp) r[k] = rp[i];
             }
         }
 #pragma unroll
         for (int k = 0; k < U; ++k) {
-            const int i = i0 + k * NT;
-            if (i >= n4) continue;
+            const int64_t i = i0 + k * NT;
+            if (i >= total) continue;
+            const int c = (int)((i / per_plane) % C);
+            const float bv = bias ? bias[c] : 0.0f;
+            const float sv = (act == ACT_PRELU) ? slope[slope_n == 1 ? 0 : c] : 0.0f;
             float4 t = v[k];
             t.x += bv; t.y += bv; t.z += bv; t.w += bv;
             if (rp) { t.x += r[k].x; t.y += r[k].y; t.z += r[k].z; t.w += r[k].w; }
@@ -232,13 +230,46 @@ __global__ void __launch_bounds__(NT) k_bias_act_fwd(const float *__restrict__ x
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < U * 4; ++k) {
-            const int i = chunk * (NT * U * 4) + k * NT + threadIdx.x;
-            if (i < HW) {
-                float t = x[base + i] + bv;
-                if (res) t += res[base + i];
-                out[base + i] = act_apply(t, act, sv);
+        for (int k = 0; k < U; ++k) {
+            const int64_t i = i0 + k * NT;
+            if (i >= total) continue;
+            const int c = (int)((i / per_plane) % C);
+            float t = x[i] + (bias ? bias[c] : 0.0f);
+            if (res) t += res[i];
+            out[i] = act_apply(t, act, (act == ACT_PRELU) ? slope[slope_n == 1 ? 0 : c] : 0.0f);
+        }
+    }
+}
+
+// g_x = g * act'(out) alone (no bias to reduce for): flat, ELU / ReLU
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_act_bwd_flat(const float *__restrict__ g, const float *__restrict__ out,
+                                                     float *__restrict__ gx, int64_t total, int act)
+{
+    constexpr int U = 4;
+    const int64_t i0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int64_t i = i0 + k * NT;
+        if (i >= total) continue;
+        if (VEC) {
+            float4 gv = reinterpret_cast<const float4 *>(g)[i];
+            const float4 ov = reinterpret_cast<const float4 *>(out)[i];
+            if (act == ACT_ELU) {
+                gv.x = (ov.x > 0.0f) ? gv.x : gv.x * (ov.x + 1.0f);
+                gv.y = (ov.y > 0.0f) ? gv.y : gv.y * (ov.y + 1.0f);
+                gv.z = (ov.z > 0.0f) ? gv.z : gv.z * (ov.z + 1.0f);
+                gv.w = (ov.w > 0.0f) ? gv.w : gv.w * (ov.w + 1.0f);
+            } else {
+                gv.x = (ov.x > 0.0f) ? gv.x : 0.0f;
+                gv.y = (ov.y > 0.0f) ? gv.y : 0.0f;
+                gv.z = (ov.z > 0.0f) ? gv.z : 0.0f;
+                gv.w = (ov.w > 0.0f) ? gv.w : 0.0f;
             }
+            reinterpret_cast<float4 *>(gx)[i] = gv;
+        } else {
+            const float ov = out[i], gv = g[i];
+            gx[i] = (ov > 0.0f) ? gv : ((act == ACT_ELU) ? gv * (ov + 1.0f) : 0.0f);
         }
     }
 }
@@ -484,16 +515,16 @@ int mvf_bias_act_fwd(const float *x, const float *bias, const float *slope, cons
     if (!x || !out || act < 0 || act > 3 || (act == ACT_PRELU && (!slope || (slope_n != 1 && slope_n != C))))
         return (int)hipErrorInvalidValue;
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)res) & 15) == 0);
-    const int per_block = NT * 4 * 4;
-    const int chunks = (HW + per_block - 1) / per_block;
-    const int64_t blocks = (int64_t)N * C * chunks;
+    const int per_plane = vec ? HW / 4 : HW;
+    const int64_t total = (int64_t)N * C * per_plane;
+    const int64_t blocks = (total + NT * 4 - 1) / (NT * 4);
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
     if (vec)
         hipLaunchKernelGGL(k_bias_act_fwd<true>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, x, bias,
-                           slope, res, out, C, HW, chunks, act, slope_n);
+                           slope, res, out, C, per_plane, total, act, slope_n);
     else
         hipLaunchKernelGGL(k_bias_act_fwd<false>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, x, bias,
-                           slope, res, out, C, HW, chunks, act, slope_n);
+                           slope, res, out, C, per_plane, total, act, slope_n);
     return hip_check_launch();
 }
 
@@ -501,10 +532,23 @@ int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias
                      int HW, int act, void *stream)
 {
     if (N <= 0 || C <= 0 || HW <= 0) return 0;
-    if (!g || !g_bias || !workspace || act < 0 || act > 2 || (act != ACT_NONE && (!out || !g_x)))
+    if (!g || act < 0 || act > 2 || (act != ACT_NONE && (!out || !g_x)) || (g_bias && !workspace))
         return (int)hipErrorInvalidValue;
-    const int nsplit = bias_act_nsplit(N, C, HW);
     const bool vec = (HW & 3) == 0 && ((((uintptr_t)g | (uintptr_t)out | (uintptr_t)g_x) & 15) == 0);
+    if (!g_bias) {                       // no bias gradient wanted: the activation's adjoint alone
+        if (act == ACT_NONE) return 0;
+        const int64_t total = (int64_t)N * C * (vec ? HW / 4 : HW);
+        const int64_t blocks = (total + NT * 4 - 1) / (NT * 4);
+        if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        if (vec)
+            hipLaunchKernelGGL(k_act_bwd_flat<true>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, g, out,
+                               g_x, total, act);
+        else
+            hipLaunchKernelGGL(k_act_bwd_flat<false>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, g, out,
+                               g_x, total, act);
+        return hip_check_launch();
+    }
+    const int nsplit = bias_act_nsplit(N, C, HW);
     if (vec)
         hipLaunchKernelGGL(k_bias_act_bwd<true>, dim3((unsigned)(C * nsplit)), dim3(NT), 0, (hipStream_t)stream, g,
                            out, g_x, workspace, N, C, HW, act, nsplit);

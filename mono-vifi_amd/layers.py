@@ -16,6 +16,8 @@ building blocks are plain ``torch.nn`` modules (MIOpen / hipBLASLt do the contra
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -162,7 +164,7 @@ class Conv3x3(nn.Module):
 # fp32 on the HIP device: a biased convolution runs without its bias and ONE epilogue pass does
 # bias + activation (+ residual) (ops.bias_act); backward one pass does the activation's adjoint
 # and the bias gradient.  False = the stock op-by-op form (also what CPU tensors / autocast take).
-FUSED_EPILOGUE = True
+FUSED_EPILOGUE = os.environ.get("MVF_FUSED_EPILOGUE", "1") != "0"      # developer knob for A/B timing
 
 
 def conv_bias_act(conv, x, act="none", act_module=None, res=None):

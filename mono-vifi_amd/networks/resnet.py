@@ -7,7 +7,24 @@ State-dict keys are torchvision's (``conv1.weight``, ``bn1.*``, ``layerN.M.conv1
 reference it forces ``find_unused_parameters=True`` and is all-reduced as zeros
 (SURVEY.md section 3.5); checkpoint loading filters keys it does not own.
 """
+import os
+
+import torch
 import torch.nn as nn
+import torch.nn.functional as F
+
+RESIDUAL_EPILOGUE = os.environ.get("MVF_FUSED_RESIDUAL", "1") != "0"      # developer knob for A/B timing
+
+
+def _add_relu(out, idt):
+    """relu(out + identity), the tail of every residual block: on the HIP device one epilogue
+    pass (ops.bias_act with a residual, in place on the batch-norm output) instead of add + clamp."""
+    from .. import layers
+    if (RESIDUAL_EPILOGUE and layers.FUSED_EPILOGUE and out.is_cuda and out.dtype == torch.float32 and idt.dtype == torch.float32
+            and out.shape == idt.shape and not torch.is_autocast_enabled()):
+        from .. import ops
+        return ops.bias_act(out, None, "relu", res=idt, inplace=True)
+    return F.relu(out + idt)
 
 
 def _conv3(cin, cout, stride=1):
@@ -30,7 +47,7 @@ class BasicBlock(nn.Module):
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.bn2(self.conv2(out))
-        return self.relu(out + idt)
+        return _add_relu(out, idt)
 
 
 class Bottleneck(nn.Module):
@@ -52,7 +69,7 @@ class Bottleneck(nn.Module):
         out = self.relu(self.bn1(self.conv1(x)))
         out = self.relu(self.bn2(self.conv2(out)))
         out = self.bn3(self.conv3(out))
-        return self.relu(out + idt)
+        return _add_relu(out, idt)
 
 
 _SPECS = {18: (BasicBlock, [2, 2, 2, 2]), 34: (BasicBlock, [3, 4, 6, 3]),

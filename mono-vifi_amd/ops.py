@@ -516,8 +516,12 @@ def _linspace(n, device):
     return t
 
 
+FLOW_WARP_BWD_GATHER = True     # False: float-atomic scatter for grad_img; tests compare both
+
+
 class FlowWarp(torch.autograd.Function):
-    """IFRNet.warp(img, flow); reference: networks/IFRNet.py:7-15"""
+    """IFRNet.warp(img, flow); reference: networks/IFRNet.py:7-15.  grad_img is a deterministic
+    gather through sorted inverse tap lists (mvf_flow_warp_bwd_gather); grad_flow is per-pixel."""
 
     @staticmethod
     def forward(ctx, img, flow):
@@ -538,15 +542,27 @@ class FlowWarp(torch.autograd.Function):
         img, flow, xs, ys = ctx.saved_tensors
         B, Cc, H, W = img.shape
         g_out = _c(g_out)
-        g_img = torch.zeros_like(img) if ctx.needs_input_grad[0] else None
+        gather = FLOW_WARP_BWD_GATHER and H >= 2 and W >= 2
+        g_img = None
+        if ctx.needs_input_grad[0]:
+            if gather:
+                g_img = torch.empty_like(img)
+                iw = torch.empty(nat.lib().mvf_fusion_bwd_workspace_ints(B, H, W), dtype=torch.int32, device=img.device)
+                nat.check(nat.lib().mvf_flow_warp_bwd_gather(nat.ptr(flow), nat.ptr(xs), nat.ptr(ys), nat.ptr(g_out),
+                                                             nat.ptr(g_img), nat.ptr(iw), B, Cc, H, W, _stream()),
+                          "flow_warp_bwd_gather")
+            else:
+                g_img = torch.zeros_like(img)
         g_flow = torch.empty_like(flow) if ctx.needs_input_grad[1] else None
-        ws = None
-        if g_flow is not None:
-            n = nat.lib().mvf_flow_warp_workspace_floats(B, Cc, H, W)
-            ws = torch.empty(n, dtype=torch.float32, device=img.device)
-        nat.check(nat.lib().mvf_flow_warp_bwd(nat.ptr(img), nat.ptr(flow), nat.ptr(xs), nat.ptr(ys),
-                                              nat.ptr(g_out), nat.ptr(g_img), nat.ptr(g_flow),
-                                              nat.ptr(ws), B, Cc, H, W, _stream()), "flow_warp_bwd")
+        if g_flow is not None or (g_img is not None and not gather):
+            ws = None
+            if g_flow is not None:
+                n = nat.lib().mvf_flow_warp_workspace_floats(B, Cc, H, W)
+                ws = torch.empty(n, dtype=torch.float32, device=img.device)
+            nat.check(nat.lib().mvf_flow_warp_bwd(nat.ptr(img), nat.ptr(flow), nat.ptr(xs), nat.ptr(ys),
+                                                  nat.ptr(g_out), nat.ptr(None if gather else g_img),
+                                                  nat.ptr(g_flow), nat.ptr(ws), B, Cc, H, W, _stream()),
+                      "flow_warp_bwd")
         return g_img, g_flow
 
 
@@ -911,14 +927,15 @@ class BiasAct(torch.autograd.Function):
         N, C = g.shape[0], g.shape[1]
         HW = g[0, 0].numel() if g.dim() > 2 else 1
         gx = torch.empty_like(g) if ctx.act != 0 else g
-        gb = None
-        if ctx.has_bias or ctx.act != 0:
+        gb = ws = None
+        if ctx.has_bias and ctx.needs_input_grad[1]:
             gb = torch.empty(C, dtype=torch.float32, device=g.device)
             ws = torch.empty(nat.lib().mvf_bias_act_workspace_floats(N, C, HW), dtype=torch.float32, device=g.device)
+        if gb is not None or ctx.act != 0:
             nat.check(nat.lib().mvf_bias_act_bwd(nat.ptr(g), nat.ptr(out), nat.ptr(gx if ctx.act != 0 else None),
                                                  nat.ptr(gb), nat.ptr(ws), N, C, HW, ctx.act, _stream()),
                       "bias_act_bwd")
-        return gx, (gb if ctx.has_bias else None), None, (gx if ctx.has_res else None), None, None
+        return gx, gb, None, (gx if ctx.has_res else None), None, None
 
 
 def bias_act(x, bias=None, act="none", slope=None, res=None, inplace=False):

@@ -484,8 +484,23 @@ def test_error_behaviour(dev):
 
 
 # ------------------------------------------------------------------ f1: flow warp (G7)
+@pytest.fixture
+def flow_bwd(request):
+    """grad_img route of the standalone flow warp: "gather" (deterministic, the default) or
+    "scatter" (float atomics)."""
+    from mono_vifi_amd import ops
+    old = ops.FLOW_WARP_BWD_GATHER
+    ops.FLOW_WARP_BWD_GATHER = request.param == "gather"
+    yield request.param
+    ops.FLOW_WARP_BWD_GATHER = old
+
+
+BOTH_FLOW_BWD = pytest.mark.parametrize("flow_bwd", ["gather", "scatter"], indirect=True)
+
+
+@BOTH_FLOW_BWD
 @pytest.mark.parametrize("case", ["a", "b", "big"])
-def test_flow_warp(dev, case):
+def test_flow_warp(dev, case, flow_bwd):
     from mono_vifi_amd import ops
     g = load_golden("g7_flow_" + case)
     assert np.array_equal(N(ops._linspace(g["img"].shape[3], dev)), g["xs"])
@@ -499,7 +514,8 @@ def test_flow_warp(dev, case):
     assert rel_err(N(flow.grad), g["grad_flow"]) <= 1e-5
 
 
-def test_flow_warp_feature_pyramid_vs_oracle(dev):
+@BOTH_FLOW_BWD
+def test_flow_warp_feature_pyramid_vs_oracle(dev, flow_bwd):
     """Feature-pyramid shapes of the fusion module (64..512 channels, 96x320 .. 6x20)."""
     from mono_vifi_amd import ops
     rng = np.random.default_rng(71)
@@ -517,6 +533,10 @@ def test_flow_warp_feature_pyramid_vs_oracle(dev):
         (out * T(wgt, dev)).sum().backward()
         g_img, _ = O.flow_warp_bwd(img, flow, xs, ys, wgt)
         assert rel_err(N(ti.grad), g_img) <= 1e-5
+        if flow_bwd == "gather":      # bit-reproducible: sorted inverse tap lists, no float atomics
+            t2 = T(img, dev, True)
+            (ops.flow_warp(t2, T(flow, dev)) * T(wgt, dev)).sum().backward()
+            assert torch.equal(t2.grad, ti.grad)
 
 
 # ------------------------------------------------------------------ f2: SI-log loss (G8)
@@ -977,6 +997,36 @@ def test_ifrnet_epilogue_equals_stock_ops(dev):
     a.requires_grad_(True)
     net(a, b, embt)[0].sum().backward()
     assert a.grad is not None and bool(torch.isfinite(a.grad).all())
+
+
+def test_resnet_residual_epilogue_equals_stock_ops(dev):
+    """relu(out + identity) of the residual blocks as one epilogue pass (in place on the batch-norm
+    output) against add + relu: features, input and parameter gradients, grouped and plain."""
+    from mono_vifi_amd import layers as L
+    from mono_vifi_amd.networks import grouped, monodepth2
+    torch.manual_seed(6)
+    enc = grouped.convert_grouped_batchnorm(monodepth2.DepthEncoder(18, False)).to(dev).train()
+    x = torch.rand(4, 3, 64, 96, device=dev)
+    for G in (1, 2):
+        res = {}
+        state = {k: v.clone() for k, v in enc.state_dict().items()}
+        for fused in (True, False):
+            L.FUSED_EPILOGUE = fused
+            try:
+                enc.load_state_dict(state)
+                enc.zero_grad()
+                xi = x.clone().requires_grad_(True)
+                with grouped.grouped(enc, G):
+                    feats = enc(xi)
+                sum((f ** 2).mean() for f in feats).backward()
+                res[fused] = ([f.detach().clone() for f in feats], xi.grad.clone(),
+                              torch.cat([p.grad.flatten() for p in enc.parameters()]))
+            finally:
+                L.FUSED_EPILOGUE = True
+        for a, b in zip(res[True][0], res[False][0]):
+            assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+        assert float((res[True][1] - res[False][1]).norm() / res[False][1].norm()) <= 1e-4
+        assert float((res[True][2] - res[False][2]).norm() / res[False][2].norm()) <= 1e-4
 
 
 # ------------------------------------------------------------------ f4: on-device augmentation
