@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 8
+#define MVF_ABI_VERSION 9
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -322,6 +322,23 @@ MVF_API int mvf_bias_act_fwd(const float *x, const float *bias, const float *slo
 MVF_API size_t mvf_bias_act_workspace_floats(int N, int C, int HW);
 MVF_API int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias, float *workspace, int N,
                      int C, int HW, int act, void *stream);
+/* F.interpolate(x, mode="bilinear", align_corners=...) over [planes, ih, iw] -> [planes, oh, ow]
+ * (HRNet fuse layers networks/hrnet_encoder.py:275-280: align_corners=True, coarse -> fine branch;
+ * Lite-Mono decoder networks/LiteMono.py:495, 502 through layers.py:225-228 `upsample`:
+ * scale_factor=2, align_corners=False).  scale_h / scale_w are ATen's area_pixel_compute_scale values:
+ * align_corners ? (in-1)/(out-1) (0 when out == 1) : (1/scale_factor when one was given, else
+ * in/out), as fp32.  One lane per output element; planes <= 262,140. */
+MVF_API int mvf_resize_bilinear_fwd(const float *x, float *out, int planes, int ih, int iw, int oh, int ow,
+                            float scale_h, float scale_w, int align_corners, void *stream);
+/* adjoint: deterministic gather (no float atomics), g_x [planes, ih, iw] fully written */
+MVF_API int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, int planes, int ih, int iw, int oh, int ow,
+                            float scale_h, float scale_w, int align_corners, void *stream);
+/* F.interpolate(x, scale_factor=f, mode="nearest") for an integer factor (layers.py:225-228
+ * `upsample`; DHRNet decoder networks/DHRNet.py branch merges): [planes, ih, iw] -> [planes, ih*f, iw*f];
+ * adjoint = the f x f block sum (gather, deterministic). */
+MVF_API int mvf_upsample_nearest_fwd(const float *x, float *out, int planes, int ih, int iw, int factor, void *stream);
+MVF_API int mvf_upsample_nearest_bwd(const float *g_out, float *g_x, int planes, int ih, int iw, int factor,
+                             void *stream);
 /* On-device colour augmentation of the data pipeline (datasets/mono_dataset.py:102-184, 214-256:
  * do_flip, do_color_aug with one torchvision ColorJitter draw per sample applied to all of its
  * frames).  img [samples*frames,3,H,W] (frame-minor), factors [samples,4] = {brightness, contrast,

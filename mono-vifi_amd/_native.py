@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -57,6 +57,10 @@ _SIGNATURES = {
     "mvf_bias_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_bias_act_workspace_floats": [_i, _i, _i],
     "mvf_bias_act_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_resize_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp],
+    "mvf_resize_bilinear_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp],
+    "mvf_upsample_nearest_fwd": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_upsample_nearest_bwd": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_color_jitter_workspace_floats": [_i],
     "mvf_color_jitter": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_unit_fwdbwd_scale": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -333,6 +333,160 @@ __global__ void __launch_bounds__(NT) k_bias_grad_finish(const float *__restrict
     gb[c] = a;
 }
 
+// ---- bilinear resize of feature maps ----------------------------------------------------------
+// F.interpolate(x, mode="bilinear") as the networks use it: HRNet's fuse layers
+// (align_corners=True, coarse branch -> fine branch, up to 8x), Lite-Mono's decoder
+// (scale_factor=2, align_corners=False).  ATen's NCHW kernel takes one thread per OUTPUT POSITION
+// and loops over batch x channels inside it: at 48x160 with 96x18 planes that is 7,680 threads
+// on 256 CUs (26 ms per DHRNet step for 42 launches).  Here one lane per output element, planes
+// along grid.y.  Source index and weights as ATen writes them (UpSample.h:
+// area_pixel_compute_source_index): align_corners ? scale*dst : max(scale*(dst+0.5)-0.5, 0);
+// value = h0*(w0*v00 + w1*v01) + h1*(w0*v10 + w1*v11).
+// Backward: deterministic gather.  The source index is monotonic in dst, so the output pixels
+// that touch input row iy form a contiguous run; each candidate of a conservatively widened run
+// is re-evaluated with the forward's own arithmetic and contributes its exact weight
+// (no float atomics; ATen's backward scatters with atomicAdd).
+struct Lin1 {
+    int i0, i1;
+    float w0, w1;
+};
+MVF_DEV Lin1 resize_lin(int dst, float scale, int n_in, int align)
+{
+    float src = align ? scale * (float)dst : scale * ((float)dst + 0.5f) - 0.5f;
+    if (!align && src < 0.0f) src = 0.0f;
+    Lin1 l;
+    l.i0 = min((int)src, n_in - 1);
+    l.i1 = (l.i0 < n_in - 1) ? l.i0 + 1 : l.i0;
+    l.w1 = src - (float)l.i0;
+    l.w0 = 1.0f - l.w1;
+    return l;
+}
+
+// grid (output pixel blocks, plane chunks); PLR planes per lane share the index arithmetic
+constexpr int PLR = 4;
+__global__ void __launch_bounds__(NT) k_resize_bilinear_fwd(const float *__restrict__ x, float *__restrict__ out,
+                                                            int planes, int ih, int iw, int oh, int ow,
+                                                            float sh, float sw, int align)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int oy = i / ow, ox = i - oy * ow;
+    const Lin1 ly = resize_lin(oy, sh, ih, align), lx = resize_lin(ox, sw, iw, align);
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)ih * iw, no = (size_t)oh * ow;
+    const int a00 = ly.i0 * iw + lx.i0, a01 = ly.i0 * iw + lx.i1, a10 = ly.i1 * iw + lx.i0, a11 = ly.i1 * iw + lx.i1;
+    float v[PLR][4];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) {
+        if (p0 + k < planes) {
+            const float *p = x + (size_t)(p0 + k) * ni;
+            v[k][0] = p[a00]; v[k][1] = p[a01]; v[k][2] = p[a10]; v[k][3] = p[a11];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes)
+            out[(size_t)(p0 + k) * no + i] = ly.w0 * (lx.w0 * v[k][0] + lx.w1 * v[k][1]) +
+                                            ly.w1 * (lx.w0 * v[k][2] + lx.w1 * v[k][3]);
+}
+
+// candidate run of output indices whose taps can include input index `i` (widened by one)
+MVF_DEV void resize_run(int i, float scale, int n_out, int align, int &lo, int &hi)
+{
+    if (!(scale > 0.0f)) { lo = 0; hi = n_out - 1; return; }
+    const float off = align ? 0.0f : 0.5f;
+    const float a = ((float)i - 1.0f + off) / scale - off, b = ((float)i + 1.0f + off) / scale - off;
+    lo = max((int)floorf(a) - 1, 0);
+    hi = min((int)ceilf(b) + 1, n_out - 1);
+}
+// weight of output index d for input index i (0 when d does not touch i)
+MVF_DEV float resize_weight(int d, int i, float scale, int n_in, int align)
+{
+    const Lin1 l = resize_lin(d, scale, n_in, align);
+    return ((l.i0 == i) ? l.w0 : 0.0f) + ((l.i1 == i) ? l.w1 : 0.0f);
+}
+
+// grid (input pixel blocks, plane chunks)
+__global__ void __launch_bounds__(NT) k_resize_bilinear_bwd(const float *__restrict__ g, float *__restrict__ gx,
+                                                            int planes, int ih, int iw, int oh, int ow, float sh,
+                                                            float sw, int align)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= ih * iw) return;
+    const int iy = i / iw, ix = i - iy * iw;
+    int ylo, yhi, xlo, xhi;
+    resize_run(iy, sh, oh, align, ylo, yhi);
+    resize_run(ix, sw, ow, align, xlo, xhi);
+    // tighten the x run to the touching candidates (weights are zero outside anyway)
+    while (xlo <= xhi && resize_weight(xlo, ix, sw, iw, align) == 0.0f) ++xlo;
+    while (xhi >= xlo && resize_weight(xhi, ix, sw, iw, align) == 0.0f) --xhi;
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)ih * iw, no = (size_t)oh * ow;
+    float acc[PLR];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) acc[k] = 0.0f;
+    for (int dy = ylo; dy <= yhi; ++dy) {
+        const float wy = resize_weight(dy, iy, sh, ih, align);
+        if (wy == 0.0f) continue;
+        for (int dx = xlo; dx <= xhi; ++dx) {
+            const float w = wy * resize_weight(dx, ix, sw, iw, align);
+            const float *gp = g + (size_t)p0 * no + (size_t)dy * ow + dx;
+#pragma unroll
+            for (int k = 0; k < PLR; ++k)
+                if (p0 + k < planes) acc[k] += w * gp[(size_t)k * no];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
+}
+
+// nearest-neighbour upsampling by an integer factor f (layers.py:225-228 `upsample`, the DHRNet
+// decoder's branch merges): out[Y][X] = x[Y/f][X/f]; adjoint = the f x f block sum (a gather).
+// ATen's NCHW kernels are position-parallel like the bilinear ones (4.6 ms backward per DHRNet step).
+__global__ void __launch_bounds__(NT) k_upsample_nearest_fwd(const float *__restrict__ x, float *__restrict__ out,
+                                                             int planes, int ih, int iw, int f)
+{
+    const int oh = ih * f, ow = iw * f;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= oh * ow) return;
+    const int oy = i / ow, ox = i - oy * ow;
+    const int src = (oy / f) * iw + ox / f;
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)ih * iw, no = (size_t)oh * ow;
+    float v[PLR];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes) v[k] = x[(size_t)(p0 + k) * ni + src];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes) out[(size_t)(p0 + k) * no + i] = v[k];
+}
+
+__global__ void __launch_bounds__(NT) k_upsample_nearest_bwd(const float *__restrict__ g, float *__restrict__ gx,
+                                                             int planes, int ih, int iw, int f)
+{
+    const int ow = iw * f;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= ih * iw) return;
+    const int iy = i / iw, ix = i - iy * iw;
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)ih * iw, no = ni * f * f;
+    float acc[PLR];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) acc[k] = 0.0f;
+    for (int dy = 0; dy < f; ++dy)
+        for (int dx = 0; dx < f; ++dx) {
+            const float *gp = g + (size_t)p0 * no + (size_t)(iy * f + dy) * ow + ix * f + dx;
+#pragma unroll
+            for (int k = 0; k < PLR; ++k)
+                if (p0 + k < planes) acc[k] += gp[(size_t)k * no];
+        }
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
+}
+
 // ---- on-device colour augmentation -------------------------------------------------------------
 // MonoDataset.__getitem__ / preprocess (datasets/mono_dataset.py:102-184, 214-256): with
 // probability 1/2 a sample's frames are flipped horizontally, and with probability 1/2 all of its
@@ -557,6 +711,47 @@ int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias
                            out, g_x, workspace, N, C, HW, act, nsplit);
     hipLaunchKernelGGL(k_bias_grad_finish, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream,
                        workspace, g_bias, C, nsplit);
+    return hip_check_launch();
+}
+
+int mvf_resize_bilinear_fwd(const float *x, float *out, int planes, int ih, int iw, int oh, int ow, float scale_h,
+                            float scale_w, int align_corners, void *stream)
+{
+    if (planes <= 0 || oh <= 0 || ow <= 0) return 0;
+    if (!x || !out || ih <= 0 || iw <= 0 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_resize_bilinear_fwd, dim3((unsigned)((oh * ow + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                       dim3(NT), 0, (hipStream_t)stream, x, out, planes, ih, iw, oh, ow, scale_h, scale_w,
+                       align_corners);
+    return hip_check_launch();
+}
+
+int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, int planes, int ih, int iw, int oh, int ow, float scale_h,
+                            float scale_w, int align_corners, void *stream)
+{
+    if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
+    if (!g_out || !g_x || oh <= 0 || ow <= 0 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_resize_bilinear_bwd, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                       dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw, oh, ow, scale_h, scale_w,
+                       align_corners);
+    return hip_check_launch();
+}
+
+int mvf_upsample_nearest_fwd(const float *x, float *out, int planes, int ih, int iw, int factor, void *stream)
+{
+    if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
+    if (!x || !out || factor < 1 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    const int no = ih * factor * iw * factor;
+    hipLaunchKernelGGL(k_upsample_nearest_fwd, dim3((unsigned)((no + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                       dim3(NT), 0, (hipStream_t)stream, x, out, planes, ih, iw, factor);
+    return hip_check_launch();
+}
+
+int mvf_upsample_nearest_bwd(const float *g_out, float *g_x, int planes, int ih, int iw, int factor, void *stream)
+{
+    if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
+    if (!g_out || !g_x || factor < 1 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_upsample_nearest_bwd, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                       dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw, factor);
     return hip_check_launch();
 }
 

@@ -139,7 +139,14 @@ def get_smooth_loss(disp, img):
 
 # ----------------------------------------------------------------------------- conv blocks
 def upsample(x, scale_factor=2, mode="nearest"):
-    """reference: layers.py:225-228"""
+    """reference: layers.py:225-228.  On the HIP device (fp32) bilinear (Lite-Mono decoder) and
+    integer-factor nearest (DHRNet decoder) run as element-parallel kernels with gather adjoints:
+    ATen's NCHW kernels take one thread per output POSITION and loop over batch x channels."""
+    if FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled():
+        if mode == "bilinear":
+            return ops.resize_bilinear(x, scale_factor=scale_factor, align_corners=False)
+        if mode == "nearest" and int(scale_factor) == scale_factor and scale_factor >= 1:
+            return ops.upsample_nearest(x, int(scale_factor))
     return F.interpolate(x, scale_factor=scale_factor, mode=mode)
 
 

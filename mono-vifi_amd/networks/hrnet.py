@@ -9,10 +9,22 @@ state-dict keys match the reference (`conv1`, `layer1.N`, `transitionK.i`, `stag
 `stageK.m.fuse_layers.i.j`), so `HRNet_W18_C_*.pth.tar` ImageNet weights and the reference's
 checkpoints load.  The architecture is table-driven here instead of config-object driven
 (yacs is absent)."""
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .resnet import BasicBlock, Bottleneck
+
+
+def _resize_ac(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=True) (reference:
+    networks/hrnet_encoder.py:275-280); on the HIP device the element-parallel kernel
+    (ops.resize_bilinear) with a deterministic gather backward."""
+    from .. import layers
+    if layers.FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+        from .. import ops
+        return ops.resize_bilinear(x, size=size, align_corners=True)
+    return F.interpolate(x, size=size, mode="bilinear", align_corners=True)
 
 # (number of exchange modules, channels per branch) of stages 2..4
 _WIDTHS = {"hrnet18": 18, "hrnet32": 32, "hrnet48": 48, "hrnet64": 64}
@@ -65,8 +77,7 @@ class ExchangeModule(nn.Module):
                 if j == i:
                     term = xs[j]
                 elif j > i:
-                    term = F.interpolate(self.fuse_layers[i][j](xs[j]), size=xs[i].shape[-2:],
-                                         mode="bilinear", align_corners=True)
+                    term = _resize_ac(self.fuse_layers[i][j](xs[j]), xs[i].shape[-2:])
                 else:
                     term = self.fuse_layers[i][j](xs[j])
                 acc = term if acc is None else acc + term

@@ -878,6 +878,88 @@ def disp_head(logit, min_depth=0.1, max_depth=100.0, want_depth=True):
     return disp, (depth if want_depth else None), part
 
 
+class ResizeBilinear(torch.autograd.Function):
+    """F.interpolate(x, mode="bilinear", align_corners=...) for feature maps (reference:
+    networks/hrnet_encoder.py:275-280, networks/LiteMono.py:495, 502 via layers.py:225-228):
+    one lane per output element forward, deterministic gather backward."""
+
+    @staticmethod
+    def forward(ctx, x, oh, ow, sh, sw, align):
+        nat.require_device(x)
+        x = _c(x)
+        if x.dim() != 4:
+            raise RuntimeError("resize_bilinear expects [N,C,H,W]")
+        N, C, ih, iw = x.shape
+        out = torch.empty((N, C, oh, ow), dtype=torch.float32, device=x.device)
+        nat.check(nat.lib().mvf_resize_bilinear_fwd(nat.ptr(x), nat.ptr(out), N * C, ih, iw, oh, ow, sh, sw,
+                                                    int(align), _stream()), "resize_bilinear_fwd")
+        ctx.geom = (N, C, ih, iw, oh, ow, sh, sw, int(align))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, ih, iw, oh, ow, sh, sw, align = ctx.geom
+        g = _c(g)
+        gx = torch.empty((N, C, ih, iw), dtype=torch.float32, device=g.device)
+        nat.check(nat.lib().mvf_resize_bilinear_bwd(nat.ptr(g), nat.ptr(gx), N * C, ih, iw, oh, ow, sh, sw, align,
+                                                    _stream()), "resize_bilinear_bwd")
+        return gx, None, None, None, None, None
+
+
+def resize_scales(ih, iw, oh, ow, align_corners, scale_factor=None):
+    """ATen's area_pixel_compute_scale for both axes, as the fp32 values its kernels use."""
+    f32 = np.float32
+
+    def one(n_in, n_out):
+        if align_corners:
+            return float(f32(n_in - 1) / f32(n_out - 1)) if n_out > 1 else 0.0
+        if scale_factor is not None and scale_factor > 0:
+            return float(f32(1.0 / scale_factor))
+        return float(f32(n_in) / f32(n_out))
+    return one(ih, oh), one(iw, ow)
+
+
+def resize_bilinear(x, size=None, scale_factor=None, align_corners=False):
+    """Drop-in for F.interpolate(x, size= | scale_factor=, mode="bilinear", align_corners=...)."""
+    ih, iw = x.shape[-2:]
+    if size is not None:
+        oh, ow = int(size[0]), int(size[1])
+        sf = None
+    else:
+        oh, ow = int(np.floor(ih * float(scale_factor))), int(np.floor(iw * float(scale_factor)))
+        sf = float(scale_factor)
+    sh, sw = resize_scales(ih, iw, oh, ow, bool(align_corners), sf)
+    return ResizeBilinear.apply(x, oh, ow, sh, sw, bool(align_corners))
+
+
+class UpsampleNearest(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=f, mode="nearest"), integer f (reference layers.py:225-228)."""
+
+    @staticmethod
+    def forward(ctx, x, f):
+        nat.require_device(x)
+        x = _c(x)
+        N, C, ih, iw = x.shape
+        out = torch.empty((N, C, ih * f, iw * f), dtype=torch.float32, device=x.device)
+        nat.check(nat.lib().mvf_upsample_nearest_fwd(nat.ptr(x), nat.ptr(out), N * C, ih, iw, f, _stream()),
+                  "upsample_nearest_fwd")
+        ctx.geom = (N, C, ih, iw, f)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        N, C, ih, iw, f = ctx.geom
+        g = _c(g)
+        gx = torch.empty((N, C, ih, iw), dtype=torch.float32, device=g.device)
+        nat.check(nat.lib().mvf_upsample_nearest_bwd(nat.ptr(g), nat.ptr(gx), N * C, ih, iw, f, _stream()),
+                  "upsample_nearest_bwd")
+        return gx, None
+
+
+def upsample_nearest(x, factor):
+    return UpsampleNearest.apply(x, int(factor))
+
+
 _ACT_CODES = {"none": 0, "elu": 1, "relu": 2, "prelu": 3}
 
 

@@ -329,18 +329,24 @@ def set_threads(n):
 
 # --------------------------------------------------------------------------- f1: FusionModule
 # reference: networks/fusion_module.py:65-130 (what enters the per-scale 1x1 convolutions).
-def resize_bilinear(x, oh, ow, scale_factor=None):
-    """F.interpolate(x, mode="bilinear", align_corners=False) as ATen's CPU kernel evaluates it:
+def resize_bilinear(x, oh, ow, scale_factor=None, align_corners=False):
+    """F.interpolate(x, mode="bilinear") as ATen's CPU kernel evaluates it.  align_corners=False:
     src = scale*(dst+0.5)-0.5 clamped at 0 (scale = in/out for size=..., 1/scale_factor when a
-    scale factor was given), and out = wy0*(wx0*v00 + wx1*v01) + wy1*(wx0*v10 + wx1*v11)."""
+    scale factor was given); align_corners=True: src = dst*(in-1)/(out-1).
+    out = wy0*(wx0*v00 + wx1*v01) + wy1*(wx0*v10 + wx1*v11)."""
     x = _f(x)
     H, W = x.shape[-2:]
     f32 = np.float32
 
     def axis(n_in, n_out):
-        scale = f32(1.0 / scale_factor) if scale_factor is not None else f32(n_in) / f32(n_out)
-        src = scale * (np.arange(n_out, dtype=f32) + f32(0.5)) - f32(0.5)
-        src = np.maximum(src, f32(0.0))
+        d = np.arange(n_out, dtype=f32)
+        if align_corners:
+            scale = f32(n_in - 1) / f32(n_out - 1) if n_out > 1 else f32(0.0)
+            src = (scale * d).astype(f32)
+        else:
+            scale = f32(1.0 / scale_factor) if scale_factor is not None else f32(n_in) / f32(n_out)
+            src = scale * (d + f32(0.5)) - f32(0.5)
+            src = np.maximum(src, f32(0.0))
         i0 = np.minimum(src.astype(np.int64), n_in - 1)
         i1 = np.minimum(i0 + 1, n_in - 1)
         l1 = (src - i0.astype(f32)).astype(f32)
@@ -351,6 +357,38 @@ def resize_bilinear(x, oh, ow, scale_factor=None):
     top = wx0 * x[..., y0, :][..., x0] + wx1 * x[..., y0, :][..., x1]
     bot = wx0 * x[..., y1, :][..., x0] + wx1 * x[..., y1, :][..., x1]
     return (wy0[:, None] * top.astype(f32) + wy1[:, None] * bot.astype(f32)).astype(f32)
+
+
+def resize_bilinear_bwd(g, ih, iw, scale_factor=None, align_corners=False):
+    """Adjoint of resize_bilinear w.r.t. its input (fp64 accumulation): scatter of the four taps."""
+    g = np.asarray(g, np.float64)
+    oh, ow = g.shape[-2:]
+    f32 = np.float32
+
+    def axis(n_in, n_out):
+        d = np.arange(n_out, dtype=f32)
+        if align_corners:
+            scale = f32(n_in - 1) / f32(n_out - 1) if n_out > 1 else f32(0.0)
+            src = (scale * d).astype(f32)
+        else:
+            scale = f32(1.0 / scale_factor) if scale_factor is not None else f32(n_in) / f32(n_out)
+            src = np.maximum(scale * (d + f32(0.5)) - f32(0.5), f32(0.0))
+        i0 = np.minimum(src.astype(np.int64), n_in - 1)
+        i1 = np.minimum(i0 + 1, n_in - 1)
+        l1 = (src - i0.astype(f32)).astype(np.float64)
+        return i0, i1, 1.0 - l1, l1
+
+    y0, y1, wy0, wy1 = axis(ih, oh)
+    x0, x1, wx0, wx1 = axis(iw, ow)
+    My = np.zeros((ih, oh))
+    Mx = np.zeros((iw, ow))
+    for d in range(oh):
+        My[y0[d], d] += wy0[d]
+        My[y1[d], d] += wy1[d]
+    for d in range(ow):
+        Mx[x0[d], d] += wx0[d]
+        Mx[x1[d], d] += wx1[d]
+    return np.einsum("yd,...de,xe->...yx", My, g, Mx)
 
 
 def flow_embedding(x, num_freqs=10):

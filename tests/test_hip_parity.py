@@ -1029,6 +1029,90 @@ def test_resnet_residual_epilogue_equals_stock_ops(dev):
         assert float((res[True][2] - res[False][2]).norm() / res[False][2].norm()) <= 1e-4
 
 
+def test_resize_bilinear_vs_oracle(dev):
+    """mvf_resize_bilinear_fwd/bwd (HRNet fuse layers: align_corners=True up to 8x; Lite-Mono
+    decoder: scale_factor=2) against the oracle (itself pinned to ATen's CPU kernels), forward
+    and the gather adjoint; the adjoint is bit-reproducible; drop-in for F.interpolate on the device."""
+    import torch.nn.functional as F
+    from mono_vifi_amd import ops
+    rng = np.random.default_rng(13)
+    cases = [(2, 18, 6, 20, 48, 160, None, True), (2, 36, 12, 40, 24, 80, None, True),
+             (2, 18, 24, 80, 48, 160, None, True), (3, 40, 24, 80, 48, 160, 2.0, False),
+             (1, 5, 5, 7, 13, 9, None, True), (1, 5, 5, 7, 13, 9, None, False),
+             (2, 3, 16, 16, 8, 8, 0.5, False), (1, 2, 3, 4, 1, 1, None, True),
+             (1, 7, 9, 11, 9, 11, None, True), (2, 16, 80, 256, 160, 512, 2.0, False)]
+    for (B, C, ih, iw, oh, ow, sf, ac) in cases:
+        x = rng.standard_normal((B, C, ih, iw)).astype(np.float32)
+        w = rng.standard_normal((B, C, oh, ow)).astype(np.float32)
+        xt = T(x, dev, True)
+        out = ops.resize_bilinear(xt, size=None if sf is not None else (oh, ow), scale_factor=sf, align_corners=ac)
+        assert tuple(out.shape) == (B, C, oh, ow)
+        ref = O.resize_bilinear(x, oh, ow, sf, ac)
+        assert np.abs(N(out) - ref).max() <= 2e-6, (ih, iw, oh, ow, sf, ac)
+        (out * T(w, dev)).sum().backward()
+        gref = O.resize_bilinear_bwd(w, ih, iw, sf, ac)
+        assert rel_err(N(xt.grad), gref) <= 1e-5, (ih, iw, oh, ow, sf, ac)
+        x2 = T(x, dev, True)
+        (ops.resize_bilinear(x2, size=None if sf is not None else (oh, ow), scale_factor=sf, align_corners=ac)
+         * T(w, dev)).sum().backward()
+        assert torch.equal(x2.grad, xt.grad)
+        # ATen's own device kernel agrees
+        x3 = T(x, dev, True)
+        y3 = (F.interpolate(x3, scale_factor=sf, mode="bilinear", align_corners=ac) if sf is not None
+              else F.interpolate(x3, size=(oh, ow), mode="bilinear", align_corners=ac))
+        assert float((y3 - out).abs().max()) <= 2e-6
+
+
+def test_dhrnet_device_glue_equals_stock_ops(dev):
+    """HRNet18 encoder + DHRNet decoder with the device glue (bilinear resize kernel, convolution
+    epilogues) against the stock op-by-op form: disparities and parameter gradients."""
+    from mono_vifi_amd import layers as L
+    from mono_vifi_amd.networks import dhrnet
+    torch.manual_seed(8)
+    enc = dhrnet.DepthEncoder().to(dev).train()
+    dec = dhrnet.DepthDecoder(enc.num_ch_enc).to(dev).train()
+    x = torch.rand(4, 3, 128, 192, device=dev)
+    params = list(enc.parameters()) + list(dec.parameters())
+    res = {}
+    state = ({k: v.clone() for k, v in enc.state_dict().items()}, {k: v.clone() for k, v in dec.state_dict().items()})
+    for fused in (True, False, None):          # None: the stock form again (its own repeatability)
+        L.FUSED_EPILOGUE = bool(fused)
+        try:
+            enc.load_state_dict(state[0]); dec.load_state_dict(state[1])
+            for p in params:
+                p.grad = None
+            out = dec(enc(x))
+            disp = out[("disp", 0)]
+            (disp ** 2).mean().backward()
+            res[fused] = (disp.detach().clone(), torch.cat([p.grad.flatten() for p in params if p.grad is not None]))
+        finally:
+            L.FUSED_EPILOGUE = True
+    assert float((res[True][0] - res[False][0]).abs().max()) <= 2e-5
+    # HRNet's backward is not run-to-run reproducible in the stock form (atomic scatter in ATen's
+    # bilinear backward, MIOpen weight gradients): the bar is that repeatability
+    noise = float((res[None][1] - res[False][1]).norm() / res[False][1].norm())
+    dev_ = float((res[True][1] - res[False][1]).norm() / res[False][1].norm())
+    assert dev_ <= 1e-4 + 3.0 * noise, (dev_, noise)
+
+
+def test_upsample_nearest_vs_torch(dev):
+    """mvf_upsample_nearest_fwd/bwd (layers.py:225-228) against F.interpolate(mode="nearest") and
+    its autograd: exact forward, block-sum adjoint."""
+    import torch.nn.functional as F
+    from mono_vifi_amd import layers, ops
+    g = torch.Generator(device="cpu").manual_seed(17)
+    for (B, C, h, w, f) in ((2, 18, 24, 80, 2), (1, 5, 3, 7, 4), (2, 36, 12, 40, 8), (1, 1, 1, 1, 2), (2, 7, 9, 5, 1)):
+        x = torch.randn(B, C, h, w, generator=g).to(dev)
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya = layers.upsample(xa, f)
+        yb = F.interpolate(xb, scale_factor=f, mode="nearest")
+        assert torch.equal(ya, yb)
+        wgt = torch.randn(ya.shape, generator=g).to(dev)
+        (ya * wgt).sum().backward()
+        (yb * wgt).sum().backward()
+        assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * max(1.0, float(xb.grad.abs().max()))
+
+
 # ------------------------------------------------------------------ f4: on-device augmentation
 def test_color_jitter_vs_oracle(dev):
     """mvf_color_jitter (flip + ColorJitter of datasets/mono_dataset.py:214-256 for a batch on the

@@ -217,3 +217,26 @@ def test_fusion_oracle_vs_golden(case):
         assert rel_err(gn[i], g[f"grad_n1_{i}"]) <= 1e-5
         assert rel_err(g0[i], g[f"grad_0_{i}"]) <= 1e-6
         assert rel_err(gp[i], g[f"grad_p1_{i}"]) <= 1e-5
+
+
+def test_resize_bilinear_oracle_vs_aten():
+    """F.interpolate(mode="bilinear") IS the reference's function for the HRNet fuse layers
+    (networks/hrnet_encoder.py:275-280, align_corners=True) and the Lite-Mono decoder
+    (networks/LiteMono.py:495 via layers.py:225-228, scale_factor=2): the oracle's restatement and
+    its adjoint against ATen's CPU kernels."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(3)
+    for (ih, iw, oh, ow, sf, ac) in [(6, 20, 48, 160, None, True), (12, 40, 24, 80, None, True),
+                                     (24, 80, 48, 160, 2.0, False), (5, 7, 13, 9, None, True),
+                                     (5, 7, 13, 9, None, False), (16, 16, 8, 8, 0.5, False),
+                                     (3, 4, 1, 1, None, True), (9, 11, 9, 11, None, True)]:
+        x = rng.standard_normal((2, 3, ih, iw)).astype(np.float32)
+        xt = torch.tensor(x, requires_grad=True)
+        y = (F.interpolate(xt, scale_factor=sf, mode="bilinear", align_corners=ac) if sf is not None
+             else F.interpolate(xt, size=(oh, ow), mode="bilinear", align_corners=ac))
+        assert tuple(y.shape[-2:]) == (oh, ow)
+        w = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+        (y * torch.tensor(w)).sum().backward()
+        assert np.abs(O.resize_bilinear(x, oh, ow, sf, ac) - y.detach().numpy()).max() <= 2e-6
+        assert np.abs(O.resize_bilinear_bwd(w, ih, iw, sf, ac) - xt.grad.numpy()).max() <= 2e-5
