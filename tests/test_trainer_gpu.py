@@ -106,7 +106,9 @@ def test_other_backbones_step(tmp_path, backbone):
     # kernels), so the bar for the parameter gradients is the step's own repeatability: the
     # staged step is run three times and fused-vs-staged may not exceed 1e-4 + three times the
     # largest deviation among the repeats (one repeat is too weak an estimate: the test flaked).
-    for tag, fused in (("fused", True), ("staged", False), ("staged2", False), ("staged3", False)):
+    # "warm": on a fresh box the first pass over a convolution shape runs MIOpen's solver search
+    # and can execute with other solvers than the passes after it (the test flaked on cold boxes)
+    for tag, fused in (("warm", True), ("fused", True), ("staged", False), ("staged2", False), ("staged3", False)):
         for k, m in t.models.items():
             m.load_state_dict(state0[k])
         t.opt.fused_units = fused
