@@ -17,6 +17,46 @@ import torch.nn.functional as F
 from ..layers import Conv3x3, ConvBlock, upsample
 
 
+class _TokenLinear(torch.autograd.Function):
+    """``F.linear`` over a token tensor [B, ..., C_in] whose WEIGHT gradient is formed per image
+    and then summed.  The stock gradient dW = dY^T X is one GEMM with a tiny output (C_out x C_in,
+    e.g. 288 x 48) and a reduction length of B*H*W tokens (1.3 M at 1024x320): hipBLASLt runs it
+    on 18 workgroups, 1.5 ms per layer and 25 ms per Lite-Mono step.  As a batched GEMM over the
+    B images it fills the device; the B partial products are folded with one small sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = g @ weight
+        B = x.shape[0]
+        g3, x3 = g.reshape(B, -1, g.shape[-1]), x.reshape(B, -1, x.shape[-1])
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(g3.transpose(1, 2), x3).sum(0)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g3.sum((0, 1))
+        return gx, gw, gb
+
+
+SPLIT_TOKEN_GRAD = True      # False: stock nn.Linear backward (tests compare both)
+
+
+def token_linear(lin, x):
+    """``lin(x)`` for an ``nn.Linear`` over [B, tokens..., C]; on the device with many tokens per
+    image the weight gradient takes the per-image batched form."""
+    if (SPLIT_TOKEN_GRAD and x.is_cuda and x.dim() >= 3 and x.shape[0] > 1 and torch.is_grad_enabled()
+            and lin.weight.requires_grad and x[0].numel() // x.shape[-1] >= 1024):
+        return _TokenLinear.apply(x, lin.weight, lin.bias)
+    return lin(x)
+
+
 class DropPath(nn.Module):
     """Stochastic depth: drops the residual branch of whole samples with probability p."""
 
@@ -76,11 +116,11 @@ class XCA(nn.Module):
 
     def forward(self, x):
         B, N, C = x.shape
-        qkv = self.qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 4, 1)
+        qkv = token_linear(self.qkv, x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 4, 1)
         q, k, v = F.normalize(qkv[0], dim=-1), F.normalize(qkv[1], dim=-1), qkv[2]
         attn = self.attn_drop(((q @ k.transpose(-2, -1)) * self.temperature).softmax(dim=-1))
         x = (attn @ v).permute(0, 3, 1, 2).reshape(B, N, C)
-        return self.proj_drop(self.proj(x))
+        return self.proj_drop(token_linear(self.proj, x))
 
 
 class LayerNorm(nn.Module):
@@ -140,7 +180,7 @@ class _InvertedBottleneck(nn.Module):
     """Shared tail of both block types: (LayerNorm) -> Linear xE -> GELU -> Linear -> gamma."""
 
     def _mlp(self, x):
-        x = self.pwconv2(self.act(self.pwconv1(x)))
+        x = token_linear(self.pwconv2, self.act(token_linear(self.pwconv1, x)))
         return x if self.gamma is None else self.gamma * x
 
 

@@ -261,3 +261,22 @@ def test_resume_from_a_checkpoint_written_in_the_reference_layout(ref, tmp_path)
             assert torch.equal(v.cpu(), ckpt[name][k]), (name, k)
     assert t.models["encoder_mf"] is t.models["encoder"]
     assert len(t.model_optimizer.state_dict()["state"]) == 0      # restarted, not crashed
+
+
+def test_token_linear_weight_gradient_equals_stock_linear():
+    """Lite-Mono's token MLPs form the weight gradient per image (batched GEMM) and sum: same
+    function as nn.Linear's single tall-skinny GEMM."""
+    import torch
+    from mono_vifi_amd.networks import litemono
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(12, 30)
+    x = torch.randn(3, 5, 7, 12, requires_grad=True)
+    w = torch.randn(3, 5, 7, 30)
+    y = litemono._TokenLinear.apply(x, lin.weight, lin.bias)
+    (y * w).sum().backward()
+    got = (x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x.grad = None
+    lin.zero_grad()
+    (lin(x) * w).sum().backward()
+    for a, b in zip(got, (x.grad, lin.weight.grad, lin.bias.grad)):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
