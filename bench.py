@@ -82,6 +82,12 @@ def parse():
     ap.add_argument("--channels-last", dest="channels_last", action="store_true")
     ap.add_argument("--miopen-find", dest="miopen_find", action="store_true",
                     help="torch.backends.cudnn.benchmark=True (MIOpen exhaustive find in warm-up)")
+    ap.add_argument("--hip-graph", dest="hip_graph", action="store_true",
+                    help="train workload: the timed steps replay the whole optimisation step as ONE "
+                         "HIP graph (trainer --hip_graph); the unit kernel's events cannot be recorded "
+                         "inside a graph, so `roofline` then comes from the hot-path-only leg")
+    ap.add_argument("--no-graph-leg", dest="no_graph_leg", action="store_true",
+                    help="train workload: skip the extra HIP-graph measurement of the step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -374,6 +380,33 @@ def hotpath_leg(args, rank, dev, nat, steps=20, warmup=5):
             "roofline": dom, "hip_graph_replay": graph_replay_leg(step)}
 
 
+def graph_step_leg(args, rank, world, dev, steps=20):
+    """The same optimisation step with its device work captured into ONE HIP graph
+    (mono-vifi_amd/trainer.py:_StepGraph) and replayed: extra to the eager, event-timed figure."""
+    try:
+        import copy
+        from mono_vifi_amd.bench_train import TrainStep
+        a = copy.copy(args)
+        a.hip_graph = True
+        step = TrainStep(a, rank, world, dev)
+        for _ in range(step.trainer._step_graph.WARMUP + 3):
+            step()
+        assert step.trainer._step_graph.graph is not None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"value": round(step.images_per_step * steps / dt, 2), "unit": "images/sec",
+                "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
+                "note": "whole optimisation step (networks, 9 units, backward, clip, AdamW) replayed as one "
+                        "HIP graph per step; tie-break noise from torch.randn (graph-safe) instead of the "
+                        "in-kernel generator"}
+    except Exception as e:      # noqa: BLE001 -- an optional leg must never take the bench line down
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
 def main():
     args = parse()
     world, rank, dev = dist_setup(args)
@@ -393,6 +426,9 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    if workload == "train" and args.hip_graph:
+        while step.trainer._step_graph.graph is None:      # eager warm-up + capture stay untimed
+            step()
     nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
     nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
     barrier_sync(world)
@@ -417,6 +453,15 @@ def main():
     if workload == "train" and rank == 0 and world == 1 and not args.no_hotpath_leg:
         hotpath_only = hotpath_leg(args, rank, dev, nat)
 
+    graph_leg = None
+    if workload == "train" and rank == 0 and world == 1 and not args.hip_graph and not args.no_graph_leg:
+        del step.trainer        # the eager trainer's activations are not needed any more
+        torch.cuda.empty_cache()
+        graph_leg = graph_step_leg(args, rank, world, dev)
+    if args.hip_graph and workload == "train" and dominant is None and hotpath_only:
+        dominant = dict(hotpath_only["roofline"] or {})
+        dominant["note"] = "measured in the hot-path-only leg of this run (HIP events are not recorded inside a graph replay)"
+
     if rank == 0:
         images = step.images_per_step * world * args.steps
         out = {
@@ -436,6 +481,8 @@ def main():
         }
         if hotpath_only:
             out["hotpath_only"] = hotpath_only
+        if graph_leg:
+            out["hip_graph_step"] = graph_leg
         if workload == "hotpath" and world == 1:
             out["hip_graph_replay"] = graph_replay_leg(step)
         if not args.no_cpu_baseline and world == 1:

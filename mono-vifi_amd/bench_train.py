@@ -26,7 +26,8 @@ class TrainStep:
             exp_name=f"bench_r{rank}", num_workers=0, synthetic_len=max(4096, args.batch * world * 4),
             log_frequency=10 ** 9, save_frequency=10 ** 9, learning_rate=1e-4,
             amp_bf16=getattr(args, "amp_bf16", False), channels_last=getattr(args, "channels_last", False),
-            inkernel_noise=getattr(args, "noise", "kernel") == "kernel")
+            inkernel_noise=getattr(args, "noise", "kernel") == "kernel",
+            hip_graph=bool(getattr(args, "hip_graph", False)))
         self.trainer = Trainer(opts)
         self.trainer.set_train()
         b = synthetic.training_batch(1234 + 7919 * rank, args.batch, args.height, args.width)
@@ -41,7 +42,8 @@ class TrainStep:
                 f"hot-path units (forward+backward tile kernel), "
                 f"{'grouped' if o.group_calls else 'one-at-a-time'} network calls with per-call "
                 f"BatchNorm statistics, AdamW, random-init weights, device-resident synthetic batch "
-                f"(data loading excluded), nets {'bf16 autocast' if o.amp_bf16 else 'fp32'}")
+                f"(data loading excluded), nets {'bf16 autocast' if o.amp_bf16 else 'fp32'}"
+                f"{', device work of the step replayed as one HIP graph' if o.hip_graph else ''}")
 
     def __call__(self):
         return self.trainer.optimisation_step(dict(self.batch))

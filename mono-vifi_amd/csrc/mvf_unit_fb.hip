@@ -257,6 +257,16 @@ struct WarpBatch {
     float a[U][3][4], bq[U][3][4];
 };
 
+#ifdef MVF_ABL_FB_LDSTAPS
+// the access pattern of a window-staged source: two 8-byte LDS reads per tap set at the tap's
+// (clamped) position inside the workgroup's plane; the values are NOT the source's
+MVF_DEV void lds_taps(const float *__restrict__ plane, int lx, int ly, int ch, float t[4])
+{
+    const float *l = plane + min(max(ly, 0), PH - 2) * LDW + min(max(lx, 0), PW - 2);
+    t[0] = l[0] + (float)ch; t[1] = l[1]; t[2] = l[LDW]; t[3] = l[LDW + 1];
+}
+#endif
+
 template <int U>
 MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
 {
@@ -269,8 +279,14 @@ MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
+#ifdef MVF_ABL_FB_LDSTAPS   // timing ablation: every tap pair from an LDS plane (upper bound of what an
+                           // LDS-staged source window could gain -- at NO cost in LDS capacity)
+            lds_taps(k.dispP, w.s[u].x0a - k.px0, w.s[u].y0a - k.py0, ch, w.a[u][ch]);
+            lds_taps(k.dispP, w.s[u].x0b - k.px0, w.s[u].y0b - k.py0, ch, w.bq[u][ch]);
+#else
             load_taps(k.sa + ch * N, w.s[u].qa.q, w.a[u][ch][0], w.a[u][ch][1], w.a[u][ch][2], w.a[u][ch][3]);
             load_taps(k.sb + ch * N, w.s[u].qb.q, w.bq[u][ch][0], w.bq[u][ch][1], w.bq[u][ch][2], w.bq[u][ch][3]);
+#endif
         }
 }
 
@@ -734,8 +750,18 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             float dxa[3], dya[3], dxb[3], dyb[3];
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
+#ifdef MVF_ABL_FB_LDSTAPS
+                float ta4[4], tb4[4];
+                lds_taps(dispP, w.ta.x0 - px0, w.ta.y0 - py0, ch, ta4);
+                lds_taps(dispP, w.tb.x0 - px0, w.tb.y0 - py0, ch, tb4);
+                dxa[ch] = (ta4[1] - ta4[0]) * (1.0f - w.ta.wy) + (ta4[3] - ta4[2]) * w.ta.wy;
+                dya[ch] = (ta4[2] - ta4[0]) * (1.0f - w.ta.wx) + (ta4[3] - ta4[1]) * w.ta.wx;
+                dxb[ch] = (tb4[1] - tb4[0]) * (1.0f - w.tb.wy) + (tb4[3] - tb4[2]) * w.tb.wy;
+                dyb[ch] = (tb4[2] - tb4[0]) * (1.0f - w.tb.wx) + (tb4[3] - tb4[1]) * w.tb.wx;
+#else
                 bilerp_grad(sa + ch * N, W, w.ta, dxa[ch], dya[ch]);
                 bilerp_grad(sb + ch * N, W, w.tb, dxb[ch], dyb[ch]);
+#endif
             }
             const f2 gix = g0 * mk2(dxa[0], dxb[0]) + g1 * mk2(dxa[1], dxb[1]) + g2 * mk2(dxa[2], dxb[2]);
             const f2 giy = g0 * mk2(dya[0], dyb[0]) + g1 * mk2(dya[1], dyb[1]) + g2 * mk2(dya[2], dyb[2]);

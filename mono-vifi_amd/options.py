@@ -112,6 +112,10 @@ def build_parser():
     p.add_argument("--inkernel_noise", type=_str2bool, default=True,
                    help="auto-mask tie-break noise (train.py:1023-1024) drawn inside the unit kernel "
                         "from a counter-based generator instead of a torch.randn tensor per unit")
+    p.add_argument("--hip_graph", type=_str2bool, default=False,
+                   help="capture the device work of an optimisation step (networks, hot-path units, "
+                        "backward, clipping, AdamW) once into a HIP graph and replay it: one launch "
+                        "per step instead of thousands (needs static shapes; trainer._StepGraph)")
     p.add_argument("--bucket_mb", type=float, default=32.0, help="gradient all-reduce bucket size")
     p.add_argument("--force_collectives", type=_str2bool, default=False,
                    help="issue the data-parallel collectives (bucketed gradient all-reduce, "

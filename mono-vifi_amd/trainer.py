@@ -195,21 +195,34 @@ class Trainer(HotPathLosses):
             parallel.broadcast_module_states([self.model_vfi_train, self.model_vfi_test], src=0)
 
         # ---- optimiser (reference: train.py:229-246)
+        use_graph = bool(getattr(o, "hip_graph", False)) and self.device.type == "cuda"
+        if use_graph and o.optimizer not in ("adamw", "adam"):
+            raise ValueError("--hip_graph needs a capturable optimizer (adamw / adam)")
+        # under a HIP graph the step counter and the learning rate live on the device: the
+        # schedulers then update the rate in place (fill_) and the replayed launch reads it
+        gkw = {"capturable": True, "foreach": True} if use_graph else {}
+        lr0 = torch.tensor(float(o.learning_rate), device=self.device) if use_graph else o.learning_rate
         if o.optimizer == "adamw":
-            self.model_optimizer = torch.optim.AdamW(self.parameters_to_train, lr=o.learning_rate,
-                                                     betas=(o.beta1, o.beta2), weight_decay=o.weight_decay)
+            self.model_optimizer = torch.optim.AdamW(self.parameters_to_train, lr=lr0,
+                                                     betas=(o.beta1, o.beta2), weight_decay=o.weight_decay,
+                                                     **gkw)
         elif o.optimizer == "adam":
-            self.model_optimizer = torch.optim.Adam(self.parameters_to_train, lr=o.learning_rate,
-                                                    betas=(o.beta1, o.beta2))
+            self.model_optimizer = torch.optim.Adam(self.parameters_to_train, lr=lr0,
+                                                    betas=(o.beta1, o.beta2), **gkw)
         else:
             self.model_optimizer = torch.optim.SGD(self.parameters_to_train, lr=o.learning_rate,
                                                    momentum=o.momentum)
+        # graph mode: the schedule runs on a host-side shadow optimiser (plain float arithmetic) and
+        # `_sched_step` pushes the new rate into the device-resident one -- a scheduler bound to a
+        # tensor rate would read it back (.item()) on every step
+        self._lr_shadow = torch.optim.SGD([torch.zeros(1)], lr=o.learning_rate) if use_graph else None
+        sched_opt = self._lr_shadow if use_graph else self.model_optimizer
         if o.lr_sche_type == "cos":
             self.model_lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(
-                self.model_optimizer, T_max=max(self.num_total_steps, 1), eta_min=o.eta_min)
+                sched_opt, T_max=max(self.num_total_steps, 1), eta_min=o.eta_min)
         else:
             self.model_lr_scheduler = torch.optim.lr_scheduler.MultiStepLR(
-                self.model_optimizer, o.decay_step, o.decay_rate)
+                sched_opt, o.decay_step, o.decay_rate)
         if checkpoint:
             # Model weights interchange with the reference's ckpt.pth; optimiser state does not:
             # the reference's optimiser holds the aliased encoder_mf / depth_mf parameters twice
@@ -219,6 +232,8 @@ class Trainer(HotPathLosses):
             try:
                 self.model_optimizer.load_state_dict(checkpoint["optimizer"])
                 self.model_lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
+                if self._lr_shadow is not None:
+                    self._lr_shadow.param_groups[0]["lr"] = float(self.model_lr_scheduler.get_last_lr()[0])
             except (ValueError, KeyError, RuntimeError) as e:
                 logging.warning("optimizer state of the checkpoint does not match this trainer's "
                                 "parameter list (%s): restarting the optimizer moments, keeping "
@@ -233,9 +248,11 @@ class Trainer(HotPathLosses):
                     for _ in range(last):
                         self.model_lr_scheduler.step()
             del checkpoint
+        self._push_lr()
 
         self.reducer = parallel.BucketedGradReducer(self.parameters_to_train, o.world_size,
                                                     o.bucket_mb, always_reduce=o.force_collectives)
+        self._step_graph = _StepGraph(self) if use_graph else None
 
         # ---- hot-path modules (reference: train.py:248-256)
         if not o.no_ssim:
@@ -273,14 +290,41 @@ class Trainer(HotPathLosses):
         for self.epoch in range(self.ep_start, self.opt.num_epochs):
             self.run_epoch()
             if self.opt.lr_sche_type == "step":
-                self.model_lr_scheduler.step()
+                self._sched_step()
             logging.info("per-epoch accuracy evaluation skipped: needs KITTI ground truth")
             if self.opt.global_rank == 0:
                 self.save_model(ep_end=True)
 
     def optimisation_step(self, inputs):
         """process_batch -> backward (bucketed all-reduce overlapped) -> clip -> optimiser
-        step (reference: train.py:654-669)."""
+        step (reference: train.py:654-669).  With ``--hip_graph`` the device work of the whole
+        step is captured once into a HIP graph and replayed (`_StepGraph`)."""
+        if self._step_graph is not None:
+            losses = self._step_graph(inputs)
+        else:
+            losses = self._device_step(inputs)
+        if self.opt.lr_sche_type == "cos":
+            self._sched_step()
+        return losses
+
+    def _sched_step(self):
+        if self._lr_shadow is not None:
+            self._lr_shadow.step()          # (marks the shadow as stepped: the scheduler's order check)
+        self.model_lr_scheduler.step()
+        self._push_lr()
+
+    def _push_lr(self):
+        """Graph mode: copy the shadow schedule's rate into the optimiser's device-resident one."""
+        if self._lr_shadow is None:
+            return
+        lr = float(self._lr_shadow.param_groups[0]["lr"])
+        for g in self.model_optimizer.param_groups:
+            if not torch.is_tensor(g["lr"]):     # a loaded optimiser state carries a float rate
+                g["lr"] = torch.tensor(lr, device=self.device)
+            g["lr"].fill_(lr)
+
+    def _device_step(self, inputs):
+        """Everything of a step that runs on the device (no host read-back anywhere)."""
         _, losses = self.process_batch(inputs)
         self.reducer.zero_grad()
         losses["loss"].backward()
@@ -289,8 +333,6 @@ class Trainer(HotPathLosses):
             for group in self.model_optimizer.param_groups:
                 nn.utils.clip_grad_norm_(group["params"], max_norm=self.opt.clip_grad)
         self.model_optimizer.step()
-        if self.opt.lr_sche_type == "cos":
-            self.model_lr_scheduler.step()
         return losses
 
     def run_epoch(self, max_steps=None):
@@ -520,7 +562,8 @@ class Trainer(HotPathLosses):
         # ---- affine-augmentation losses
         if o.use_affine:
             Rc = inputs["Rc"]
-            Rc_inv = torch.inverse(Rc)
+            # (the graph step inverts Rc before the replay: a solver call does not belong in a capture)
+            Rc_inv = inputs["Rc_inv"] if "Rc_inv" in inputs else torch.inverse(Rc)
             srcs_a = [inputs[("color_affine", -1, 0)], inputs[("color_affine", 1, 0)]]
             mask_rec = inputs["valid_mask_rec"]
             todo = ((pose_0_n1, pose_0_p1, depth_0, depth_0_fuse), (pose_nt_n1, pose_nt_p1, depth_nt, depth_nt_fuse),
@@ -570,7 +613,7 @@ class Trainer(HotPathLosses):
     # ------------------------------------------------------------------ logging / ckpt
     def log_time(self, batch_idx, data_time, batch_time, loss):
         left = (self.num_total_steps - self.step) * batch_time if self.step > 1 else 0
-        lr = self.model_optimizer.state_dict()["param_groups"][0]["lr"]
+        lr = float(self.model_optimizer.param_groups[0]["lr"])
         logging.info("epoch: %2d/%d | batch: %4d/%d | data time: %.4f | batch time: %.3f | loss: %.4f | "
                      "lr: %.2e | time left: %s", self.epoch, self.opt.num_epochs - 1, batch_idx,
                      self.num_steps_per_epoch, data_time, batch_time, loss, lr, sec_to_hm_str(left))
@@ -598,6 +641,8 @@ class Trainer(HotPathLosses):
         to_save["step_in_total"] = self.step
         to_save["batch_idx"] = batch_idx
         to_save["optimizer"] = self.model_optimizer.state_dict()
+        for g in to_save["optimizer"]["param_groups"]:      # graph mode keeps the rate on the device:
+            g["lr"] = float(g["lr"])                        # checkpoints always carry a float
         to_save["lr_scheduler"] = self.model_lr_scheduler.state_dict()
         torch.save(to_save, os.path.join(self.log_path, "ckpt.pth"))
 
@@ -628,6 +673,75 @@ class Trainer(HotPathLosses):
         path = os.path.abspath(self.opt.pretrained_path)
         assert os.path.exists(path), "Cannot find folder {}".format(path)
         self._load_into_models(torch.load(path, map_location="cpu", weights_only=False))
+
+
+class _StepGraph:
+    """The device work of ``Trainer._device_step`` as ONE HIP graph (``--hip_graph``).
+
+    A training step is several thousand launches (ResNet18: ~2,500, DHRNet: ~13,500 -- at
+    26 us of host time per launch the DHRNet step is bound by the enqueueing Python thread, not
+    by the GPU).  Shapes are static, nothing in the step reads a value back to the host, the
+    gradients live in the reducer's persistent flat buckets and the optimiser is capturable, so
+    the whole step -- teacher, encoders, decoders, the nine unit kernels, backward, gradient
+    clipping, AdamW -- is captured once and replayed with one launch per step.
+
+    Protocol: the batch is copied into static input tensors; the first ``WARMUP`` steps run
+    eagerly on a side stream (MIOpen solver selection, allocator and optimiser state), the next
+    call captures, every later call replays.  What stays outside the graph: the host-to-device
+    copy of the batch, the inverse of ``Rc`` (a solver call) and the learning-rate schedule
+    (updates the device-resident rate in place).  The tie-break noise is drawn with
+    ``torch.randn`` (graph-safe Philox offsets), not from the in-kernel generator whose key is a
+    launch argument and would be frozen into the capture."""
+
+    WARMUP = 3
+
+    def __init__(self, trainer):
+        self.t = trainer
+        self.calls = 0
+        self.graph = None
+        self.static = None
+        self.losses = None
+        self.stream = torch.cuda.Stream(device=trainer.device)
+        trainer.opt.inkernel_noise = False
+
+    def _load(self, inputs):
+        dev = self.t.device
+        if self.static is None:
+            self.static = {k: (v.to(dev, non_blocking=True).clone() if torch.is_tensor(v) else v)
+                           for k, v in inputs.items()}
+            if "Rc" in self.static:
+                self.static["Rc_inv"] = torch.empty_like(self.static["Rc"])
+        else:
+            for k, v in inputs.items():
+                if torch.is_tensor(v):
+                    dst = self.static[k]
+                    if dst.shape != v.shape:
+                        raise RuntimeError(f"--hip_graph needs static shapes: {k} changed from "
+                                           f"{tuple(dst.shape)} to {tuple(v.shape)} (drop_last must be on)")
+                    dst.copy_(v, non_blocking=True)
+        if "Rc" in self.static:
+            # LU-based like torch.inverse, without its host-side error check (no synchronisation)
+            self.static["Rc_inv"].copy_(torch.linalg.inv_ex(self.static["Rc"])[0])
+
+    def __call__(self, inputs):
+        t = self.t
+        self._load(inputs)
+        self.calls += 1
+        if self.graph is None:
+            cur = torch.cuda.current_stream(t.device)
+            self.stream.wait_stream(cur)
+            if self.calls <= self.WARMUP:
+                with torch.cuda.stream(self.stream):
+                    losses = t._device_step(dict(self.static))
+                cur.wait_stream(self.stream)
+                return losses
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream):
+                self.losses = t._device_step(dict(self.static))
+            self.graph = g
+            logging.info("optimisation step captured into a HIP graph")
+        self.graph.replay()
+        return self.losses
 
 
 def main(argv=None):
