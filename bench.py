@@ -86,8 +86,10 @@ def parse():
                     help="train workload: the timed steps replay the whole optimisation step as ONE "
                          "HIP graph (trainer --hip_graph); the unit kernel's events cannot be recorded "
                          "inside a graph, so `roofline` then comes from the hot-path-only leg")
-    ap.add_argument("--no-graph-leg", dest="no_graph_leg", action="store_true",
-                    help="train workload: skip the extra HIP-graph measurement of the step")
+    ap.add_argument("--graph-leg", dest="graph_leg", action="store_true",
+                    help="train workload: add a HIP-graph measurement of the step as an extra object "
+                         "(opt-in: at the full BASELINE shapes the replay of a captured step faulted on "
+                         "ROCm 7.2 -- DESIGN.md section 7 -- and a GPU memory fault cannot be caught)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -454,7 +456,7 @@ def main():
         hotpath_only = hotpath_leg(args, rank, dev, nat)
 
     graph_leg = None
-    if workload == "train" and rank == 0 and world == 1 and not args.hip_graph and not args.no_graph_leg:
+    if workload == "train" and rank == 0 and world == 1 and not args.hip_graph and args.graph_leg:
         del step.trainer        # the eager trainer's activations are not needed any more
         torch.cuda.empty_cache()
         graph_leg = graph_step_leg(args, rank, world, dev)

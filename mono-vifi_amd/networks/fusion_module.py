@@ -10,6 +10,7 @@ import torch.nn.functional as F
 
 from ..layers import ConvBlock1x1
 from .ifrnet import warp
+from ..consts import const_tensor
 
 # On a HIP device everything up to the 1x1 convolution of a level -- the two flow warps, the
 # three resizes, the 84 sin/cos embedding channels, the mask merge and the concatenations -- is
@@ -60,7 +61,7 @@ class FusionModule(nn.Module):
         for feat in features:
             _, _, H, W = feat.shape
             fl = F.interpolate(flow, size=(H, W), mode="bilinear", align_corners=False)
-            scale = torch.tensor([W / fw, H / fh], device=fl.device, dtype=fl.dtype).view(1, 2, 1, 1)
+            scale = const_tensor((W / fw, H / fh), fl.device, fl.dtype).view(1, 2, 1, 1)
             out.append(warp(feat, fl * scale))
         return out
 

@@ -24,6 +24,7 @@ import contextlib
 import torch
 import torch.distributed as dist
 import torch.nn as nn
+from ..consts import const_tensor
 
 
 def merge_groups(tensors):
@@ -208,8 +209,7 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         r_g = (1-m) r + m s_g.  The per-call form would apply the G updates in sequence:
         r <- (1-m)^G r + sum_g m (1-m)^(G-1-g) s_g."""
         m = self.momentum
-        coef = torch.tensor([(1 - m) ** (G - 1 - g) for g in range(G)], dtype=rm.dtype,
-                            device=rm.device).view(G, 1)
+        coef = const_tensor([(1 - m) ** (G - 1 - g) for g in range(G)], rm.device, rm.dtype).view(G, 1)
         for run, upd in ((self.running_mean, rm), (self.running_var, rv)):
             s_times_m = upd.view(G, C) - (1 - m) * run          # m * s_g
             run.mul_((1 - m) ** G).add_((coef * s_times_m).sum(0))

@@ -11,6 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..layers import conv_bias_act
+from ..consts import const_tensor
 
 
 def _hip_flow_warp(img, flow):
@@ -150,7 +151,7 @@ class IFRNet(nn.Module):
         mask = torch.sigmoid(out[:, 4:5])
 
         sx, sy = 1.0 / scale_factor[1], 1.0 / scale_factor[0]
-        scale = torch.tensor([sx, sy], device=up0.device, dtype=up0.dtype).view(1, 2, 1, 1)
+        scale = const_tensor((sx, sy), up0.device, up0.dtype).view(1, 2, 1, 1)
         up0 = F.interpolate(up0, size=(H, W), mode="bilinear", align_corners=False) * scale
         up1 = F.interpolate(up1, size=(H, W), mode="bilinear", align_corners=False) * scale
         mask = F.interpolate(mask, size=(H, W), mode="bilinear", align_corners=False)

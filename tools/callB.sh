@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_trainer_gpu.py -k "hip_graph or optimisation_steps or checkpoint_roundtrip" -x -q 2>&1 | tail -25
+timeout 600 python -m pytest tests/test_trainer_gpu.py -k "hip_graph or checkpoint_roundtrip or fused_units" -x -q 2>&1 | grep -v "^20[0-9][0-9]-" | tail -70
 timeout 900 python bench.py --steps 20 --warmup 5 2> gpurun_out/b_train.err | tail -1 > gpurun_out/b_train.json
 python -c "
 import json; d=json.load(open('gpurun_out/b_train.json')); print(d['value'], d['ms_per_step'], d['roofline']['avg_us'], d.get('hip_graph_step'), d['hotpath_only']['value'])"
