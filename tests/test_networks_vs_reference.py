@@ -280,3 +280,30 @@ def test_token_linear_weight_gradient_equals_stock_linear():
     (lin(x) * w).sum().backward()
     for a, b in zip(got, (x.grad, lin.weight.grad, lin.bias.grad)):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5)
+
+
+def test_litemono_nchw_mlp_equals_token_form():
+    """The CDC block's channel MLP evaluated in NCHW (batched GEMMs over the images) is the same
+    function as the reference's permute -> nn.Linear -> permute form: outputs and every gradient."""
+    import torch
+    from mono_vifi_amd.networks import litemono
+    torch.manual_seed(1)
+    blk = litemono.DilatedConv(12, 3, dilation=2, drop_path=0.0, layer_scale_init_value=0.5, expan_ratio=6)
+    blk.train()
+    x = torch.randn(3, 12, 9, 14, requires_grad=True)
+    w = torch.randn(3, 12, 9, 14)
+    res = {}
+    try:
+        for flag in (True, False):
+            litemono.NCHW_MLP = flag
+            x.grad = None
+            blk.zero_grad()
+            y = blk(x)
+            (y * w).sum().backward()
+            res[flag] = [y.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in blk.parameters()
+                                                                 if p.grad is not None]
+    finally:
+        litemono.NCHW_MLP = True
+    assert len(res[True]) == len(res[False]) >= 8
+    for a, b in zip(res[True], res[False]):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
