@@ -69,7 +69,7 @@ class DropPath(nn.Module):
             return x
         keep = 1.0 - self.p
         mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
-        return x * mask / keep
+        return x * (mask / keep)        # one pass over x (the scale is per sample)
 
 
 class PositionalEncodingFourier(nn.Module):
