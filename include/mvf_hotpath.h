@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 9
+#define MVF_ABI_VERSION 10
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -339,6 +339,15 @@ MVF_API int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, int planes, 
 MVF_API int mvf_upsample_nearest_fwd(const float *x, float *out, int planes, int ih, int iw, int factor, void *stream);
 MVF_API int mvf_upsample_nearest_bwd(const float *g_out, float *g_x, int planes, int ih, int iw, int factor,
                              void *stream);
+/* nn.MaxPool2d(kernel_size=3, stride=2, padding=1) of the ResNet trunks (networks/monodepth2.py:39
+ * `self.encoder.maxpool`, networks/posenet.py:21, 87): x [planes, H, W] -> out [planes, OH, OW],
+ * OH = (H-1)/2 + 1, OW = (W-1)/2 + 1; idx [planes, OH, OW] uint8 = window-local position (kh*3 + kw
+ * relative to (2*oy-1, 2*ox-1)) of the maximum, selected as ATen does (first maximum in kh, kw scan
+ * order; a NaN wins).  Backward: g_x [planes, H, W] fully written, deterministic gather over the
+ * <= 4 windows of an input pixel in ATen's accumulation order.  planes <= 262,140. */
+MVF_API int mvf_maxpool3s2_fwd(const float *x, float *out, uint8_t *idx, int planes, int H, int W, void *stream);
+MVF_API int mvf_maxpool3s2_bwd(const float *g_out, const uint8_t *idx, float *g_x, int planes, int H, int W,
+                       void *stream);
 /* On-device colour augmentation of the data pipeline (datasets/mono_dataset.py:102-184, 214-256:
  * do_flip, do_color_aug with one torchvision ColorJitter draw per sample applied to all of its
  * frames).  img [samples*frames,3,H,W] (frame-minor), factors [samples,4] = {brightness, contrast,

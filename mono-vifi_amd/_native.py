@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -61,6 +61,8 @@ _SIGNATURES = {
     "mvf_resize_bilinear_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp],
     "mvf_upsample_nearest_fwd": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_upsample_nearest_bwd": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_maxpool3s2_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvf_maxpool3s2_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mvf_color_jitter_workspace_floats": [_i],
     "mvf_color_jitter": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_unit_fwdbwd_scale": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -487,6 +487,83 @@ __global__ void __launch_bounds__(NT) k_upsample_nearest_bwd(const float *__rest
         if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
 }
 
+// ---- 3x3 / stride 2 / pad 1 max pooling of the ResNet stems ------------------------------------
+// nn.MaxPool2d(3, 2, 1) between conv1 and layer1 of every ResNet trunk (networks/monodepth2.py:39,
+// networks/posenet.py:21, 87) on the largest activation of the step ([96, 64, 96, 320] for the depth
+// encoder's grouped call: 755 MB).  ATen's pair keeps an int64 index per output and its backward ran
+// at 1.2 ms per launch (max_pool_backward_nchw: 2.4 ms per step, forward 1.0 ms).  Here the forward
+// stores the window-local position of the maximum as ONE byte (0..8 = kh*3 + kw, relative to the
+// window's unclamped origin (2*oy-1, 2*ox-1)) and the backward is a gather: an input pixel lies
+// in at most 2 x 2 windows.  Selection rule as ATen writes it (MaxPoolForward: scan kh then kw,
+// `val > max || isnan(val)`, start = first in-bounds element); the backward adds the (<= 4)
+// matching windows in ATen's order (oy, then ox ascending), so sums are bit-identical.
+__global__ void __launch_bounds__(NT) k_maxpool3s2_fwd(const float *__restrict__ x, float *__restrict__ out,
+                                                       uint8_t *__restrict__ idx, int planes, int H, int W, int OH,
+                                                       int OW)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= OH * OW) return;
+    const int oy = i / OW, ox = i - oy * OW;
+    const int y0 = 2 * oy - 1, x0 = 2 * ox - 1;
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)H * W, no = (size_t)OH * OW;
+    float best[PLR];
+    int bi[PLR];
+    const int first = (y0 < 0 ? 3 : 0) + (x0 < 0 ? 1 : 0);
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) { best[k] = -INFINITY; bi[k] = first; }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int yy = y0 + kh;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int xx = x0 + kw;
+            if (xx < 0 || xx >= W) continue;
+            const float *xp = x + (size_t)p0 * ni + (size_t)yy * W + xx;
+#pragma unroll
+            for (int k = 0; k < PLR; ++k) {
+                if (p0 + k >= planes) continue;
+                const float v = xp[(size_t)k * ni];
+                if ((v > best[k]) || (v != v)) { best[k] = v; bi[k] = kh * 3 + kw; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes) {
+            out[(size_t)(p0 + k) * no + i] = best[k];
+            idx[(size_t)(p0 + k) * no + i] = (uint8_t)bi[k];
+        }
+}
+
+__global__ void __launch_bounds__(NT) k_maxpool3s2_bwd(const float *__restrict__ g, const uint8_t *__restrict__ idx,
+                                                       float *__restrict__ gx, int planes, int H, int W, int OH,
+                                                       int OW)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W) return;
+    const int y = i / W, xq = i - y * W;
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)H * W, no = (size_t)OH * OW;
+    float acc[PLR];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) acc[k] = 0.0f;
+    // windows covering row y: 2*oy-1 <= y <= 2*oy+1  <=>  oy in {y>>1, (y+1)>>1}
+    const int oy_hi = min((y + 1) >> 1, OH - 1), ox_hi = min((xq + 1) >> 1, OW - 1);
+    for (int oy = y >> 1; oy <= oy_hi; ++oy)
+        for (int ox = xq >> 1; ox <= ox_hi; ++ox) {
+            const int code = (y - 2 * oy + 1) * 3 + (xq - 2 * ox + 1);
+            const size_t o = (size_t)p0 * no + (size_t)oy * OW + ox;
+#pragma unroll
+            for (int k = 0; k < PLR; ++k)
+                if (p0 + k < planes && idx[o + (size_t)k * no] == (uint8_t)code) acc[k] += g[o + (size_t)k * no];
+        }
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
+}
+
 // ---- on-device colour augmentation -------------------------------------------------------------
 // MonoDataset.__getitem__ / preprocess (datasets/mono_dataset.py:102-184, 214-256): with
 // probability 1/2 a sample's frames are flipped horizontally, and with probability 1/2 all of its
@@ -752,6 +829,26 @@ int mvf_upsample_nearest_bwd(const float *g_out, float *g_x, int planes, int ih,
     if (!g_out || !g_x || factor < 1 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_upsample_nearest_bwd, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw, factor);
+    return hip_check_launch();
+}
+
+int mvf_maxpool3s2_fwd(const float *x, float *out, uint8_t *idx, int planes, int H, int W, void *stream)
+{
+    if (planes <= 0 || H <= 0 || W <= 0) return 0;
+    if (!x || !out || !idx || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool3s2_fwd, dim3((unsigned)((OH * OW + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                       dim3(NT), 0, (hipStream_t)stream, x, out, idx, planes, H, W, OH, OW);
+    return hip_check_launch();
+}
+
+int mvf_maxpool3s2_bwd(const float *g_out, const uint8_t *idx, float *g_x, int planes, int H, int W, void *stream)
+{
+    if (planes <= 0 || H <= 0 || W <= 0) return 0;
+    if (!g_out || !idx || !g_x || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    hipLaunchKernelGGL(k_maxpool3s2_bwd, dim3((unsigned)((H * W + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                       dim3(NT), 0, (hipStream_t)stream, g_out, idx, g_x, planes, H, W, OH, OW);
     return hip_check_launch();
 }
 

@@ -112,12 +112,27 @@ class ResNetTrunk(nn.Module):
         return nn.Sequential(*blocks)
 
 
+STEM_POOL_KERNEL = os.environ.get("MVF_STEM_POOL", "1") != "0"      # developer knob for A/B timing
+
+
+def _stem_pool(trunk, f0):
+    """The trunk's 3x3 / stride-2 max pool; on the HIP device (fp32) the byte-index gather pair
+    (ops.maxpool3s2) instead of ATen's int64-index kernels."""
+    mp = trunk.maxpool
+    if (STEM_POOL_KERNEL and f0.is_cuda and f0.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode)
+            == (3, 2, 1, 1, False)):
+        from .. import ops
+        return ops.maxpool3s2(f0)
+    return mp(f0)
+
+
 def pyramid_features(trunk, image):
     """The 5-level feature list both encoders return (reference: monodepth2.py:33-45,
     posenet.py:80-93): colour normalisation (x-0.45)/0.225, then stem and 4 stages."""
     x = (image - 0.45) / 0.225
     f0 = trunk.relu(trunk.bn1(trunk.conv1(x)))
-    f1 = trunk.layer1(trunk.maxpool(f0))
+    f1 = trunk.layer1(_stem_pool(trunk, f0))
     f2 = trunk.layer2(f1)
     f3 = trunk.layer3(f2)
     f4 = trunk.layer4(f3)

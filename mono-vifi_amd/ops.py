@@ -960,6 +960,42 @@ def upsample_nearest(x, factor):
     return UpsampleNearest.apply(x, int(factor))
 
 
+class MaxPool3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) of the ResNet trunks (reference networks/monodepth2.py:39,
+    networks/posenet.py:87): one byte of window-local argmax per output instead of ATen's int64
+    index, backward as a deterministic gather (`mvf_maxpool3s2_fwd/bwd`)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        nat.require_device(x)
+        x = _c(x)
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, C, OH, OW), dtype=torch.uint8, device=x.device)
+        nat.check(nat.lib().mvf_maxpool3s2_fwd(nat.ptr(x), nat.ptr(out), nat.ptr(idx), N * C, H, W, _stream()),
+                  "maxpool3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, C, H, W)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, = ctx.saved_tensors
+        N, C, H, W = ctx.geom
+        g = _c(g)
+        gx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        nat.check(nat.lib().mvf_maxpool3s2_bwd(nat.ptr(g), nat.ptr(idx), nat.ptr(gx), N * C, H, W, _stream()),
+                  "maxpool3s2_bwd")
+        return gx
+
+
+def maxpool3s2(x):
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise RuntimeError("maxpool3s2 expects a float32 [N,C,H,W] tensor")
+    return MaxPool3s2.apply(x)
+
+
 _ACT_CODES = {"none": 0, "elu": 1, "relu": 2, "prelu": 3}
 
 

@@ -469,6 +469,51 @@ def fusion_backward(feats, flows, mask, gouts):
     return g_n1, g_0, g_p1
 
 
+# --------------------------------------------------------------------------- f4: stem max pooling
+def maxpool3s2(x):
+    """nn.MaxPool2d(3, 2, 1) of the ResNet trunks (reference networks/monodepth2.py:39,
+    networks/posenet.py:21, 87) restated as ATen evaluates it (MaxPoolKernel: scan kh then kw over the
+    in-bounds part of the window, `val > max || isnan(val)`, start at the first in-bounds element).
+    x [P,H,W] -> (out [P,OH,OW], code [P,OH,OW] uint8 = kh*3+kw relative to (2*oy-1, 2*ox-1)).
+    Pinned to ATen's CPU kernel in tests/test_oracle_golden.py."""
+    x = np.asarray(x, np.float32)
+    P, H, W = x.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    oy, ox = np.arange(OH)[:, None], np.arange(OW)[None, :]
+    best = np.full((P, OH, OW), -np.inf, np.float32)
+    code = np.broadcast_to(np.where(2 * oy - 1 < 0, 3, 0) + np.where(2 * ox - 1 < 0, 1, 0), (P, OH, OW)).copy()
+    for kh in range(3):
+        for kw in range(3):
+            yy, xx = 2 * oy - 1 + kh, 2 * ox - 1 + kw
+            ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+            v = x[:, np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]
+            with np.errstate(invalid="ignore"):
+                take = ok[None] & ((v > best) | np.isnan(v))
+            best = np.where(take, v, best)
+            code = np.where(take, kh * 3 + kw, code)
+    return best, code.astype(np.uint8)
+
+
+def maxpool3s2_bwd(g, code, H, W):
+    """Adjoint of maxpool3s2: an input pixel collects the (<= 2 x 2) windows whose maximum it is, in
+    ATen's accumulation order (oy, then ox ascending; fp32 adds)."""
+    g = np.asarray(g, np.float32)
+    P, OH, OW = g.shape
+    y, xq = np.arange(H)[:, None], np.arange(W)[None, :]
+    gx = np.zeros((P, H, W), np.float32)
+    for a in (0, 1):
+        oy = (y >> 1) + a
+        vy = (oy <= ((y + 1) >> 1)) & (oy < OH)
+        for b in (0, 1):
+            ox = (xq >> 1) + b
+            vx = (ox <= ((xq + 1) >> 1)) & (ox < OW)
+            want = (y - 2 * oy + 1) * 3 + (xq - 2 * ox + 1)
+            oyc, oxc = np.clip(oy, 0, OH - 1), np.clip(ox, 0, OW - 1)
+            hit = (vy & vx)[None] & (code[:, oyc, oxc] == want[None])
+            gx = (gx + np.where(hit, g[:, oyc, oxc], np.float32(0))).astype(np.float32)
+    return gx
+
+
 # --------------------------------------------------------------------------- f4: colour augmentation
 def color_jitter(img, factors, order, apply, flip, frames=1):
     """Flip + ColorJitter of datasets/mono_dataset.py:214-256 on float images, restating

@@ -1063,6 +1063,37 @@ def test_resize_bilinear_vs_oracle(dev):
         assert float((y3 - out).abs().max()) <= 2e-6
 
 
+def test_maxpool3s2_vs_oracle(dev):
+    """mvf_maxpool3s2_fwd/bwd (the ResNet trunks' nn.MaxPool2d(3, 2, 1)) against the oracle (pinned
+    bit for bit to ATen's CPU kernels): values, the selected window element (ties, NaN, -inf
+    windows, odd sizes, 1x1) and the gather adjoint are bit-identical; at the stem's full shape
+    against ATen's device kernels."""
+    import torch.nn.functional as F
+    from mono_vifi_amd import ops
+    from test_oracle_golden import _pool_cases
+    rng = np.random.default_rng(22)
+    for x in _pool_cases(rng):
+        P, H, W = x.shape
+        xt = T(x[None], dev, True)
+        out = ops.maxpool3s2(xt)
+        ref, code = O.maxpool3s2(x)
+        assert np.array_equal(N(out)[0], ref, equal_nan=True), (P, H, W)
+        w = rng.standard_normal(ref.shape).astype(np.float32)
+        (out * T(w[None], dev)).sum().backward()
+        assert np.array_equal(N(xt.grad)[0], O.maxpool3s2_bwd(w, code, H, W)), (P, H, W)
+    # the depth encoder's grouped stem at the BASELINE shape: [96, 64, 96, 320] (post-ReLU values)
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.randn((24, 64, 96, 320), device=dev, generator=g).clamp_min_(0).requires_grad_(True)
+    w = torch.randn((24, 64, 48, 160), device=dev, generator=g)
+    out = ops.maxpool3s2(x)
+    (out * w).sum().backward()
+    x2 = x.detach().clone().requires_grad_(True)
+    ref = F.max_pool2d(x2, 3, 2, 1)
+    (ref * w).sum().backward()
+    assert torch.equal(out, ref)
+    assert float((x.grad - x2.grad).abs().max()) <= 1e-6      # same elements selected; sums of <= 4 terms
+
+
 def test_dhrnet_device_glue_equals_stock_ops(dev):
     """HRNet18 encoder + DHRNet decoder with the device glue (bilinear resize kernel, convolution
     epilogues) against the stock op-by-op form: disparities and parameter gradients."""

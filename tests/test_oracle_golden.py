@@ -240,3 +240,44 @@ def test_resize_bilinear_oracle_vs_aten():
         (y * torch.tensor(w)).sum().backward()
         assert np.abs(O.resize_bilinear(x, oh, ow, sf, ac) - y.detach().numpy()).max() <= 2e-6
         assert np.abs(O.resize_bilinear_bwd(w, ih, iw, sf, ac) - xt.grad.numpy()).max() <= 2e-5
+
+
+def _pool_cases(rng):
+    cases = []
+    for (P, H, W) in [(3, 8, 10), (2, 7, 9), (2, 1, 1), (1, 2, 5), (4, 96, 320 // 4), (1, 5, 2)]:
+        x = rng.standard_normal((P, H, W)).astype(np.float32)
+        cases.append(x)
+        cases.append(np.maximum(x, 0))                        # post-ReLU input: ties at 0 everywhere
+        q = np.round(x * 2) / 2                               # coarse values: many exact ties
+        cases.append(q.astype(np.float32))
+    s = rng.standard_normal((2, 6, 7)).astype(np.float32)
+    s[0, 2, 3] = np.nan
+    s[1, 0, 0] = np.nan
+    s[1, 1, 1] = np.nan
+    s[0, 4:, :] = -np.inf
+    cases.append(s)
+    return cases
+
+
+def test_maxpool3s2_oracle_vs_aten():
+    """nn.MaxPool2d(3, 2, 1) IS the reference's function between conv1 and layer1 of the ResNet
+    trunks (networks/monodepth2.py:39, networks/posenet.py:87): the oracle's restatement (values,
+    the selected element incl. ties / NaN / -inf windows) and its adjoint against ATen's CPU kernels,
+    bit for bit."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(21)
+    for x in _pool_cases(rng):
+        P, H, W = x.shape
+        xt = torch.tensor(x[None], requires_grad=True)
+        y, ind = F.max_pool2d(xt, 3, 2, 1, return_indices=True)
+        out, code = O.maxpool3s2(x)
+        assert out.shape == tuple(y.shape[1:])
+        assert np.array_equal(out, y[0].detach().numpy(), equal_nan=True)
+        OH, OW = out.shape[1:]
+        iy, ix = ind[0].numpy() // W, ind[0].numpy() % W
+        want = (iy - (2 * np.arange(OH)[:, None] - 1)) * 3 + (ix - (2 * np.arange(OW)[None, :] - 1))
+        assert np.array_equal(code.astype(np.int64), want)
+        w = rng.standard_normal(out.shape).astype(np.float32)
+        (y * torch.tensor(w[None])).sum().backward()
+        assert np.array_equal(O.maxpool3s2_bwd(w, code, H, W), xt.grad[0].numpy())
