@@ -546,22 +546,38 @@ __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd(const float *__restrict__
     const int y = i / W, xq = i - y * W;
     const int p0 = blockIdx.y * PLR;
     const size_t ni = (size_t)H * W, no = (size_t)OH * OW;
-    float acc[PLR];
+    // windows covering row y: 2*oy-1 <= y <= 2*oy+1  <=>  oy in {y>>1, (y+1)>>1}: the second one
+    // exists for odd y (and oy < OH).  All (<= 4) index bytes and gradients of a plane are loaded
+    // unconditionally from clamped addresses, so the 8 loads x PLR planes of a lane are in flight
+    // together (a loop with data-dependent bounds and a load behind each compare ran
+    // latency-bound at 1 TB/s); invalid windows are masked in the select.
+    const int oy0 = y >> 1, ox0 = xq >> 1;
+    const bool vy = (y & 1) && (oy0 + 1 < OH), vx = (xq & 1) && (ox0 + 1 < OW);
+    const int oy1 = vy ? oy0 + 1 : oy0, ox1 = vx ? ox0 + 1 : ox0;
+    const int cy0 = (y - 2 * oy0 + 1) * 3, cy1 = (y - 2 * oy1 + 1) * 3;
+    const int cx0 = xq - 2 * ox0 + 1, cx1 = xq - 2 * ox1 + 1;
+    const size_t o00 = (size_t)oy0 * OW + ox0, o01 = (size_t)oy0 * OW + ox1, o10 = (size_t)oy1 * OW + ox0,
+                 o11 = (size_t)oy1 * OW + ox1;
+    uint8_t c[PLR][4];
+    float v[PLR][4];
 #pragma unroll
-    for (int k = 0; k < PLR; ++k) acc[k] = 0.0f;
-    // windows covering row y: 2*oy-1 <= y <= 2*oy+1  <=>  oy in {y>>1, (y+1)>>1}
-    const int oy_hi = min((y + 1) >> 1, OH - 1), ox_hi = min((xq + 1) >> 1, OW - 1);
-    for (int oy = y >> 1; oy <= oy_hi; ++oy)
-        for (int ox = xq >> 1; ox <= ox_hi; ++ox) {
-            const int code = (y - 2 * oy + 1) * 3 + (xq - 2 * ox + 1);
-            const size_t o = (size_t)p0 * no + (size_t)oy * OW + ox;
+    for (int k = 0; k < PLR; ++k) {
+        if (p0 + k >= planes) continue;
+        const uint8_t *ip = idx + (size_t)(p0 + k) * no;
+        const float *gp = g + (size_t)(p0 + k) * no;
+        c[k][0] = ip[o00]; c[k][1] = ip[o01]; c[k][2] = ip[o10]; c[k][3] = ip[o11];
+        v[k][0] = gp[o00]; v[k][1] = gp[o01]; v[k][2] = gp[o10]; v[k][3] = gp[o11];
+    }
 #pragma unroll
-            for (int k = 0; k < PLR; ++k)
-                if (p0 + k < planes && idx[o + (size_t)k * no] == (uint8_t)code) acc[k] += g[o + (size_t)k * no];
-        }
-#pragma unroll
-    for (int k = 0; k < PLR; ++k)
-        if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
+    for (int k = 0; k < PLR; ++k) {
+        if (p0 + k >= planes) continue;
+        float acc = 0.0f;          // ATen's order: (oy0,ox0), (oy0,ox1), (oy1,ox0), (oy1,ox1)
+        if (c[k][0] == (uint8_t)(cy0 + cx0)) acc += v[k][0];
+        if (vx && c[k][1] == (uint8_t)(cy0 + cx1)) acc += v[k][1];
+        if (vy && c[k][2] == (uint8_t)(cy1 + cx0)) acc += v[k][2];
+        if (vy && vx && c[k][3] == (uint8_t)(cy1 + cx1)) acc += v[k][3];
+        gx[(size_t)(p0 + k) * ni + i] = acc;
+    }
 }
 
 // ---- on-device colour augmentation -------------------------------------------------------------
