@@ -1,4 +1,5 @@
-# round-2 final measurements (GPU box): full GPU suite, bench lines, rocprofv3 summaries -> gpurun_out/r02f/
+# Round-end measurement suite (GPU box): full GPU test suite, bench lines of the four training configurations,
+# rocprofv3 kernel stats of the hot path and of the ResNet18 / DHRNet steps -> gpurun_out/r02f/ (copy into profiles/).
 R=${GRAFT_REPO_ROOT:-$PWD}; cd $R
 O=gpurun_out/r02f; mkdir -p $O
 ulimit -c 0
