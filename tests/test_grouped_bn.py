@@ -147,3 +147,40 @@ def test_grouped_sync_two_ranks_gloo():
         p.join(300)
         assert p.exitcode == 0
     assert q.get(timeout=10) is True
+
+
+def test_grouped_bn_layer_issues_few_ops():
+    """An HRNet18 step runs 325 grouped batch-norm layers: the per-layer bookkeeping (tiling the
+    per-channel vectors over the calls, folding the running statistics back) is a launch budget,
+    pinned here by counting the ATen ops one layer dispatches in forward + backward."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from mono_vifi_amd.networks import grouped
+
+    class Count(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.ops = []
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = func.overloadpacket.__name__
+            # views / metadata do not launch anything
+            if name not in ("view", "_unsafe_view", "unbind", "t", "detach", "alias", "set_", "empty",
+                            "as_strided", "expand", "select", "reshape", "unsqueeze", "squeeze", "transpose",
+                            "new_empty", "lift_fresh", "_to_copy", "empty_like"):
+                self.ops.append(name)
+            return func(*args, **(kwargs or {}))
+
+    torch.manual_seed(0)
+    bn = grouped.GroupedBatchNorm2d(6)
+    bn.train()
+    bn.groups = 4
+    x = torch.randn(8, 6, 5, 7, requires_grad=True)
+    w = torch.randn(8, 6, 5, 7)
+    with Count() as c:
+        y = bn(x)
+        fwd = len(c.ops)
+        (y * w).sum().backward()
+    # forward: stack, repeat, batch norm, 2 x addmv_, num_batches_tracked add  (was ~19)
+    assert fwd <= 7, c.ops[:fwd]
+    # backward on top of the loss's own mul / sum / expand: batch-norm backward, stack, sum  (+ contiguous)
+    assert len(c.ops) - fwd <= 10, c.ops[fwd:]
