@@ -45,6 +45,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0    # same guide: measured-achievable copy bandwidth (SURVEY.md section 8d quotes both)
 FWD_BYTES_PER_PX = 44          # disp 4 + tgt 12 + 2 src 24 read, 4 written
 BWD_BYTES_PER_PX = 45          # same reads + argmin 1, grad_disp 4 written
 # the forward+backward tile kernel reads its inputs ONCE: disp 4 + tgt 12 + 2 src 24 read,
@@ -296,6 +297,7 @@ def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n):
         ach = bytes_px * px / avg_s / 1e9
         return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                "frac_of_measured_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
                 "traffic": traffic_from_profiles(name), "valu": valu_from_profiles(name),
                 "static_source": profiles_source(),
                 "avg_us": round(avg_s * 1e6, 2),
