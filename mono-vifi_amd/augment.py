@@ -10,7 +10,9 @@ the rotated / cropped / resized views.  Here the host only draws those few numbe
 views are produced by ``mvf_affine_transform_fwd`` (the same op ``Trainer.affine_transform``
 applies to the teacher frames, train.py:888-902) -- all on the device, for the whole batch.
 torchvision is on neither box: the jitter restates its published float-tensor algorithm
-(parity unpinned; checked against the oracle's restatement).
+(the kernel is checked against the oracle's restatement; the oracle against PIL's ImageEnhance / HSV
+implementation -- torchvision's PIL backend, which the reference's loader runs -- to within uint8
+quantisation: tests/test_pil_pins.py).
 """
 from __future__ import annotations
 

@@ -518,7 +518,8 @@ def maxpool3s2_bwd(g, code, H, W):
 def color_jitter(img, factors, order, apply, flip, frames=1):
     """Flip + ColorJitter of datasets/mono_dataset.py:214-256 on float images, restating
     torchvision's published float-tensor algorithms (_blend, rgb_to_grayscale, _rgb2hsv, _hsv2rgb;
-    parity unpinned: torchvision is absent).  img [samples*frames,3,H,W] -> (raw flipped, augmented)."""
+    torchvision is absent; pinned to PIL's ImageEnhance / 8-bit HSV implementation -- its PIL backend,
+    what the reference's loader runs -- within uint8 quantisation: tests/test_pil_pins.py).  img [samples*frames,3,H,W] -> (raw flipped, augmented)."""
     f32 = np.float32
     img = _f(img)
     raw = img.copy()

@@ -13,7 +13,8 @@ def rotate_bilinear(img, angle_deg):
     bilinear, zero fill -- torchvision ``functional.rotate(img, angle, interpolation=2)``
     semantics (inverse-mapped pixel-centre grid, ``align_corners=False``), which the
     reference calls once per sample (train.py:898, 915).  torchvision is absent on both
-    boxes, so this restatement is parity-unpinned."""
+    boxes; the oracle's rotate, which this formulation is compared with, is pinned to PIL's
+    ``Image.rotate(angle, BILINEAR)`` -- the reference's own loader op -- in tests/test_pil_pins.py."""
     B, _, H, W = img.shape
     a = angle_deg.reshape(B).to(img.dtype) * (math.pi / 180.0)
     cos, sin = torch.cos(a).view(B, 1, 1), torch.sin(a).view(B, 1, 1)
