@@ -3,7 +3,8 @@
 Runs only where /root/reference exists (the build container); the reference never travels
 to the GPU box, so there these tests skip.  The ResNet trunks cannot be compared: the
 reference builds them from torchvision, which is absent ("parity
-unpinned"); everything importable is compared: DepthDecoder, PoseDecoder, FusionModule,
+unpinned" -- tests/test_resnet_vs_hf.py holds them to an independent implementation, transformers'
+ResNetModel, instead); everything importable is compared: DepthDecoder, PoseDecoder, FusionModule,
 IFRNet (large and small)."""
 import importlib
 import os
