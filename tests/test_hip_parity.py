@@ -516,10 +516,14 @@ def test_flow_warp(dev, case, flow_bwd):
 
 @BOTH_FLOW_BWD
 def test_flow_warp_feature_pyramid_vs_oracle(dev, flow_bwd):
-    """Feature-pyramid shapes of the fusion module (64..512 channels, 96x320 .. 6x20)."""
+    """Feature-pyramid shapes of the fusion module: ResNet18 at 640x192 (64..512 channels, 96x320 ..
+    6x20), the 512x192 Cityscapes pyramid of the HRNet18 encoder (C5) and Lite-Mono's 3-scale
+    pyramid at 1024x320 (C4)."""
     from mono_vifi_amd import ops
     rng = np.random.default_rng(71)
-    for (C, H, W) in ((64, 96, 320), (128, 24, 80), (512, 6, 20), (3, 192, 640)):
+    for (C, H, W) in ((64, 96, 320), (128, 24, 80), (512, 6, 20), (3, 192, 640),
+                      (64, 96, 256), (18, 48, 128), (144, 6, 16),        # C5: 512x192
+                      (48, 80, 256), (80, 40, 128), (128, 20, 64)):      # C4: Lite-Mono 1024x320
         img = rng.random((2, C, H, W)).astype(np.float32)
         flow = (4 * rng.standard_normal((2, 2, H, W))).astype(np.float32)
         wgt = rng.standard_normal((2, C, H, W)).astype(np.float32)
