@@ -39,8 +39,15 @@ def ref():
             for n in ("IFRNet", "fusion_module", "monodepth2", "posenet")}
     yield mods
     sys.path[:] = saved_path
-    for k in list(sys.modules):
-        if k not in saved_mods:
+    # remove what this module injected -- the stubs (no __file__) and the reference's own modules --
+    # and nothing else: torch sub-modules imported lazily in the meantime must stay (deleting them
+    # makes a later re-import register their dispatcher kernels twice)
+    for k, m in list(sys.modules.items()):
+        if k in saved_mods or k.split(".")[0] in ("torch", "numpy", "transformers"):
+            continue
+        f = getattr(m, "__file__", None)
+        if k.split(".")[0] in ("torchvision", "networks", "layers", "timm", "yacs", "matplotlib", "hrnet_config") \
+                or (f and os.path.abspath(f).startswith(REF)):
             del sys.modules[k]
 
 
