@@ -198,10 +198,10 @@ class _InvertedBottleneck(nn.Module):
         l1, l2 = self.pwconv1, self.pwconv2
         h = torch.bmm(l1.weight.unsqueeze(0).expand(B, -1, -1), y.view(B, C, H * W))
         if l1.bias is not None:
-            h += l1.bias.view(1, -1, 1)
+            h += l1.bias.view(1, -1, 1).to(h.dtype)          # (bf16 autocast: the GEMM output is bf16)
         o = torch.bmm(l2.weight.unsqueeze(0).expand(B, -1, -1), self.act(h))
         if l2.bias is not None:
-            o += l2.bias.view(1, -1, 1)
+            o += l2.bias.view(1, -1, 1).to(o.dtype)
         if self.gamma is not None:
             o = self.gamma.view(1, -1, 1) * o
         return o.view(B, -1, H, W)
