@@ -315,3 +315,66 @@ def test_litemono_nchw_mlp_equals_token_form():
     assert len(res[True]) == len(res[False]) >= 8
     for a, b in zip(res[True], res[False]):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), float((a - b).abs().max())
+
+
+def test_samplers_equal_the_reference_classes(monkeypatch):
+    """CustomSampler / CustomDistributedSampler (reference datasets/__init__.py:10-88) drive the data
+    order and the mid-epoch resume: this build's classes against the reference's own, imported under
+    another package name with its dataset sub-modules (cv2 / skimage users) stubbed."""
+    import importlib.util
+    from mono_vifi_amd import datasets as ours
+    subs = {"kitti_dataset": ["KITTIRAWDataset", "KITTIOdomDataset", "KITTIDepthDataset"],
+            "make3d_dataset": ["Make3DDataset"], "nyuv2_dataset": ["NYUDataset"],
+            "cityscapes_dataset": ["CityscapesDataset"],
+            "VFI_dataset": ["KITTI_VFI_Dataset", "Cityscapes_VFI_Dataset"]}
+    injected = []
+    try:
+        for sub, names in subs.items():
+            m = types.ModuleType("mvf_refdatasets." + sub)
+            for n in names:
+                setattr(m, n, object)
+            sys.modules[m.__name__] = m
+            injected.append(m.__name__)
+        spec = importlib.util.spec_from_file_location(
+            "mvf_refdatasets", os.path.join(REF, "datasets", "__init__.py"),
+            submodule_search_locations=[os.path.join(REF, "datasets")])
+        ref = importlib.util.module_from_spec(spec)
+        sys.modules["mvf_refdatasets"] = ref
+        injected.append("mvf_refdatasets")
+        old = sys.dont_write_bytecode
+        sys.dont_write_bytecode = True
+        try:
+            spec.loader.exec_module(ref)
+        finally:
+            sys.dont_write_bytecode = old
+    finally:
+        pass
+
+    class D:
+        def __len__(self):
+            return 103
+
+    try:
+        a, b = ref.CustomSampler(D(), seed=7), ours.CustomSampler(D(), seed=7)
+        for epoch, start in ((0, 0), (3, 0), (3, 17)):
+            for s in (a, b):
+                s.set_epoch(epoch)
+                s.set_start_iter(start)
+            assert list(a) == list(b) and len(a) == len(b)
+        import torch.utils.data.distributed as tud
+        world = 4
+        for rank in range(world):
+            monkeypatch.setattr(tud.dist, "is_available", lambda: True)
+            monkeypatch.setattr(tud.dist, "get_world_size", lambda *a_, **k_: world)
+            monkeypatch.setattr(tud.dist, "get_rank", lambda *a_, **k_: rank)
+            theirs = ref.CustomDistributedSampler(D(), seed=7)
+            mine = ours.CustomDistributedSampler(D(), seed=7, num_replicas=world, rank=rank)
+            for epoch, start in ((0, 0), (2, 0), (2, 9)):
+                for s in (theirs, mine):
+                    s.set_epoch(epoch)
+                    s.set_start_iter(start)
+                assert list(theirs) == list(mine), (rank, epoch, start)
+            assert len(theirs) == len(mine) == 103 // world
+    finally:
+        for n in injected:
+            sys.modules.pop(n, None)
