@@ -168,10 +168,12 @@ class HotPathStep:
 
 def cpu_baseline(args):
     """The oracle (CPU port of the reference's algorithm) on a bounded sample: one unit,
-    forward + backward, batch 2 at the benchmark resolution, all host cores (OpenMP)."""
+    forward + backward, at the benchmark's batch and resolution (the same per-call work as the GPU's:
+    a smaller batch leaves the port's row-parallel regions too little work for a 256-core host),
+    thread count from a sweep (OpenMP)."""
     from mono_vifi_amd import synthetic
     from oracle import oracle as O
-    Bs = 2
+    Bs = args.batch
     inp = synthetic.unit_inputs(4321, Bs, args.height, args.width, with_mask=True)
     T = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
                   for k in range(2)], 0)
@@ -217,7 +219,7 @@ def cpu_baseline_unfused(args):
     from mono_vifi_amd import synthetic
     from oracle import oracle as O
     from oracle import torch_unfused as U
-    Bs = 2
+    Bs = args.batch
     inp = synthetic.unit_inputs(4321, Bs, args.height, args.width, with_mask=True)
     T = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
                   for k in range(2)], 0)
