@@ -3,10 +3,17 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload hotpath|train]
 
-One process per GPU (the driver launches ``python -m torch.distributed.run`` for N > 1; RANK /
-LOCAL_RANK / WORLD_SIZE / MASTER_* come from the environment).  W untimed warm-up steps,
-then exactly K timed steps bracketed by barrier + synchronize on both sides; the maximum
-over ranks is used and rank 0 prints ONE JSON line.
+One process per GPU.  Under ``python -m torch.distributed.run`` (RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* in the environment) each process is one rank; started plainly with ``--gpus N > 1``
+the script launches the N ranks ITSELF (re-executes under ``torch.distributed.run`` on
+127.0.0.1) and fails loudly when the box has fewer than N GPUs -- it never prints a line whose
+``n_gpus`` differs from the world size the process group reports (reference: train.py:1178-1185,
+README.md:130-133: world = visible GPUs, one process each, ``init_process_group('nccl')``).
+W untimed warm-up steps, then exactly K timed steps bracketed by barrier + synchronize on both
+sides; the maximum over ranks is used and rank 0 prints ONE JSON line.  For N > 1 (or
+``--force-collectives`` on one GPU) the line carries a ``comm`` object: backend, world size and
+devices as the process group reports them, gradient buckets, collectives per step by kind, and
+the step time with the exchange issued after backward (``no_overlap``) beside the overlapped one.
 
 Workloads (config.workload in the JSON names the one that ran):
 
@@ -64,7 +71,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default=os.environ.get("MVF_BENCH_WORKLOAD", "auto"),
-                    choices=["auto", "hotpath", "train"])
+                    choices=["auto", "hotpath", "train", "mock"],
+                    help="mock: a toy CPU step over gloo -- plumbing test of the launcher / comm report "
+                         "(tests/test_bench_launch.py), never a benchmark")
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
@@ -92,38 +101,174 @@ def parse():
                          "(opt-in: at the full BASELINE shapes the replay of a captured step faulted on "
                          "ROCm 7.2 -- DESIGN.md section 7 -- and a GPU memory fault cannot be caught)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-batch-units", dest="no_batch_units", action="store_true",
+                    help="one launch per unit (round-2 launch structure) instead of one per group of three")
+    ap.add_argument("--no-share-identity", dest="no_share_identity", action="store_true",
+                    help="multi-frame units re-evaluate the identity candidates instead of taking the maps "
+                         "of the single-frame unit of the same target")
+    ap.add_argument("--grad-exchange", dest="grad_exchange", default="all_reduce",
+                    choices=["all_reduce", "reduce_scatter"],
+                    help="per gradient bucket: one RCCL all-reduce, or reduce-scatter + all-gather on the "
+                         "flat buffer (SURVEY.md 8f-3)")
+    ap.add_argument("--no-overlap", dest="no_overlap", action="store_true",
+                    help="timed region with the gradient exchange issued AFTER backward (the default "
+                         "issues each bucket from a hook during backward)")
+    ap.add_argument("--force-collectives", dest="force_collectives", action="store_true",
+                    help="N = 1: run the data-parallel collectives through RCCL in a group of one")
+    ap.add_argument("--comm-leg-steps", dest="comm_leg_steps", type=int, default=10,
+                    help="N > 1: timed steps of the extra no-overlap measurement in `comm` (0 = skip)")
+    ap.add_argument("--also-configs", dest="also_configs", default="auto",
+                    help="train workload, N = 1: also time BASELINE.json configs 3-5 (DHRNet 640x192, "
+                         "Lite-Mono 1024x320, DHRNet 512x192) for a few steps each and report them as "
+                         "`other_configs`; auto = on for the default headline run, 'none' = off, or a "
+                         "comma list of C3,C4,C5")
+    ap.add_argument("--also-steps", dest="also_steps", type=int, default=10)
+    ap.add_argument("--also-warmup", dest="also_warmup", type=int, default=5)
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks_if_needed(args):
+    """`python bench.py --gpus N` (N > 1) without a torchrun environment: start the N ranks here.
+    One process per GPU like the reference's launcher (README.md:130-133); refuses to run when
+    the box cannot give every rank its own GPU."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import subprocess
+    if args.workload != "mock":
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.exit(f"[bench] --gpus {args.gpus} needs {args.gpus} GPUs (one process per GPU); this "
+                     f"box has {have}.  Not running {args.gpus} ranks on fewer devices.")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL between processes)
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
-    local = local % torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    if world > 1:
+    mock = args.workload == "mock"
+    if world != args.gpus:
+        sys.exit(f"[bench] --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: "
+                 "refusing to report a line whose n_gpus is not the number of ranks")
+    if mock:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+        if world > torch.cuda.device_count() and os.environ.get("MVF_BENCH_SHARE_GPU") != "1":
+            sys.exit(f"[bench] {world} ranks but {torch.cuda.device_count()} GPUs: one process per GPU")
+        local = local % torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+    backend = None
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        # RCCL ("nccl" on ROCm) over xGMI; MVF_DIST_BACKEND=gloo only for single-GPU dry runs
-        backend = os.environ.get("MVF_DIST_BACKEND", "nccl")
-        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        # RCCL ("nccl" on ROCm) over xGMI; MVF_DIST_BACKEND=gloo only for dry runs / the mock test
+        backend = os.environ.get("MVF_DIST_BACKEND", "gloo" if mock else "nccl")
+        kw = {"device_id": dev} if backend == "nccl" else {}
         torch.distributed.init_process_group(backend=backend, init_method="env://",
                                              world_size=world, rank=rank, **kw)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    return world, rank, torch.device("cuda", local)
+        got = torch.distributed.get_world_size()
+        if got != args.gpus:
+            sys.exit(f"[bench] process group reports world size {got}, --gpus {args.gpus}")
+    return world, rank, dev, backend
+
+
+def comm_report(args, world, rank, dev, backend, step, counts_per_step):
+    """What the process group itself says about the job (all ranks call this)."""
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        return None
+    mine = torch.tensor([torch.cuda.current_device() if dev.type == "cuda" else -1, os.getpid()],
+                        dtype=torch.int64, device=dev)
+    parts = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, mine)
+    devices = [int(p[0]) for p in parts]
+    pids = [int(p[1]) for p in parts]
+    if backend == "nccl" and len(set(devices)) != len(devices):
+        sys.exit(f"[bench] ranks share a GPU under RCCL: devices {devices}")
+    red = getattr(getattr(step, "trainer", step), "reducer", None)
+    rep = {"backend": "rccl (torch backend 'nccl')" if backend == "nccl" else backend,
+           "world_size": dist.get_world_size(), "devices": devices,
+           "distinct_processes": len(set(pids)),
+           "grad_exchange": red.exchange if red else None,
+           "overlap_with_backward": bool(red.overlap) if red else None,
+           "grad_buckets": red.num_buckets if red else 0,
+           "grad_bucket_bytes": red.total_bytes if red else 0,
+           "collectives_per_step": counts_per_step}
+    return rep
 
 
 def barrier_sync(world):
     if world > 1:
         torch.distributed.barrier()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+class MockStep:
+    """Toy data-parallel step on the CPU over gloo (plumbing test of the launcher and of the
+    `comm` report; the numbers mean nothing)."""
+
+    def __init__(self, args, rank, world):
+        from mono_vifi_amd import parallel
+        torch.manual_seed(0)
+        self.net = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.ReLU(), torch.nn.Linear(64, 8))
+        self.reducer = parallel.BucketedGradReducer(
+            list(self.net.parameters()), world, bucket_mb=0.008, exchange=args.grad_exchange,
+            overlap=not args.no_overlap, always_reduce=args.force_collectives)
+        self.x = torch.randn(args.batch, 64, generator=torch.Generator().manual_seed(rank))
+        self.images_per_step = args.batch
+
+    def describe(self):
+        return "mock CPU step (plumbing test of the multi-rank launcher; NOT a benchmark)"
+
+    def __call__(self):
+        self.reducer.zero_grad()
+        loss = self.net(self.x).pow(2).mean()
+        loss.backward()
+        self.reducer.finish()
+        return loss
 
 
 # ----------------------------------------------------------------------------- hot path
+def unit_bytes_per_px(noise_tensor, share_identity, use_affine=True):
+    """Mean algorithmic HBM bytes per pixel and unit over the units of a step:
+    every unit reads disp 4 + target 12 + 2 sources 24 and writes argmin 1 + grad_disp 4 = 45;
+    + 8 tie-break noise when it is supplied as a tensor; + 4 mask_rec on the affine units;
+    + 8 for the identity maps a single-frame unit writes and its multi-frame partner reads."""
+    groups = 3 if use_affine else 2
+    per = [FB_BYTES_PER_PX + (NOISE_BYTES_PER_PX if noise_tensor else 0)] * groups
+    if share_identity:
+        per[0] += 8
+        per[1] += 8
+    if use_affine:
+        per[2] += MASK_BYTES_PER_PX
+    return sum(per) / groups
+
+
 class HotPathStep:
-    """9 fused units, forward + backward, on distinct HBM-resident buffers."""
+    """The 9 units of a step, forward + backward, as the trainer issues them: three launches of
+    three mutually independent units (single-frame / multi-frame / affine, reference
+    train.py:747-760, 795-810, 837-882).  The multi-frame units share target, sources and poses
+    with the single-frame ones (train.py:747-749 vs 795-797) and take their identity maps;
+    every unit has its own disparity, the affine units their own images: 15 distinct image
+    buffers + 9 disparities per step (> 256 MiB Infinity Cache at batch 12, 640x192)."""
 
     def __init__(self, args, rank, dev):
         from types import SimpleNamespace
@@ -133,9 +278,12 @@ class HotPathStep:
         class L(HotPathLosses):
             pass
         self.l = L()
+        self.share = not getattr(args, "no_share_identity", False)
+        self.batched = not getattr(args, "no_batch_units", False)
         self.l.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False,
                                      avg_reprojection=False, disable_automasking=False,
-                                     disparity_smoothness=1e-3, inkernel_noise=args.noise == "kernel")
+                                     disparity_smoothness=1e-3, inkernel_noise=args.noise == "kernel",
+                                     batch_units=self.batched)
         B, H, W = args.batch, args.height, args.width
         self.units = []
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -144,24 +292,38 @@ class HotPathStep:
             affine = u >= 6          # the three affine units carry valid_mask_rec
             inp = synthetic.unit_inputs(1234 + 97 * rank + u, B, H, W, with_mask=affine,
                                         disp_mode=args.disp)
-            aa, tr = t(inp["axisangle"]), t(inp["translation"])
-            T = torch.stack([layers.transformation_from_parameters(aa[k], tr[k], invert=(k == 1))
-                             for k in range(2)], 0).detach()
-            self.units.append(dict(
-                disp=t(inp["disp"]).requires_grad_(True), T=T.requires_grad_(True),
-                tgt=t(inp["tgt"]), src=[t(inp["src"][0]), t(inp["src"][1])],
-                K=t(inp["K"]), inv_K=t(inp["inv_K"]),
-                mask=t(inp["mask_rec"]) if affine else None))
+            d = dict(disp=t(inp["disp"]).requires_grad_(True))
+            if 3 <= u < 6:           # multi-frame unit of target u-3: same target, sources, poses
+                first = self.units[u - 3]
+                d.update({k: first[k] for k in ("T", "tgt", "src", "K", "inv_K", "mask")})
+            else:
+                aa, tr = t(inp["axisangle"]), t(inp["translation"])
+                T = torch.stack([layers.transformation_from_parameters(aa[k], tr[k], invert=(k == 1))
+                                 for k in range(2)], 0).detach()
+                d.update(T=T.requires_grad_(True), tgt=t(inp["tgt"]), src=[t(inp["src"][0]), t(inp["src"][1])],
+                         K=t(inp["K"]), inv_K=t(inp["inv_K"]), mask=t(inp["mask_rec"]) if affine else None)
+            self.units.append(d)
         self.images_per_step = B
+        self.bytes_per_px = unit_bytes_per_px(args.noise != "kernel", self.share and self.batched)
+
+    def describe(self):
+        return None
 
     def __call__(self):
-        total = None
         for u in self.units:
             u["disp"].grad = None
             u["T"].grad = None
-            loss, _ = self.l.compute_unit({("disp", 0): u["disp"]}, u["tgt"], u["T"], u["src"],
-                                          u["K"], u["inv_K"], u["mask"])
-            total = loss if total is None else total + loss
+        total, idents = None, None
+        for g in range(3):
+            us = self.units[3 * g:3 * g + 3]
+            entries = [dict(disp_tgt={("disp", 0): u["disp"]}, img_tgt=u["tgt"], poses=u["T"], imgs_src=u["src"],
+                            K=u["K"], inv_K=u["inv_K"], mask_rec=u["mask"],
+                            ident=(idents[i] if (g == 1 and idents is not None) else None))
+                       for i, u in enumerate(us)]
+            losses, ids, _ = self.l.compute_units(entries, want_ident=(g == 0 and self.share))
+            if g == 0:
+                idents = ids
+            total = losses.sum() if total is None else total + losses.sum()
         total.backward()
         return total
 
@@ -289,39 +451,58 @@ def profiles_source():
                     "not measured in this run"}
 
 
-def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n):
+def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n, fb_pixels=0, fb_bytes_px=None,
+                     static=True, launches_hint=None):
     px = args.batch * args.height * args.width
 
-    def roof(ms, n, bytes_px, name):
+    def roof(ms, n, bytes_px, name, pixels=None):
         if n == 0:
             return None
         avg_s = ms / n / 1e3
-        ach = bytes_px * px / avg_s / 1e9
-        return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "frac_of_measured_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
-                "traffic": traffic_from_profiles(name), "valu": valu_from_profiles(name),
-                "static_source": profiles_source(),
-                "avg_us": round(avg_s * 1e6, 2),
-                "launches": n, "algorithmic_bytes_per_launch": round(bytes_px * px),
-                "algorithmic_bytes_per_px": round(bytes_px, 2)}
+        px_launch = (pixels / n) if pixels else px         # a launch may carry several units
+        ach = bytes_px * px_launch / avg_s / 1e9
+        r = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+             "frac_of_measured_achievable": round(ach / HBM_ACHIEVABLE_GBS, 4),
+             "traffic": traffic_from_profiles(name) if static else None,
+             "valu": valu_from_profiles(name) if static else None,
+             "avg_us": round(avg_s * 1e6, 2),
+             "launches": n, "images_per_launch": round(px_launch / (args.height * args.width), 2),
+             "us_per_unit": round(avg_s * 1e6 * px / px_launch, 2),
+             "algorithmic_bytes_per_launch": round(bytes_px * px_launch),
+             "algorithmic_bytes_per_px": round(bytes_px, 2)}
+        if static:
+            r["static_source"] = profiles_source()
+        return r
 
     r_fwd = roof(fwd_ms, fwd_n, FWD_BYTES_PER_PX, "k_photo_fwd<fused>")
     r_bwd = roof(bwd_ms, bwd_n, BWD_BYTES_PER_PX, "k_photo_bwd<fused>")
-    # forward+backward of a unit in one tile kernel (the training path): priced on ITS OWN
-    # minimum traffic (inputs read once), plus the optional planes the launches were given
-    noise_px = 0 if args.noise == "kernel" else NOISE_BYTES_PER_PX
-    fb_px = FB_BYTES_PER_PX + noise_px + MASK_BYTES_PER_PX * MASKED_UNITS_PER_STEP / UNITS_PER_STEP
-    r_fb = roof(fb_ms, fb_n, fb_px, "k_unit_fb<2>")
+    # forward+backward of units in one tile kernel (the training path): priced on ITS OWN minimum
+    # traffic (inputs read once), plus the optional planes the launches were given
+    if fb_bytes_px is None:
+        st = getattr(launches_hint, "trainer", launches_hint)
+        o = getattr(st, "opt", None)
+        if hasattr(launches_hint, "bytes_per_px"):
+            fb_bytes_px = launches_hint.bytes_per_px
+        elif o is not None:
+            fb_bytes_px = unit_bytes_per_px(not getattr(o, "inkernel_noise", True),
+                                            getattr(o, "share_identity", True) and getattr(o, "batch_units", True)
+                                            and getattr(o, "fused_units", True),
+                                            getattr(o, "use_affine", True))
+        else:
+            fb_bytes_px = unit_bytes_per_px(args.noise != "kernel", True)
+    r_fb = roof(fb_ms, fb_n, fb_bytes_px, "k_unit_fb<2>", fb_pixels)
     if r_fb:
-        survey = (FWD_BYTES_PER_PX + BWD_BYTES_PER_PX) * px / (fb_ms / fb_n / 1e3) / 1e9
+        px_launch = (fb_pixels / fb_n) if fb_pixels else px
+        survey = (FWD_BYTES_PER_PX + BWD_BYTES_PER_PX) * px_launch / (fb_ms / fb_n / 1e3) / 1e9
         r_fb["frac_survey_8d"] = round(survey / HBM_PEAK_GBS, 4)
         r_fb["bytes_note"] = (
-            f"algorithmic bytes = {FB_BYTES_PER_PX} B/px (disp 4 + target 12 + 2 sources 24 read once; "
-            f"argmin 1 + grad_disp 4 written) + {noise_px} B/px tie-break noise tensor + "
-            f"{MASK_BYTES_PER_PX} B/px mask_rec on {MASKED_UNITS_PER_STEP} of {UNITS_PER_STEP} units; "
-            "frac_survey_8d prices the same launch at SURVEY 8d's forward 44 + backward 45 B/px "
-            "(the two kernels it replaces) for comparison with round 1")
+            f"algorithmic bytes per pixel and unit, mean over the units of a step: {FB_BYTES_PER_PX} B (disp 4 + "
+            f"target 12 + 2 sources 24 read once; argmin 1 + grad_disp 4 written), + {NOISE_BYTES_PER_PX} B when the "
+            f"tie-break noise is a tensor, + {MASK_BYTES_PER_PX} B mask_rec on the affine units, + 8 B identity maps "
+            "written by a single-frame unit and read by its multi-frame partner; a launch carries "
+            "images_per_launch images (several units); frac_survey_8d prices the same launch at SURVEY 8d's "
+            "forward 44 + backward 45 B/px (the two kernels it replaces) for comparison with round 1")
     cands = [(ms, r) for ms, r in ((fwd_ms, r_fwd), (bwd_ms, r_bwd), (fb_ms, r_fb)) if r]
     dominant = max(cands, key=lambda t: t[0])[1] if cands else None
     return {"unit_fwd": r_fwd, "unit_bwd": r_bwd, "unit_fwdbwd": r_fb}, dominant
@@ -378,7 +559,8 @@ def hotpath_leg(args, rank, dev, nat, steps=20, warmup=5):
     dt = time.perf_counter() - t0
     nat.lib().mvf_profile_enable(0)
     fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
-    kernels, dom = kernel_rooflines(args, 0.0, 0, 0.0, 0, fb_ms, fb_n)
+    kernels, dom = kernel_rooflines(args, 0.0, 0, 0.0, 0, fb_ms, fb_n, nat.profile_read_work(nat.PROF_UNIT_FWDBWD),
+                                    launches_hint=step)
     return {"value": round(step.images_per_step * steps / dt, 1), "unit": "images/sec",
             "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
             "workload": f"hot path only: {UNITS_PER_STEP} units fwd+bwd, batch {args.batch}, "
@@ -413,20 +595,86 @@ def graph_step_leg(args, rank, world, dev, steps=20):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+OTHER_CONFIGS = {
+    # BASELINE.json configs[2..4] at their per-GPU shapes (reference: configs/dhrnet/DHRNet_KITTI_MR.txt,
+    # configs/litemono/LiteMono_KITTI_HR.txt, configs/dhrnet/DHRNet_CS.txt)
+    "C3": dict(backbone="DHRNet", batch=12, height=192, width=640),
+    "C4": dict(backbone="LiteMono", batch=8, height=320, width=1024),
+    "C5": dict(backbone="DHRNet", batch=12, height=192, width=512),
+}
+
+
+def timed_steps(step, steps, world):
+    barrier_sync(world)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier_sync(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def other_config_leg(args, name, rank, world, dev, nat):
+    """One of BASELINE.json's other training configurations for a few steps (same step function,
+    same timing discipline as the headline; fewer steps so the default run stays within minutes)."""
+    import copy
+    import gc
+    from mono_vifi_amd.bench_train import TrainStep
+    t_leg = time.perf_counter()
+    try:
+        a = copy.copy(args)
+        for k, v in OTHER_CONFIGS[name].items():
+            setattr(a, k, v)
+        step = TrainStep(a, rank, world, dev)
+        for _ in range(args.also_warmup):
+            step()
+        nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
+        nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
+        elapsed = timed_steps(step, args.also_steps, world)
+        nat.lib().mvf_profile_enable(0)
+        fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
+        _, dom = kernel_rooflines(a, 0.0, 0, 0.0, 0, fb_ms, fb_n, nat.profile_read_work(nat.PROF_UNIT_FWDBWD),
+                                  static=False, launches_hint=step)
+        out = {"workload": step.describe(), "value": round(a.batch * world * args.also_steps / elapsed, 2),
+               "unit": "images/sec", "ms_per_step": round(elapsed / args.also_steps * 1e3, 3),
+               "steps": args.also_steps, "warmup": args.also_warmup,
+               "unit_launch_avg_us": dom and dom["avg_us"], "us_per_unit": dom and dom["us_per_unit"],
+               "frac": dom and dom["frac"], "unit_launches": dom and dom["launches"],
+               "images_per_unit_launch": dom and dom.get("images_per_launch")}
+        del step
+        gc.collect()
+        torch.cuda.empty_cache()
+    except Exception as e:      # noqa: BLE001 -- an extra leg must never take the headline line down
+        out = {"error": f"{type(e).__name__}: {e}"[:300]}
+    out["leg_seconds"] = round(time.perf_counter() - t_leg, 1)
+    return out
+
+
 def main():
     args = parse()
-    world, rank, dev = dist_setup(args)
-    from mono_vifi_amd import _native as nat
-    nat.lib()   # fail loudly if the HIP library is missing
+    launch_ranks_if_needed(args)
+    world, rank, dev, backend = dist_setup(args)
+    from mono_vifi_amd import parallel
 
     workload = args.workload
     if workload == "auto":
         workload = "train" if os.path.exists(os.path.join(ROOT, "mono-vifi_amd", "trainer.py")) \
             else "hotpath"
+    nat = None
+    if workload != "mock":
+        from mono_vifi_amd import _native as nat
+        nat.lib()   # fail loudly if the HIP library is missing
     if workload == "train":
         torch.backends.cudnn.benchmark = bool(args.miopen_find)
         from mono_vifi_amd.bench_train import TrainStep
         step = TrainStep(args, rank, world, dev)
+    elif workload == "mock":
+        step = MockStep(args, rank, world)
     else:
         step = HotPathStep(args, rank, dev)
 
@@ -435,24 +683,39 @@ def main():
     if workload == "train" and args.hip_graph:
         while step.trainer._step_graph.graph is None:      # eager warm-up + capture stay untimed
             step()
-    nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
-    nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
-    barrier_sync(world)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier_sync(world)
-    elapsed = time.perf_counter() - t0
-    nat.lib().mvf_profile_enable(0)
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    if nat:
+        nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
+        nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
+    parallel.reset_comm_counts()
+    elapsed = timed_steps(step, args.steps, world)
+    counts = {k: round(v / args.steps, 2) for k, v in sorted(parallel.comm_counts().items())}
+    if nat:
+        nat.lib().mvf_profile_enable(0)
 
-    fwd_ms, fwd_n = nat.profile_read(nat.PROF_UNIT_FWD)
-    bwd_ms, bwd_n = nat.profile_read(nat.PROF_UNIT_BWD)
-    fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
-    kernels, dominant = kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n)
+    kernels, dominant = {}, None
+    if nat:
+        fwd_ms, fwd_n = nat.profile_read(nat.PROF_UNIT_FWD)
+        bwd_ms, bwd_n = nat.profile_read(nat.PROF_UNIT_BWD)
+        fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
+        kernels, dominant = kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n,
+                                             nat.profile_read_work(nat.PROF_UNIT_FWDBWD), launches_hint=step)
+
+    # ---- communication report (every rank takes part in its collectives)
+    comm = comm_report(args, world, rank, dev, backend, step, counts)
+    red = getattr(getattr(step, "trainer", step), "reducer", None)
+    if comm is not None and red is not None and args.comm_leg_steps > 0 and not args.hip_graph:
+        # the same step with the other issue order of the gradient exchange
+        red.overlap = not red.overlap
+        for _ in range(2):
+            step()
+        t_other = timed_steps(step, args.comm_leg_steps, world)
+        red.overlap = not red.overlap
+        key = "overlapped" if args.no_overlap else "no_overlap"
+        comm[key] = {"ms_per_step": round(t_other / args.comm_leg_steps * 1e3, 4),
+                     "steps": args.comm_leg_steps,
+                     "note": "gradient buckets reduced after backward" if key == "no_overlap"
+                             else "gradient buckets reduced from hooks during backward"}
+        comm["timed_region_ms_per_step"] = round(elapsed / args.steps * 1e3, 4)
 
     # like-for-like figure for the CPU baselines: the hot path alone on the GPU, same units
     hotpath_only = None
@@ -468,30 +731,67 @@ def main():
         dominant = dict(hotpath_only["roofline"] or {})
         dominant["note"] = "measured in the hot-path-only leg of this run (HIP events are not recorded inside a graph replay)"
 
+    # ---- BASELINE.json configs 3-5, a few steps each (N = 1 headline run only)
+    also = args.also_configs
+    default_headline = (workload == "train" and world == 1 and args.backbone == "ResNet18" and
+                        (args.batch, args.height, args.width) == (12, 192, 640) and not args.hip_graph)
+    if also == "auto":
+        names = list(OTHER_CONFIGS) if default_headline else []
+    elif also in ("none", "off", ""):
+        names = []
+    else:
+        names = [n.strip().upper() for n in also.split(",") if n.strip()]
+    other = None
+    if names and workload == "train":
+        describe_headline = step.describe()
+        images_headline = step.images_per_step
+        del step            # free the headline trainer's activations and MIOpen workspaces
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        other = {n: other_config_leg(args, n, rank, world, dev, nat) for n in names if n in OTHER_CONFIGS}
+
+        class _Done:        # the headline's description outlives its trainer
+            images_per_step = images_headline
+
+            @staticmethod
+            def describe():
+                return describe_headline
+        step = _Done()
+
     if rank == 0:
+        n_gpus = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        assert n_gpus == args.gpus == world
         images = step.images_per_step * world * args.steps
+        metric = {"train": "training images/sec (640x192, 3-frame)",
+                  "mock": "mock plumbing steps/sec x batch (NOT a benchmark)"}.get(
+            workload, "hot-path images/sec (9 view-synthesis + photometric-loss units "
+                      "fwd+bwd per batch, 640x192, 3-frame)")
         out = {
-            "metric": "training images/sec (640x192, 3-frame)" if workload == "train"
-                      else "hot-path images/sec (9 view-synthesis + photometric-loss units "
-                           "fwd+bwd per batch, 640x192, 3-frame)",
-            "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": world,
+            "metric": metric,
+            "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{workload}: " + getattr(step, "describe", lambda: (
-                f"{UNITS_PER_STEP} units fwd+bwd, batch {args.batch}/GPU, "
-                f"{args.width}x{args.height}, 2 sources/unit, exact mode, {args.disp} disparity"))(),
+            "config": {"workload": f"{workload}: " + (getattr(step, "describe", lambda: None)() or (
+                f"{UNITS_PER_STEP} units fwd+bwd (3 launches of 3 units, identity maps handed from the "
+                f"single-frame to the multi-frame units), batch {args.batch}/GPU, "
+                f"{args.width}x{args.height}, 2 sources/unit, exact mode, {args.disp} disparity")),
                 "global_batch": args.batch * world, "parallelism": f"dp{world}"},
             "roofline": dominant,
             "kernels": kernels,
         }
+        if comm:
+            out["comm"] = comm
         if hotpath_only:
             out["hotpath_only"] = hotpath_only
         if graph_leg:
             out["hip_graph_step"] = graph_leg
+        if other:
+            out["other_configs"] = other
         if workload == "hotpath" and world == 1:
             out["hip_graph_replay"] = graph_replay_leg(step)
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and workload != "mock":
             out["cpu_baseline"] = cpu_baseline(args)
             out["cpu_baseline_unfused"] = cpu_baseline_unfused(args)
             gpu_hp = hotpath_only["value"] if hotpath_only else (out["value"] if workload == "hotpath" else None)
@@ -502,8 +802,8 @@ def main():
                 "gpu_hotpath_only_hip_graph": gr.get("value"),
                 "cpu_port_openmp": out["cpu_baseline"]["value"],
                 "cpu_unfused_torch_ops": out["cpu_baseline_unfused"]["value"]}
-        print(json.dumps(out))
-    if world > 1:
+        print(json.dumps(out), flush=True)
+    if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 

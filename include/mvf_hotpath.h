@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 10
+#define MVF_ABI_VERSION 11
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -44,6 +44,7 @@ extern "C" {
 #define MVF_NO_AUTOMASK 4
 
 #define MVF_MAX_SRC 4
+#define MVF_MAX_UNITS 4 /* hot-path units one mvf_units_fwdbwd launch can carry */
 
 MVF_API int mvf_abi_version(void);
 MVF_API const char *mvf_error_string(int err);
@@ -183,7 +184,64 @@ MVF_API int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *co
                     int32_t *idx_xy, float *g_disp_raw, float *g_T_raw, float *workspace, int B, int H,
                     int W, uint64_t noise_seed, float *noise_out, const float *disp_mean_partials,
                     void *stream);
-/* backward() of the above: g_disp = (g_disp_raw - shift_b) * (*g_loss), g_T = g_T_raw * (*g_loss),
+/* ---- several units in ONE launch ------------------------------------------------------------
+ * Trainer.process_batch (train.py:747-883) runs nine units per step in three groups of three
+ * mutually independent ones (single-frame train.py:747-760, multi-frame 795-810, affine 837-882);
+ * the units of a group share B, H, W, S and the flags and go out as one launch of
+ * n_units * B * tiles workgroups.  Images are addressed as base + b * stride (strides in FLOATS,
+ * 0 = contiguous), so the interleaved [B*G,...] output of a grouped decoder call is read in
+ * place; inside an image the reference's planar layout is required (3*H*W*4 < 2^32 bytes).
+ *
+ * ident_out / ident_in ([B,H,W,2], nullable): the two identity-reprojection maps of the unit
+ * (compute_reprojection_loss of the raw sources against the target, train.py:1020-1022, BEFORE
+ * the tie-break noise).  The multi-frame unit of a target shares target and sources with the
+ * single-frame one (train.py:747-749 vs 795-797), so it can take the maps the first wrote
+ * instead of staging the sources and re-evaluating their SSIM: same values, bit for bit.
+ *
+ * One finishing launch folds the tile partials of all units (loss[3], stats[B,4], g_T_raw;
+ * deterministic: fixed fold order); the last block of a unit to arrive folds its images.
+ * tickets: mvf_units_ticket_ints(n_units, B) int32 counters, ZERO on entry; the call leaves them
+ * zero, so one persistent buffer per stream serves every call.
+ * workspace: mvf_units_workspace_floats(...) floats, 8-byte aligned.
+ * Everything else as for mvf_unit_fwdbwd (which is this call with one contiguous unit). */
+typedef struct mvf_unit_desc {
+    const float *disp;     int64_t disp_stride;       /* [B,1,H,W] */
+    const float *tgt;      int64_t tgt_stride;        /* [B,3,H,W] */
+    const float *src[2];   int64_t src_stride[2];     /* [B,3,H,W] each; src[1] unused when S == 1 */
+    const float *T;                                   /* [S,B,4,4] */
+    const float *K, *inv_K;                           /* [B,4,4] */
+    const float *mask_rec; int64_t mask_stride;       /* nullable [B,1,H,W] */
+    const float *noise;                               /* nullable [B,n_id,H,W] contiguous */
+    const float *disp_mean_partials;                  /* nullable [B,32] */
+    const float *ident_in;                            /* nullable [B,H,W,2] */
+    uint64_t noise_seed;
+    float *ident_out;                                 /* nullable [B,H,W,2] */
+    float *loss;                                      /* [3] */
+    float *stats;                                     /* [B,4] */
+    float *g_disp_raw;     int64_t g_stride;          /* [B,1,H,W] */
+    float *g_T_raw;                                   /* [S,B,4,4] */
+    uint8_t *argmin;                                  /* nullable [B,H,W] */
+    float *auto_mask, *to_opt;                        /* nullable [B,1,H,W] contiguous */
+    int32_t *idx_xy;                                  /* nullable [S,B,H,W,2] */
+    float *noise_out;                                 /* nullable, layout of noise */
+} mvf_unit_desc;
+MVF_API size_t mvf_units_workspace_floats(int n_units, int B, int H, int W);
+MVF_API size_t mvf_units_ticket_ints(int n_units, int B);
+MVF_API int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, float smoothness,
+                     float min_disp, float range, float eps, float *workspace, int32_t *tickets, int B,
+                     int H, int W, void *stream);
+/* backward() of mvf_units_fwdbwd, one launch for the units' grad_disp and grad_T (formula below);
+ * g_loss: one device scalar per unit. */
+typedef struct mvf_unit_scale_desc {
+    const float *g_disp_raw; int64_t in_stride;
+    const float *g_T_raw, *stats, *g_loss;
+    float *g_disp;           int64_t out_stride;
+    float *g_T;
+} mvf_unit_scale_desc;
+MVF_API int mvf_units_fwdbwd_scale(const mvf_unit_scale_desc *units, int n_units, float smoothness, int B,
+                           int S, int H, int W, void *stream);
+
+/* backward() of mvf_unit_fwdbwd: g_disp = (g_disp_raw - shift_b) * (*g_loss), g_T = g_T_raw * (*g_loss),
  * shift_b = (smoothness * (stats[b,2] + stats[b,3]) / (H*W)) / stats[b,1]; g_loss device scalar.
  * In-place use (g_disp == g_disp_raw) is allowed. */
 MVF_API int mvf_unit_fwdbwd_scale(const float *g_disp_raw, const float *g_T_raw, const float *stats,
@@ -375,6 +433,8 @@ MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32
 MVF_API int mvf_profile_enable(int on);
 MVF_API int mvf_profile_reset(void);
 MVF_API int mvf_profile_read(int kernel_id, double *total_ms, int64_t *launches);
+/* pixels (images x H x W, summed over the units of each launch) the recorded launches processed */
+MVF_API int mvf_profile_read_work(int kernel_id, int64_t *pixels);
 
 /* floats of scratch the reducing entry points need for a [B,*,H,W] problem */
 MVF_API size_t mvf_workspace_floats(int B, int H, int W);

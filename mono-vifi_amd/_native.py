@@ -12,12 +12,42 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
+MAX_UNITS = 4
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+
+
+
+class UnitDesc(C.Structure):
+    """mvf_unit_desc (include/mvf_hotpath.h): one unit of an mvf_units_fwdbwd launch."""
+    _fields_ = [
+        ("disp", _vp), ("disp_stride", _i64),
+        ("tgt", _vp), ("tgt_stride", _i64),
+        ("src", _vp * 2), ("src_stride", _i64 * 2),
+        ("T", _vp), ("K", _vp), ("inv_K", _vp),
+        ("mask_rec", _vp), ("mask_stride", _i64),
+        ("noise", _vp), ("disp_mean_partials", _vp), ("ident_in", _vp),
+        ("noise_seed", C.c_uint64),
+        ("ident_out", _vp), ("loss", _vp), ("stats", _vp),
+        ("g_disp_raw", _vp), ("g_stride", _i64),
+        ("g_T_raw", _vp), ("argmin", _vp), ("auto_mask", _vp), ("to_opt", _vp), ("idx_xy", _vp),
+        ("noise_out", _vp),
+    ]
+
+
+class UnitScaleDesc(C.Structure):
+    """mvf_unit_scale_desc: one unit of an mvf_units_fwdbwd_scale launch."""
+    _fields_ = [
+        ("g_disp_raw", _vp), ("in_stride", _i64),
+        ("g_T_raw", _vp), ("stats", _vp), ("g_loss", _vp),
+        ("g_disp", _vp), ("out_stride", _i64),
+        ("g_T", _vp),
+    ]
+
 
 # name -> argument ctypes (return type is always int = hipError_t unless listed in _RESTYPE)
 _SIGNATURES = {
@@ -50,6 +80,11 @@ _SIGNATURES = {
     # to_opt,stats,idx_xy,g_disp_raw,g_T_raw,ws, B,H,W, noise_seed,noise_out,mean_partials, stream
     "mvf_unit_fwdbwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp,
                         _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.c_uint64, _vp, _vp, _vp],
+    # units*, n_units, S, flags, smooth, min_disp, range, eps, workspace, tickets, B, H, W, stream
+    "mvf_units_fwdbwd": [_vp, _i, _i, _i, _f, _f, _f, _f, _vp, _vp, _i, _i, _i, _vp],
+    "mvf_units_fwdbwd_scale": [_vp, _i, _f, _i, _i, _i, _i, _vp],
+    "mvf_units_workspace_floats": [_i, _i, _i, _i],
+    "mvf_units_ticket_ints": [_i, _i],
     "mvf_up2cat_pad_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_up2cat_pad_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_disp_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp],
@@ -90,12 +125,14 @@ _SIGNATURES = {
     "mvf_profile_enable": [_i],
     "mvf_profile_reset": [],
     "mvf_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
+    "mvf_profile_read_work": [_i, C.POINTER(C.c_int64)],
 }
 (PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD,
  PROF_UNIT_FWDBWD) = range(7)
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,
-            "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t}
+            "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t,
+            "mvf_units_workspace_floats": C.c_size_t, "mvf_units_ticket_ints": C.c_size_t}
 
 EXPORTS = tuple(_SIGNATURES)
 
@@ -181,3 +218,10 @@ def profile_read(kernel_id):
     ms, n = C.c_double(0.0), C.c_int64(0)
     check(lib().mvf_profile_read(kernel_id, C.byref(ms), C.byref(n)), "profile_read")
     return ms.value, n.value
+
+
+def profile_read_work(kernel_id):
+    """Pixels (images x H x W over all units of every launch) the recorded launches processed."""
+    px = C.c_int64(0)
+    check(lib().mvf_profile_read_work(kernel_id, C.byref(px)), "profile_read_work")
+    return px.value

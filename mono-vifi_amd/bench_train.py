@@ -27,7 +27,12 @@ class TrainStep:
             log_frequency=10 ** 9, save_frequency=10 ** 9, learning_rate=1e-4,
             amp_bf16=getattr(args, "amp_bf16", False), channels_last=getattr(args, "channels_last", False),
             inkernel_noise=getattr(args, "noise", "kernel") == "kernel",
-            hip_graph=bool(getattr(args, "hip_graph", False)))
+            hip_graph=bool(getattr(args, "hip_graph", False)),
+            batch_units=not getattr(args, "no_batch_units", False),
+            share_identity=not getattr(args, "no_share_identity", False),
+            grad_exchange=getattr(args, "grad_exchange", "all_reduce"),
+            no_overlap=bool(getattr(args, "no_overlap", False)),
+            force_collectives=bool(getattr(args, "force_collectives", False)))
         self.trainer = Trainer(opts)
         self.trainer.set_train()
         b = synthetic.training_batch(1234 + 7919 * rank, args.batch, args.height, args.width)
@@ -39,7 +44,8 @@ class TrainStep:
         o = self.opts
         return (f"full optimisation step, {o.backbone} {o.width}x{o.height} 3-frame, batch "
                 f"{o.batch_size}/GPU, use_affine, {o.fuse_model_type}, IFRNet-L teacher, 9 fused "
-                f"hot-path units (forward+backward tile kernel), "
+                f"hot-path units (forward+backward tile kernel, "
+                f"{'3 launches of 3 units' if o.batch_units else '9 launches'}), "
                 f"{'grouped' if o.group_calls else 'one-at-a-time'} network calls with per-call "
                 f"BatchNorm statistics, AdamW, random-init weights, device-resident synthetic batch "
                 f"(data loading excluded), nets {'bf16 autocast' if o.amp_bf16 else 'fp32'}"

@@ -130,9 +130,58 @@ MVF_DEV float2 ldg2(const float *__restrict__ p)
     F2U v = *reinterpret_cast<const F2U *>(p);
     return make_float2(v.a, v.b);
 }
+// the same load addressed as (plane base) + (32-bit BYTE offset).  With a wave-uniform base this
+// is the scalar-base form of the instruction (global_load_dwordx2 v, v_off, s[base:base+1]): no
+// 64-bit address arithmetic in the VALU.  Round 2's ISA spent ~28 VALU instructions per tap set
+// of a source pair on it (v_mad_u64_u32, v_lshlrev_b64 and twelve v_lshl_add_u64, partly
+// quarter-rate); a plane is far below 4 GiB, so the byte offset fits 32 bits by construction.
+// (global address space stated explicitly: a pointer rebuilt from scalar registers is otherwise
+// a generic one and the access becomes a flat_load)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define MVF_GLOBAL __attribute__((address_space(1)))
+#else
+#define MVF_GLOBAL       /* host pass of the single-source compile: only parsed */
+#endif
+MVF_DEV float2 ldg2_at(const float *__restrict__ base, unsigned byte_off)
+{
+    F2U v = *(const MVF_GLOBAL F2U *)((const MVF_GLOBAL char *)base + byte_off);
+    return make_float2(v.a, v.b);
+}
+
+MVF_DEV float ldg_at(const float *__restrict__ base, unsigned byte_off)
+{
+    return *(const MVF_GLOBAL float *)((const MVF_GLOBAL char *)base + byte_off);
+}
+MVF_DEV float2 ldg_f2_at(const float *__restrict__ base, unsigned byte_off)     // 8-byte aligned
+{
+    return *(const MVF_GLOBAL float2 *)((const MVF_GLOBAL char *)base + byte_off);
+}
+MVF_DEV void stg_at(float *__restrict__ base, unsigned byte_off, float v)
+{
+    *(MVF_GLOBAL float *)((MVF_GLOBAL char *)base + byte_off) = v;
+}
+MVF_DEV void stg_f2_at(float *__restrict__ base, unsigned byte_off, float2 v)     // 8-byte aligned
+{
+    *(MVF_GLOBAL float2 *)((MVF_GLOBAL char *)base + byte_off) = v;
+}
+MVF_DEV void stg_u8_at(uint8_t *__restrict__ base, unsigned byte_off, uint8_t v)
+{
+    *((MVF_GLOBAL uint8_t *)base + byte_off) = v;
+}
+// A pointer every lane of the wave holds the same value of (derived from blockIdx), moved to
+// scalar registers.  hipcc computes 64-bit `base + b * stride` in the VALU (there is no scalar
+// 64-bit multiply on gfx950) and then keeps every address derived from it in VGPR pairs.
+template <typename T>
+MVF_DEV T *uniform_ptr(T *p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<T *>(((uint64_t)hi << 32) | lo);
+}
 
 struct TapRows {
-    unsigned o0, o1;   // offsets of the tap pairs in rows y0 and y1
+    unsigned o0, o1;   // BYTE offsets of the tap pairs in rows y0 and y1 within one [H,W] plane
     bool sh;           // pair anchored one pixel left of x0 (right border)
 };
 MVF_DEV TapRows taprows_of(const Tap &t, int W)
@@ -140,14 +189,16 @@ MVF_DEV TapRows taprows_of(const Tap &t, int W)
     TapRows q;
     int xb = min(t.x0, W - 2);
     q.sh = t.x0 > xb;
-    q.o0 = (unsigned)t.y0 * W + xb;
-    q.o1 = (unsigned)t.y1 * W + xb;
+    // 24-bit multiplies (full rate; y < 2^24 rows, 4 W < 2^24): v_mad_u32_u24
+    const unsigned w4 = (unsigned)W * 4u, x4 = (unsigned)xb * 4u;
+    q.o0 = __umul24((unsigned)t.y0, w4) + x4;
+    q.o1 = __umul24((unsigned)t.y1, w4) + x4;
     return q;
 }
 MVF_DEV void load_taps(const float *__restrict__ im, const TapRows &q, float &nw, float &ne, float &sw,
                        float &se)
 {
-    float2 r0 = ldg2(im + q.o0), r1 = ldg2(im + q.o1);
+    float2 r0 = ldg2_at(im, q.o0), r1 = ldg2_at(im, q.o1);
     nw = q.sh ? r0.y : r0.x;
     ne = r0.y;
     sw = q.sh ? r1.y : r1.x;
@@ -555,13 +606,15 @@ inline int hip_check_launch()
 }
 
 // measurement hooks (implemented in mvf_geom.hip): event pair around one kernel launch
+// `work` = pixels the launch processes (summed per kernel id: a launch may carry several units)
 void prof_begin(int kernel_id, hipStream_t st);
-void prof_end(int kernel_id, hipStream_t st);
+void prof_end(int kernel_id, hipStream_t st, int64_t work);
 struct ProfScope {
     int id;
     hipStream_t st;
-    ProfScope(int kernel_id, hipStream_t s) : id(kernel_id), st(s) { prof_begin(id, st); }
-    ~ProfScope() { prof_end(id, st); }
+    int64_t work;
+    ProfScope(int kernel_id, hipStream_t s, int64_t w = 0) : id(kernel_id), st(s), work(w) { prof_begin(id, st); }
+    ~ProfScope() { prof_end(id, st, work); }
 };
 
 }  // namespace mvf

@@ -724,6 +724,7 @@ struct ProfState {
     hipEvent_t open_start[MVF_PROF_COUNT] = {};
     double acc_ms[MVF_PROF_COUNT] = {};
     int64_t acc_n[MVF_PROF_COUNT] = {};
+    int64_t acc_work[MVF_PROF_COUNT] = {};     // pixels processed (a launch may carry several units)
 };
 ProfState &prof() { static ProfState p; return p; }
 constexpr size_t kMaxPairs = 1 << 16;
@@ -756,12 +757,13 @@ void prof_begin(int id, hipStream_t st)
     p.open_start[id] = e;
 }
 
-void prof_end(int id, hipStream_t st)
+void prof_end(int id, hipStream_t st, int64_t work)
 {
     ProfState &p = prof();
     if (!p.on) return;
     std::lock_guard<std::mutex> g(p.mu);
     if (!p.open_start[id]) return;
+    p.acc_work[id] += work;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, st);
@@ -800,6 +802,7 @@ int mvf_profile_reset(void)
         mvf::drain(p, i);
         p.acc_ms[i] = 0.0;
         p.acc_n[i] = 0;
+        p.acc_work[i] = 0;
     }
     return 0;
 }
@@ -815,12 +818,22 @@ int mvf_profile_read(int id, double *total_ms, int64_t *launches)
     return 0;
 }
 
+int mvf_profile_read_work(int id, int64_t *pixels)
+{
+    if (id < 0 || id >= MVF_PROF_COUNT || !pixels) return (int)hipErrorInvalidValue;
+    auto &p = mvf::prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    *pixels = p.acc_work[id];
+    return 0;
+}
+
 const char *mvf_error_string(int err) { return hipGetErrorString((hipError_t)err); }
 
 size_t mvf_workspace_floats(int B, int H, int W)
 {
     size_t nblk = ((size_t)H * W + NT - 1) / NT;
-    return (size_t)B * nblk * 16 * MVF_MAX_SRC + 1024;
+    // (+ B*16: mvf_unit_fwdbwd keeps its ticket counters behind the one-unit workspace)
+    return (size_t)B * nblk * 16 * MVF_MAX_SRC + 1024 + (size_t)B * 16;
 }
 
 int mvf_disp_to_depth_fwd(const float *disp, float *scaled, float *depth, int64_t n,

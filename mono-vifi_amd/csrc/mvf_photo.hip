@@ -250,13 +250,13 @@ __global__ void __launch_bounds__(NT, MVF_FWD_WAVES) k_photo_fwd(FwdArgs a)
 
 // per-image mean of disp: NMEAN partial sums per image, folded in fixed order by consumers
 __global__ void __launch_bounds__(256) k_disp_mean(const float *__restrict__ disp,
-                                                   float *__restrict__ ws, int N)
+                                                   float *__restrict__ ws, int N, size_t stride)
 {
     __shared__ float scratch[4];
     int b = blockIdx.y, chunk = blockIdx.x;
     int per = (N + NMEAN - 1) / NMEAN;
     int lo = chunk * per, hi = min(lo + per, N);
-    const float *d = disp + (size_t)b * N;
+    const float *d = disp + (size_t)b * stride;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int i = lo + threadIdx.x;
     for (; i + 3 * 256 < hi; i += 4 * 256) {
@@ -976,7 +976,7 @@ int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *sta
     const int N = a.H * a.W;
     a.tiles_x = (a.W + TW - 1) / TW;
     a.tiles_y = (a.H + TH - 1) / TH;
-    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, a.B), dim3(256), 0, st, a.disp, a.ws, N);
+    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, a.B), dim3(256), 0, st, a.disp, a.ws, N, (size_t)N);
     dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B));
     {
         ProfScope ps(fused ? MVF_PROF_UNIT_FWD : MVF_PROF_PHOTO_FWD, st);
@@ -992,9 +992,9 @@ int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *sta
 
 // shared with mvf_unit_fb.hip
 namespace mvf_photo {
-void launch_disp_mean(const float *disp, float *ws, int B, int N, hipStream_t st)
+void launch_disp_mean(const float *disp, size_t image_stride, float *ws, int B, int N, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, ws, N);
+    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, ws, N, image_stride);
 }
 }  // namespace mvf_photo
 
@@ -1048,7 +1048,7 @@ int mvf_smooth_fwd(const float *disp, const float *img, float *out, float *stats
     if (B * H * W <= 0) return 0;
     hipStream_t st = (hipStream_t)stream;
     int nblk = (H * W + 255) / 256;
-    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, workspace, H * W);
+    hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, workspace, H * W, (size_t)H * W);
     hipLaunchKernelGGL(k_smooth_fwd, dim3(nblk, B), dim3(256), 0, st, disp, img, workspace,
                        normalise, B, H, W);
     hipLaunchKernelGGL(k_finish_fwd, dim3(1), dim3(1024), 0, st, workspace, out, stats, B, H, W,

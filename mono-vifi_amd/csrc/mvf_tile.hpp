@@ -70,6 +70,13 @@ MVF_DEV int refl_clamp(int j, int n)
     return min(max(j, 0), n - 1);
 }
 
+// byte offset of pixel (gy, gx) inside one [H,W] fp32 plane: 24-bit multiply (full rate), 32-bit
+// result -- with a wave-uniform plane base the load takes the scalar-base form (mvf_common.hpp)
+MVF_DEV unsigned plane_off4(int gy, int gx, int W)
+{
+    return __umul24((unsigned)gy, (unsigned)W * 4u) + (unsigned)gx * 4u;
+}
+
 // stage one [H,W] plane into LDS with reflect addressing; plane origin (py0, px0)
 constexpr int NSTAGE = (PH * PW + NT - 1) / NT;   // plane elements per lane (5)
 
@@ -84,7 +91,7 @@ MVF_DEV void stage_plane(float *__restrict__ lds, const float *__restrict__ img,
         int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        v[it] = img[(unsigned)gy * W + gx];
+        v[it] = ldg_at(img, plane_off4(gy, gx, W));
     }
 #pragma unroll
     for (int it = 0; it < NSTAGE; ++it) {
@@ -104,8 +111,8 @@ MVF_DEV void stage_planes3(float *__restrict__ lds, const float *__restrict__ im
         int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        unsigned o = (unsigned)gy * W + gx;
-        v[it][0] = img[o]; v[it][1] = img[N + o]; v[it][2] = img[2 * N + o];
+        const unsigned o = plane_off4(gy, gx, W);
+        v[it][0] = ldg_at(img, o); v[it][1] = ldg_at(img + N, o); v[it][2] = ldg_at(img + 2 * N, o);
     }
 #pragma unroll
     for (int it = 0; it < NSTAGE; ++it) {
@@ -315,8 +322,8 @@ MVF_DEV void stage_lane3(f2 *__restrict__ pairP, int lane, const float *__restri
         int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        unsigned o = (unsigned)gy * W + gx;
-        v[it][0] = im[o]; v[it][1] = im[N + o]; v[it][2] = im[2 * N + o];
+        const unsigned o = plane_off4(gy, gx, W);
+        v[it][0] = ldg_at(im, o); v[it][1] = ldg_at(im + N, o); v[it][2] = ldg_at(im + 2 * N, o);
     }
 #pragma unroll
     for (int it = 0; it < NSTAGE; ++it) {
@@ -353,11 +360,11 @@ MVF_DEV void stage_first(float *__restrict__ tgtP, float *__restrict__ dispP, f2
         int idx = min((int)threadIdx.x + it * NT, PH * PW - 1);
         int r = idx / PW, c = idx - r * PW;
         int gy = refl_clamp(py0 + r, H), gx = refl_clamp(px0 + c, W);
-        unsigned o = (unsigned)gy * W + gx;
-        vt[it][0] = tgt[o]; vt[it][1] = tgt[N + o]; vt[it][2] = tgt[2 * N + o];
-        vd[it] = disp[o];
-        va[it][0] = im0[o]; va[it][1] = im0[N + o]; va[it][2] = im0[2 * N + o];
-        vb[it][0] = im1[o]; vb[it][1] = im1[N + o]; vb[it][2] = im1[2 * N + o];
+        const unsigned o = plane_off4(gy, gx, W);
+        vt[it][0] = ldg_at(tgt, o); vt[it][1] = ldg_at(tgt + N, o); vt[it][2] = ldg_at(tgt + 2 * N, o);
+        vd[it] = ldg_at(disp, o);
+        va[it][0] = ldg_at(im0, o); va[it][1] = ldg_at(im0 + N, o); va[it][2] = ldg_at(im0 + 2 * N, o);
+        vb[it][0] = ldg_at(im1, o); vb[it][1] = ldg_at(im1 + N, o); vb[it][2] = ldg_at(im1 + 2 * N, o);
     }
 #pragma unroll
     for (int it = 0; it < NSTAGE; ++it) {
@@ -477,10 +484,10 @@ MVF_DEV WarpSlot warp_slot(int idx, const float *__restrict__ dispP, const float
     s.qa = taps_of(w.ta, W);
     s.qb = taps_of(w.tb, W);
 #ifdef MVF_ABL_COALESCED   // ablation: taps at the pixel itself (perfectly coalesced gathers)
-    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = (unsigned)gy * W + min(gx, W - 2);
+    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = ((unsigned)gy * W + min(gx, W - 2)) * 4u;
 #endif
 #ifdef MVF_ABL_NOCHAIN     // ablation: no projection chain (taps from the disparity bits)
-    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = (unsigned)gy * W + min(gx, W - 2);
+    s.qa.q.o0 = s.qa.q.o1 = s.qb.q.o0 = s.qb.q.o1 = ((unsigned)gy * W + min(gx, W - 2)) * 4u;
     s.qa.wnw = s.qb.wnw = dispP[s.r * LDW + s.c];
 #endif
     s.x0a = w.ta.x0; s.y0a = w.ta.y0; s.x0b = w.tb.x0; s.y0b = w.tb.y0;

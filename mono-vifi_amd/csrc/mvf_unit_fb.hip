@@ -1,20 +1,27 @@
-// mvf_unit_fb.hip -- forward AND backward of one hot-path unit in a single tile kernel
-// (mvf_unit_fwdbwd): S <= 2 x generate_images_pred (train.py:956-971) + compute_losses_base
-// (train.py:987-1051) + its whole adjoint down to grad_disp and grad_T.  This is the kernel the
-// training step runs nine times (train.py:747-883).
+// mvf_unit_fb.hip -- forward AND backward of hot-path units in a single tile kernel
+// (mvf_units_fwdbwd): per unit, S <= 2 x generate_images_pred (train.py:956-971) +
+// compute_losses_base (train.py:987-1051) + its whole adjoint down to grad_disp and grad_T.
+// A training step runs nine units (train.py:747-883); the three of each group (single-frame /
+// multi-frame / affine: train.py:747-760, 795-810, 837-882) are mutually independent and go
+// out as ONE launch: workgroup -> (unit, image, tile), per-unit descriptors in the kernel
+// arguments, images addressed by (base, image stride) so that the interleaved output of a
+// grouped decoder call is read where it lies.
 //
 // In training both directions of a unit always run, and everything the backward needs from the
 // forward is per-pixel local -- the candidates, their min / argmin, the mask -- except two
-// per-image scalars: the mean disparity (k_disp_mean runs first) and the smoothness sum of the
-// mean-normalisation term, which enters grad_disp as a per-image constant and is applied by
-// mvf_unit_fwdbwd_scale together with the upstream gradient (the backward is linear in it).
+// per-image scalars: the mean disparity (the disparity head's partials, or k_disp_mean first)
+// and the smoothness sum of the mean-normalisation term, which enters grad_disp as a per-image
+// constant and is applied by mvf_units_fwdbwd_scale together with the upstream gradient (the
+// backward is linear in it).
 //
-// One workgroup (256 lanes, 4 px per lane) owns a 64x16 region and emits its 62x14 interior, so
+// One workgroup (256 lanes, 2 px per lane) owns a 32x16 region and emits its 30x14 interior, so
 // the 3x3 (reflect-aware) SSIM adjoint never leaves the workgroup.  Phases:
-//   1  stage target, disparity and the identity pair (one memory phase, 35 loads per lane)
-//   2  identity candidates (SSIM + L1, packed for the pair)
-//   3  fused warp of the source pair into LDS: exact projection chain (guard-free divides),
-//      all taps of two plane positions in flight
+//   1  stage target, disparity and the identity pair (one memory phase)
+//   2  identity candidates (SSIM + L1, packed for the pair) -- or, for the second unit of a
+//      (single-frame, multi-frame) pair that shares target and sources (train.py:747-812), the
+//      identity maps the first unit wrote (ident_out -> ident_in: 8 B/px instead of 24 B/px of
+//      staging and the identity pair's SSIM; the tie-break noise is still per unit)
+//   3  fused warp of the source pair into LDS: exact projection chain (guard-free divides)
 //   4  warped candidates: ONE pass over the window statistics yields the SSIM value AND its
 //      partial derivatives, which stay in registers (unweighted) until the argmin is known
 //   5  min / argmin / mask / outputs
@@ -22,15 +29,14 @@
 //      in the channel's (consumed) pair plane
 //   7  bilinear + projection adjoint per output pixel -> grad_disp, grad_P partials
 //   8  smoothness (value and gradient), store, ONE reduction of all 27 tile partials
+// One finishing launch per unit launch (k_units_finish: loss, stats, grad_T of every unit).
 // Compiled with -ffp-contract=off (arithmetic contract in mvf_common.hpp): everything that
 // feeds an integer (sampling indices, argmin) follows the reference's evaluation order.
-// Region geometry of this kernel (mvf_tile.hpp): 32 x 16 pixels, 2 per lane.  Compared with the
-// 64 x 16 / 4-px geometry of the separate forward / backward kernels the workgroup needs 40 KB
-// of LDS instead of 75 KB and half the per-lane register state (128 VGPRs), so FOUR workgroups
-// share a CU instead of two (4 waves per SIMD).  The kernel is bound by exposed latency (plane
-// staging, tap gathers, 14 barriers per tile): measured at B12 640x192, 1 / 2 workgroups per CU
-// with the 64x16 geometry 252 / 158 us, 3 / 4 with this one 148 / 138 us although it executes
-// 14 % more VALU instructions (more halo per output pixel, less product sharing per lane).
+// Region geometry (mvf_tile.hpp): 32 x 16 pixels, 2 per lane: 40 KB of LDS and 128 VGPRs, so FOUR
+// workgroups share a CU (4 waves per SIMD).
+// Addressing: every image base is wave-uniform (blockIdx) and held in scalar registers; pixels
+// and taps are 32-bit byte offsets from it (scalar-base global loads, 24-bit multiplies) -- round
+// 2's ISA spent 236 64-bit VALU address instructions, partly quarter rate, on the same accesses.
 #ifndef MVF_FB_TW
 #define MVF_FB_TW 32
 #endif
@@ -52,19 +58,30 @@ namespace {
 
 constexpr int OW = TW - 2, OH = TH - 2;   // output interior of a region
 constexpr int NRED = 27;                  // 24 grad_P + photo + smooth x + smooth y
+constexpr int NIMG = 4;                   // doubles per image of the folded loss terms (photo, sx, sy, pad)
 
-struct FbArgs {
-    const float *disp, *tgt, *mask, *T, *K, *invK, *noise, *mean_ws;
-    SrcPtrs src;
+// one unit of a launch (device copy of mvf_unit_desc, include/mvf_hotpath.h)
+struct UnitArgs {
+    const float *disp, *tgt, *src0, *src1, *mask, *T, *K, *invK, *noise, *mean_ws, *ident_in;
+    size_t disp_stride, tgt_stride, src0_stride, src1_stride, mask_stride, g_stride;
     float *g_disp;        // [B,1,H,W] for an upstream gradient of 1, WITHOUT the per-image shift
-    float *gp_ws;         // [S][B][ntiles][12] grad_P partials
-    float *part;          // [B][ntiles][NPART] loss partials
+    float *g_T;           // [S,B,4,4]
+    float *loss, *stats;  // [3], [B,4]
+    float *ident_out;
     uint8_t *argmin_out;
     float *auto_mask_out, *to_opt_out, *noise_out;
     int32_t *idx_xy;
-    int flags, B, H, W, tiles_x, tiles_y;
-    float smoothness, min_disp, range, eps;
     uint32_t seed0, seed1;   // in-kernel tie-break noise (noise == nullptr)
+};
+
+struct FbArgs {
+    UnitArgs u[MVF_MAX_UNITS];
+    float *gp_ws;         // [U][S][B][ntiles][12] grad_P partials
+    float *part;          // [U][B][ntiles][NPART] loss partials
+    double *img_ws;       // [U][B][NIMG] per-image folded loss terms
+    int *tickets;         // [U] one per unit (k_units_finish); zero on entry, zero on exit
+    int nunits, flags, B, H, W, tiles_x, tiles_y;
+    float smoothness, min_disp, range, eps;
 };
 
 // LDS carve (floats): target 3 planes | pair 3 f2 planes | disparity | coefficient 3 f2 region
@@ -356,8 +373,13 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + FB_POSE);
     float *scratch = smem + FB_COEF;       // the coefficient planes are free when the final reduction runs
 
-    const TileId tid = tile_of_block(a.tiles_x, a.tiles_y, a.B);
-    const int H = a.H, W = a.W, b = tid.b;
+    // workgroup -> (unit, image, tile): the images of all units form one batch of nunits * B
+    const TileId tid = tile_of_block(a.tiles_x, a.tiles_y, a.B * a.nunits);
+    const int H = a.H, W = a.W;
+    const int unit = __builtin_amdgcn_readfirstlane(tid.b / a.B);
+    const int b = __builtin_amdgcn_readfirstlane(tid.b - unit * a.B);
+    const int ub = unit * a.B + b;          // image slot of this launch
+    const UnitArgs &u = a.u[unit];
     const size_t N = (size_t)H * W;
     const int cy0 = tid.by * OH - 1, cx0 = tid.bx * OW - 1;   // region origin
     const int py0 = cy0 - 1, px0 = cx0 - 1;                   // plane origin
@@ -368,15 +390,23 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     constexpr bool hasb = S > 1;
     constexpr int kb = hasb ? 1 : 0;
 
+    // image bases in scalar registers
+    const float *tgt_b = uniform_ptr(u.tgt + (size_t)b * u.tgt_stride);
+    const float *disp_b = uniform_ptr(u.disp + (size_t)b * u.disp_stride);
+    const float *sa = uniform_ptr(u.src0 + (size_t)b * u.src0_stride);
+    const float *sb = hasb ? uniform_ptr(u.src1 + (size_t)b * u.src1_stride) : sa;
+    const float *iK = u.invK + b * 16;
+    const bool ident_given = automask && (u.ident_in != nullptr);
+
     if (threadIdx.x == 0) {
         float m = 0.0f;
-        for (int i = 0; i < NMEAN; ++i) m += a.mean_ws[b * NMEAN + i];
+        for (int i = 0; i < NMEAN; ++i) m += u.mean_ws[b * NMEAN + i];
         sh.den = m / (float)N + 1e-7f;
         sh.gpix = 1.0f / (float)((double)a.B * (double)N);
     }
     if (threadIdx.x < 12 * S) {
         int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
-        sh.P[k][e] = proj_entry(a.K + b * 16, a.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
+        sh.P[k][e] = proj_entry(u.K + b * 16, u.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
     }
     const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
     const int off = row * LDW + seg * PX;     // plane element of the window's top-left
@@ -386,58 +416,59 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
 
     // ---- 1: target, disparity (and the identity pair) -> LDS
-    if (automask) {
-        stage_first(tgtP, dispP, pairP, a.tgt + (size_t)b * 3 * N, a.disp + (size_t)b * N,
-                    a.src.p[0] + (size_t)b * 3 * N, a.src.p[kb] + (size_t)b * 3 * N, N, H, W, py0, px0);
+    if (automask && !ident_given) {
+        stage_first(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, H, W, py0, px0);
     } else {
-        stage_planes3(tgtP, a.tgt + (size_t)b * 3 * N, N, H, W, py0, px0);
-        stage_plane(dispP, a.disp + (size_t)b * N, H, W, py0, px0);
+        stage_planes3(tgtP, tgt_b, N, H, W, py0, px0);
+        stage_plane(dispP, disp_b, H, W, py0, px0);
     }
     __syncthreads();
 
-    // ---- 3a: the first plane position of the fused warp is started BEFORE the identity pass:
-    // its projection chain only needs the staged disparity, and its 24 tap pairs then fly
-    // while the identity SSIM (pure LDS / VALU work) runs
     f2 P2[12];
     load_pose_pair(sh, 0, kb, P2);
     WarpCtx wk_ctx;
     {
         WarpCtx &k = wk_ctx;
         k.pairP = pairP; k.dispP = dispP;
-        k.sa = a.src.p[0] + (size_t)b * 3 * N; k.sb = a.src.p[kb] + (size_t)b * 3 * N;
-        k.iK = a.invK + b * 16; k.P2 = P2;
+        k.sa = sa; k.sb = sb;
+        k.iK = iK; k.P2 = P2;
         k.H = H; k.W = W; k.py0 = py0; k.px0 = px0; k.oy0 = cy0 + 1; k.ox0 = cx0 + 1;
         k.min_disp = a.min_disp; k.range = a.range; k.eps = a.eps;
-        k.idx_a = a.idx_xy ? a.idx_xy + ((size_t)b) * N * 2 : nullptr;
-        k.idx_b = a.idx_xy ? a.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
+        k.idx_a = u.idx_xy ? u.idx_xy + ((size_t)b) * N * 2 : nullptr;
+        k.idx_b = u.idx_xy ? u.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
     }
-    // (pays at 2 workgroups / CU with the 64x16 geometry; with 32x16 the 48 tap registers it
-    // pins across the identity pass push the kernel over the 3-waves/SIMD register budget)
-#if MVF_FB_PX == 2
-#define MVF_FB_NO_PREFETCH 1
-#endif
-#ifndef MVF_FB_NO_PREFETCH
-    WarpBatch<1> pre;
-    if (automask) warp_issue<1>(wk_ctx, 0, pre);
-#endif
 
     // ---- 2: identity candidates of every region pixel
     f2 vid[PX];
 #pragma unroll
     for (int j = 0; j < PX; ++j) vid[j] = f2s(0.0f);
-    if (automask) {
+    if (automask && !ident_given) {
 #ifndef MVF_ABL_NOID     // timing ablation: identity candidates not evaluated
         reproj_identity(pairP, tgtP, off, no_ssim, vid, coefP, roff);
 #else
         for (int j = 0; j < PX; ++j) vid[j] = pairP[off + LDW + 1 + j];
 #endif
         __syncthreads();                       // identity pair consumed
-    } else if (!no_ssim) {
+    } else {
+        if (ident_given) {
+            // the identity maps of the unit this one shares target and sources with (pre-noise;
+            // exactly the values reproj_identity would produce here): one 8-byte load per pixel,
+            // in flight while the target statistics below are evaluated
+            const float *idb = uniform_ptr(u.ident_in + (size_t)b * N * 2);
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                const int yc = min(max(y, 0), H - 1), xc = min(max(x0 + j, 0), W - 1);
+                const float2 v = ldg_f2_at(idb, plane_off4(yc, xc, W) * 2u);
+                vid[j] = mk2(v.x, v.y);
+            }
+        }
+        if (!no_ssim) {
 #pragma unroll 1
-        for (int c = 0; c < 3; ++c) {
-            f2 my[PX];
-            target_stats(tgtP + c * PLANE + off, my);
-            stash_tstats(coefP + c * RPPLANE + roff, my);
+            for (int c = 0; c < 3; ++c) {
+                f2 my[PX];
+                target_stats(tgtP + c * PLANE + off, my);
+                stash_tstats(coefP + c * RPPLANE + roff, my);
+            }
         }
     }
 
@@ -446,18 +477,12 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     stage_pair3(pairP, wk_ctx.sa, wk_ctx.sb, N, H, W, py0, px0);
     if (false)
 #endif
-#ifndef MVF_FB_NO_PREFETCH
-    if (automask) {
-        warp_finish<1>(wk_ctx, pre);
-        warp_pair_into_lds_fb(wk_ctx, 1);
-    } else
-#endif
         warp_pair_into_lds_fb(wk_ctx, 0);
     __syncthreads();
 
-    // ---- 4: warped candidates; SSIM partials of the three channels stay in registers.
-    // The channel loop is rolled (code size); the partials rotate through three static slots:
-    // after the loop slot 2 holds channel 0, slot 1 channel 1, slot 0 channel 2.
+    // ---- 4: warped candidates; the SSIM partials of the three channels stay in registers
+    // (channel loops unrolled: round 2 rolled them and rotated the partials through three slots,
+    // 24 register moves per channel here and again in phase 6)
     f2 pm[3][PX], px2[3][PX], pg[3][PX];      // d/d mu_x, 2 d/d E[xx], d/d E[xy]
     f2 vw[PX];
     {
@@ -468,13 +493,12 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
             for (int q = 0; q < 3; ++q) pm[q][j] = px2[q][j] = pg[q][j] = f2s(0.0f);
         }
-#pragma unroll 1
-        for (int c = 0; c < 3; ++c) {
+#ifndef MVF_FB_ROLL4
 #pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                pm[2][j] = pm[1][j]; px2[2][j] = px2[1][j]; pg[2][j] = pg[1][j];
-                pm[1][j] = pm[0][j]; px2[1][j] = px2[0][j]; pg[1][j] = pg[0][j];
-            }
+#else
+#pragma unroll 1
+#endif
+        for (int c = 0; c < 3; ++c) {
 #ifdef MVF_ABL_NOSSIM4
             if (true) {
 #else
@@ -494,7 +518,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                     const f2 my = tm[j];
                     f2 val;
                     ssim_val_partials_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
-                                         div9(s.sxy[j]), val, pm[0][j], px2[0][j], pg[0][j]);
+                                         div9(s.sxy[j]), val, pm[c][j], px2[c][j], pg[c][j]);
                     ss[j] = ss[j] + val;
                     ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
                 }
@@ -512,26 +536,25 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // waves per SIMD); with 4 workgroups per CU the one exposed load latency is covered
     float mraw[PX];            // mask value (1 without a mask), 0 outside the image
     f2 nz[PX];
+    const float *mask_b = u.mask ? uniform_ptr(u.mask + (size_t)b * u.mask_stride) : nullptr;
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         const int x = x0 + j;
         const bool in = rowin && (x >= 0) && (x < W);
-        const size_t pix = (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
-        const size_t pi = (size_t)b * N + pix;
-        mraw[j] = in ? ((a.mask) ? a.mask[pi] : 1.0f) : 0.0f;
+        const unsigned pix4 = plane_off4(min(max(y, 0), H - 1), min(max(x, 0), W - 1), W);
+        mraw[j] = in ? (mask_b ? ldg_at(mask_b, pix4) : 1.0f) : 0.0f;
         nz[j] = f2s(0.0f);
         if (automask && in) {
-            if (a.noise) {
-                if (avg) nz[j] = f2s(a.noise[pi]);
-                else nz[j] = mk2(a.noise[((size_t)b * S) * N + pix], hasb ? a.noise[((size_t)b * S + 1) * N + pix] : 0.0f);
+            if (u.noise) {
+                const float *nb = uniform_ptr(u.noise + (size_t)b * (avg ? 1 : S) * N);
+                if (avg) nz[j] = f2s(ldg_at(nb, pix4));
+                else nz[j] = mk2(ldg_at(nb, pix4), hasb ? ldg_at(nb + N, pix4) : 0.0f);
             } else {
-                nz[j] = normal_pair(a.seed0, a.seed1, (uint32_t)pi);
-                if (a.noise_out) {
-                    if (avg) a.noise_out[pi] = nz[j].x;
-                    else {
-                        a.noise_out[((size_t)b * S) * N + pix] = nz[j].x;
-                        if (hasb) a.noise_out[((size_t)b * S + 1) * N + pix] = nz[j].y;
-                    }
+                nz[j] = normal_pair(u.seed0, u.seed1, (uint32_t)b * (uint32_t)N + (pix4 >> 2));
+                if (u.noise_out) {
+                    float *nb = uniform_ptr(u.noise_out + (size_t)b * (avg ? 1 : S) * N);
+                    stg_at(nb, pix4, nz[j].x);
+                    if (!avg && hasb) stg_at(nb + N, pix4, nz[j].y);
                 }
             }
         }
@@ -544,7 +567,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     for (int j = 0; j < PX; ++j) {
         const int x = x0 + j, col = seg * PX + j;
         const bool in = rowin && (x >= 0) && (x < W);
-        const size_t pi = (size_t)b * N + (size_t)min(max(y, 0), H - 1) * W + min(max(x, 0), W - 1);
+        const unsigned pix4 = plane_off4(min(max(y, 0), H - 1), min(max(x, 0), W - 1), W);
         float best = 0.0f;
         int bi = 0, nc = 0;
         if (automask) {
@@ -577,13 +600,15 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 ++nc;
             }
         }
-        if (a.mask) best = best * mraw[j];
+        if (mask_b) best = best * mraw[j];
         const int sel = (nc > 1) ? bi : 255;
         const bool outp = row_out && (col >= 1) && (col <= OW) && in;
         if (outp) {
-            if (a.argmin_out) a.argmin_out[pi] = (uint8_t)sel;
-            if (a.auto_mask_out) a.auto_mask_out[pi] = (bi > n_id - 1) ? 1.0f : 0.0f;
-            if (a.to_opt_out) a.to_opt_out[pi] = best;
+            if (u.argmin_out) stg_u8_at(uniform_ptr(u.argmin_out + (size_t)b * N), pix4 >> 2, (uint8_t)sel);
+            if (u.auto_mask_out) stg_at(uniform_ptr(u.auto_mask_out + (size_t)b * N), pix4, (bi > n_id - 1) ? 1.0f : 0.0f);
+            if (u.to_opt_out) stg_at(uniform_ptr(u.to_opt_out + (size_t)b * N), pix4, best);
+            if (u.ident_out && automask)
+                stg_f2_at(uniform_ptr(u.ident_out + (size_t)b * N * 2), pix4 * 2u, make_float2(vid[j].x, vid[j].y));
             fb_photo += best;
         }
         // selection weight of the two sources: the argmin picked it (or the averaged channel)
@@ -597,10 +622,10 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 
     // ---- 6: SSIM adjoint, one channel at a time through the coefficient planes.
     // g_x(q) = sum over the 3x3 windows p around q of A(p) + x(q) B(p) + y(q) G(p).  The
-    // horizontal 3-sums are formed in registers before the LDS round trip: a lane owns 4
+    // horizontal 3-sums are formed in registers before the LDS round trip: a lane owns PX
     // consecutive columns, the two missing neighbours come from lanes seg-1 / seg+1 of the same
-    // 16-lane row by DPP row shifts (zero-filled at the row ends: columns -1 and 64 do not exist
-    // and would only reach region columns 0 and 63, which are never outputs).  The planes then
+    // 16-lane row by DPP row shifts (zero-filled at the row ends: those columns do not exist
+    // and would only reach the region's border columns, which are never outputs).  The planes then
     // hold row sums, and the vertical step reads two rows instead of nine row segments.
     // Reflect-pad multiplicities only exist next to the image border (rows 1, H-2, cols 1, W-2).
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
@@ -622,9 +647,13 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     };
     auto from_left = [&](f2 v) { return mk2(dpp1(v.x, false), dpp1(v.y, false)); };    // lane seg-1 (0 at seg 0)
     auto from_right = [&](f2 v) { return mk2(dpp1(v.x, true), dpp1(v.y, true)); };     // lane seg+1 (0 at seg 15)
+#ifndef MVF_FB_ROLL4
+#pragma unroll
+#else
 #pragma unroll 1
+#endif
     for (int c = 0; c < 3; ++c) {
-        f2 hs[3][PX];              // row sums of A, B, G at this lane's 4 columns
+        f2 hs[3][PX];              // row sums of A, B, G at this lane's columns
         if (!no_ssim) {
             if (c > 0) __syncthreads();        // vertical reads of the previous channel done
 #pragma unroll
@@ -632,9 +661,8 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 f2 cf[PX + 2];
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    // slot 2 holds the current channel; the slots rotate down below
                     const f2 g = wk[j] * ((0.85f / 3.0f) / 9.0f);
-                    cf[j + 1] = g * (pl == 0 ? pm[2][j] : (pl == 1 ? px2[2][j] : pg[2][j]));
+                    cf[j + 1] = g * (pl == 0 ? pm[c][j] : (pl == 1 ? px2[c][j] : pg[c][j]));
                 }
                 cf[0] = from_left(cf[PX]);
                 cf[PX + 1] = from_right(cf[1]);
@@ -649,11 +677,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
                 for (int j = 0; j < PX; j += 2)
                     cp[j / 2] = make_float4(hs[pl][j].x, hs[pl][j].y, hs[pl][j + 1].x, hs[pl][j + 1].y);
-            }
-#pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                pm[2][j] = pm[1][j]; px2[2][j] = px2[1][j]; pg[2][j] = pg[1][j];
-                pm[1][j] = pm[0][j]; px2[1][j] = px2[0][j]; pg[1][j] = pg[0][j];
             }
             __syncthreads();
         }
@@ -686,8 +709,8 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 f2 uu[PX], dd[PX];
 #pragma unroll
                 for (int j = 0; j < PX; j += 2) {
-                    const float4 u = up[j / 2], d = dn[j / 2];
-                    uu[j] = mk2(u.x, u.y); uu[j + 1] = mk2(u.z, u.w);
+                    const float4 uv = up[j / 2], d = dn[j / 2];
+                    uu[j] = mk2(uv.x, uv.y); uu[j + 1] = mk2(uv.z, uv.w);
                     dd[j] = mk2(d.x, d.y); dd[j + 1] = mk2(d.z, d.w);
                 }
 #pragma unroll
@@ -699,7 +722,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 }
             }
         }
-        // park grad_warped of this channel in its own pair plane (own 4 entries only)
+        // park grad_warped of this channel in its own pair plane (own entries only)
         {
             f2 *gp = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
 #pragma unroll
@@ -709,11 +732,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     __syncthreads();      // every grad_warped is parked
 
     // ---- 7 + 8: bilinear + projection adjoint, smoothness value + gradient, store grad_disp.
-    // Lanes now walk the region linearly (position p = tid + k*256, 64 per row): neighbouring
+    // Lanes now walk the region linearly (position p = tid + k*256, TW per row): neighbouring
     // lanes handle neighbouring pixels, so the bilinear taps of a wave fall into a few cache
-    // lines (with the owner mapping a wave's taps were 4 pixels apart per lane).
+    // lines (with the owner mapping a wave's taps were PX pixels apart per lane).
     load_pose_pair(sh, 0, kb, P2);
-    const float *sa = a.src.p[0] + (size_t)b * 3 * N, *sb = a.src.p[kb] + (size_t)b * 3 * N;
+    float *gd_b = uniform_ptr(u.g_disp + (size_t)b * u.g_stride);
     f2 accP[12];
 #pragma unroll
     for (int q = 0; q < 12; ++q) accP[q] = f2s(0.0f);
@@ -724,12 +747,24 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #ifndef MVF_FB_UNROLL7
 #define MVF_FB_UNROLL7 2
 #endif
+    // (only the OW x OH interior is enumerated: 420 positions = 7 wave passes; walking the whole
+    // 32 x 16 region cost 8, a fifth of its lanes idle on the border ring)
+#ifdef MVF_FB_WALK_REGION
+    constexpr int NPOS7 = TW * TH;
+#else
+    constexpr int NPOS7 = OW * OH;
+#endif
 #pragma unroll MVF_FB_UNROLL7
-    for (int k = 0; k < (TW * TH) / NT; ++k) {
+    for (int k = 0; k < (NPOS7 + NT - 1) / NT; ++k) {
         const int p = (int)threadIdx.x + k * NT;
+#ifdef MVF_FB_WALK_REGION
         const int r = p / TW, cc = p - r * TW;
+#else
+        if ((NPOS7 % NT) && ((int)(threadIdx.x & ~(kWave - 1)) + k * NT >= NPOS7)) break;   // whole wave beyond: wave-uniform
+        const int r = 1 + p / OW, cc = 1 + (p - (p / OW) * OW);
+#endif
         const int yy = cy0 + r, xx = cx0 + cc;
-        const bool outp = (r >= 1) && (r <= OH) && (cc >= 1) && (cc <= OW) && (yy < H) && (xx < W);
+        const bool outp = (p < NPOS7) && (r >= 1) && (r <= OH) && (cc >= 1) && (cc <= OW) && (yy < H) && (xx < W);
         if (!outp) continue;       // yy, xx >= 0 for interior positions
         const int e = (r + 1) * LDW + cc + 1;
         float gdp = 0.0f;
@@ -745,7 +780,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         if (live) {
             // the exact chain again: the taps must be the forward's (a flipped cell would flip the
             // bilinear gradient)
-            const WarpPair w = warp_point_pair(dispP[e], a.invK + b * 16, P2, xx, yy, H, W, a.min_disp,
+            const WarpPair w = warp_point_pair(dispP[e], iK, P2, xx, yy, H, W, a.min_disp,
                                                a.range, a.eps);
             float dxa[3], dya[3], dxb[3], dyb[3];
 #pragma unroll
@@ -791,7 +826,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         }
 #endif
         // smoothness: d/d disp_j of s*smooth(disp/den) = gn_j/den - (per-image constant); the
-        // constant needs the per-image smoothness sum and is applied by mvf_unit_fwdbwd_scale.
+        // constant needs the per-image smoothness sum and is applied by mvf_units_fwdbwd_scale.
         const float *dc = dispP + e;
         const float *t0 = tgtP + e;
         auto wgt = [&](int o) {
@@ -818,139 +853,143 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         }
         if (yy - 1 >= 0) gn -= cys * wgt(-LDW) * sgn(dc[-LDW] - nd);
 #endif
-        a.g_disp[(size_t)b * N + (size_t)yy * W + xx] = gdp + gn * rden;
+        stg_at(gd_b, plane_off4(yy, xx, W), gdp + gn * rden);
     }
 
     // ---- one reduction for all tile partials: grad_P of both sources, photo, smoothness sums
+    const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
+    const size_t tile = (size_t)tid.by * a.tiles_x + tid.bx;
+    const size_t UB = (size_t)a.nunits * a.B;
     {
-        const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
-        const size_t tile = (size_t)tid.by * a.tiles_x + tid.bx;
         float flat[NRED];
 #pragma unroll
         for (int q = 0; q < 12; ++q) { flat[q] = accP[q].x; flat[12 + q] = accP[q].y; }
         flat[24] = fb_photo; flat[25] = fb_sx; flat[26] = fb_sy;
         const float tot = block_sum_many<NT, NRED>(flat, scratch);
         const int t = threadIdx.x;
-        if (t < 12) a.gp_ws[(((size_t)b) * ntiles + tile) * 12 + t] = tot;
-        else if (t < 24) { if (hasb) a.gp_ws[(((size_t)kb * a.B + b) * ntiles + tile) * 12 + t - 12] = tot; }
-        else if (t < NRED) a.part[((size_t)b * ntiles + tile) * NPART + (t - 24)] = tot;
+        // gp_ws [S][U*B][ntiles][12], part [U*B][ntiles][NPART]; folded by k_units_finish
+        if (t < 12) a.gp_ws[(((size_t)ub) * ntiles + tile) * 12 + t] = tot;
+        else if (t < 24) { if (hasb) a.gp_ws[((UB + ub) * ntiles + tile) * 12 + t - 12] = tot; }
+        else if (t < NRED) a.part[((size_t)ub * ntiles + tile) * NPART + (t - 24)] = tot;
     }
 }
 
-// ---- finishing kernel: loss[3], stats[B,4], grad_T -- one launch -------------------------------
-// block b < B*S : grad_T of (source s, image b) = K^T [grad_P ; 0], tile partials folded in fp64
-// block B*S     : loss[0..2] and stats[B][4] = {mean, den, sx_b, sy_b}
-__global__ void __launch_bounds__(256) k_fb_finish(const float *__restrict__ mean_ws,
-                                                   const float *__restrict__ part,
-                                                   const float *__restrict__ gp_ws,
-                                                   const float *__restrict__ K, float *__restrict__ loss,
-                                                   float *__restrict__ stats, float *__restrict__ gT,
-                                                   int B, int S, int H, int W, int ntiles, float smoothness)
+// ---- finishing kernel: ONE launch for all units of a unit launch ------------------------------
+// block (unit, image): folds the image's tile partials (27 values x ntiles; tiles strided over 8
+// slices in fp64, then the slices in order) into grad_T of both sources (= K^T [grad_P ; 0]),
+// stats[b] and the image's loss terms; the block of a unit that finishes LAST (device-scope
+// ticket) folds the images in index order into loss[3].  Every fold reads its inputs in index
+// order whoever performs it: the results do not depend on the arrival order.
+// (Round 2: one launch PER UNIT whose B*S+1 blocks each walked all tiles serially, 10.2 us.
+//  Folding inside the unit kernel by its last-arriving workgroup was built and measured this
+//  round: with release/acquire fences 545 us per unit instead of 102 -- buffer_wbl2 / buffer_inv
+//  act on the whole L2 --, with device-scope sc1 accesses instead of fences 107: every workgroup
+//  then waits for a write-through and a ticket round trip while it holds 40 KB of LDS.)
+__global__ void __launch_bounds__(256) k_units_finish(FbArgs a, int S)
 {
-    __shared__ double sh[4][12];
-    __shared__ double gP[12];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    if ((int)blockIdx.x < B * S) {
-        const int s = blockIdx.x / B, b = blockIdx.x - s * B;
-        const float *w = gp_ws + ((size_t)s * B + b) * ntiles * 12;
-        double acc[12];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) acc[k] = 0.0;
-        for (int t = threadIdx.x; t < ntiles; t += 256)
-#pragma unroll
-            for (int k = 0; k < 12; ++k) acc[k] += (double)w[(size_t)t * 12 + k];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            double v = acc[k];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-            if (lane == 0) sh[wid][k] = v;
-        }
-        __syncthreads();
-        if (threadIdx.x < 12) gP[threadIdx.x] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) +
-                                                 (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
-        __syncthreads();
-        if (threadIdx.x < 16) {
-            const int k = threadIdx.x >> 2, j = threadIdx.x & 3;
-            const float *Kb = K + b * 16;
-            double v = 0.0;
-            for (int q = 0; q < 3; ++q) v += (double)Kb[q * 4 + k] * gP[q * 4 + j];
-            gT[((size_t)s * B + b) * 16 + threadIdx.x] = (float)v;
-        }
-        return;
+    __shared__ double red[8 * 32];
+    __shared__ int s_last;
+    const int ub = blockIdx.x, unit = ub / a.B, b = ub - unit * a.B;
+    const UnitArgs &u = a.u[unit];
+    const int H = a.H, W = a.W;
+    const size_t N = (size_t)H * W;
+    const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
+    const size_t UB = (size_t)a.nunits * a.B;
+    const int q = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    double acc = 0.0;
+    if (q < NRED) {
+        const float *srcp;
+        size_t stride;
+        if (q < 12) { srcp = a.gp_ws + ((size_t)ub * ntiles) * 12 + q; stride = 12; }
+        else if (q < 24) { srcp = a.gp_ws + ((UB + ub) * ntiles) * 12 + (q - 12); stride = 12; }
+        else { srcp = a.part + ((size_t)ub * ntiles) * NPART + (q - 24); stride = NPART; }
+        if (q < 12 || q >= 24 || S > 1)
+            for (size_t t = slice; t < ntiles; t += 8) acc += (double)srcp[t * stride];
     }
-    // loss / stats block: one wave per image, 4 images per pass, images folded in index order
-    __shared__ double shp[4], shs[4];
-    __shared__ double acc_photo, acc_smooth;
-    const double N = (double)H * W;
-    if (threadIdx.x == 0) { acc_photo = 0.0; acc_smooth = 0.0; }
+    red[slice * 32 + q] = acc;
     __syncthreads();
-    for (int b0 = 0; b0 < B; b0 += 4) {
-        const int b = b0 + wid;
-        if (b < B) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-            for (int t = lane; t < ntiles; t += 64) {
-                const float *q = part + ((size_t)b * ntiles + t) * NPART;
-                a0 += (double)q[0]; a1 += (double)q[1]; a2 += (double)q[2];
-            }
-            for (int off = 32; off > 0; off >>= 1) {
-                a0 += __shfl_down(a0, off, 64);
-                a1 += __shfl_down(a1, off, 64);
-                a2 += __shfl_down(a2, off, 64);
-            }
-            if (lane == 0) {
-                const double sxb = a1 / ((double)B * H * (W - 1)), syb = a2 / ((double)B * (H - 1) * W);
-                shp[wid] = a0;
-                shs[wid] = sxb + syb;
-                float m = 0.0f;
-                for (int i = 0; i < NMEAN; ++i) m += mean_ws[b * NMEAN + i];
-                const float mean = m / (float)N;
-                stats[b * 4 + 0] = mean;
-                stats[b * 4 + 1] = mean + 1e-7f;
-                stats[b * 4 + 2] = (float)sxb;
-                stats[b * 4 + 3] = (float)syb;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (int i = 0; i < 4 && b0 + i < B; ++i) { acc_photo += shp[i]; acc_smooth += shs[i]; }
-        __syncthreads();
+    if (threadIdx.x < 32) {
+        double v = 0.0;
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) v += red[sl * 32 + q];
+        red[q] = v;          // slice 0's row now holds the totals (each lane wrote only its own q)
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * S) {
+        const int s = threadIdx.x >> 4, e16 = threadIdx.x & 15, kk = e16 >> 2, j = e16 & 3;
+        const float *Kb = u.K + b * 16;
+        double v = 0.0;
+        for (int qq = 0; qq < 3; ++qq) v += (double)Kb[qq * 4 + kk] * red[s * 12 + qq * 4 + j];
+        u.g_T[((size_t)s * a.B + b) * 16 + e16] = (float)v;
     }
     if (threadIdx.x == 0) {
-        const double pm = acc_photo / ((double)B * N);
-        loss[0] = (float)(pm + (double)smoothness * acc_smooth);
-        loss[1] = (float)pm;
-        loss[2] = (float)acc_smooth;
+        const double sxb = red[25] / ((double)a.B * H * (W - 1)), syb = red[26] / ((double)a.B * (H - 1) * W);
+        float m = 0.0f;
+        for (int i = 0; i < NMEAN; ++i) m += u.mean_ws[b * NMEAN + i];
+        const float mean = m / (float)N;
+        u.stats[b * 4 + 0] = mean;
+        u.stats[b * 4 + 1] = mean + 1e-7f;
+        u.stats[b * 4 + 2] = (float)sxb;
+        u.stats[b * 4 + 3] = (float)syb;
+        double *iw = a.img_ws + (size_t)ub * NIMG;
+        iw[0] = red[24];
+        iw[1] = sxb + syb;
+        __threadfence();                       // the image's terms are visible before its ticket
+        s_last = (atomicAdd(a.tickets + unit, 1) == a.B - 1);
+        if (s_last) {
+            __threadfence();
+            double photo = 0.0, smooth = 0.0;
+            for (int i = 0; i < a.B; ++i) {
+                const double *jw = a.img_ws + ((size_t)unit * a.B + i) * NIMG;
+                photo += __builtin_nontemporal_load(jw);
+                smooth += __builtin_nontemporal_load(jw + 1);
+            }
+            const double pmn = photo / ((double)a.B * (double)N);
+            u.loss[0] = (float)(pmn + (double)a.smoothness * smooth);
+            u.loss[1] = (float)pmn;
+            u.loss[2] = (float)smooth;
+            a.tickets[unit] = 0;               // leave the counter as it was found
+        }
     }
 }
 
 // backward(): out = (raw - shift_b) * g_loss for grad_disp, g_T_raw * g_loss for grad_T.
 // shift_b = (smoothness * smooth_b / N) / den_b is the mean-normalisation term of the smoothness
 // gradient; (x - s) * g in this order reproduces the bits of the two-kernel path for g = 1.
-__global__ void __launch_bounds__(256) k_fb_scale(const float *__restrict__ g_raw,
-                                                  const float *__restrict__ gT_raw,
-                                                  const float *__restrict__ stats,
-                                                  const float *__restrict__ g_loss, float smoothness,
-                                                  float *__restrict__ g_disp, float *__restrict__ gT,
-                                                  int N4, int N, int nT)
+struct ScaleUnit {
+    const float *g_raw, *gT_raw, *stats, *g_loss;
+    float *g_disp, *gT;
+    size_t in_stride, out_stride;
+};
+struct ScaleArgs {
+    ScaleUnit u[MVF_MAX_UNITS];
+    float smoothness;
+    int N4, N, nT;
+};
+__global__ void __launch_bounds__(256) k_fb_scale(ScaleArgs a)
 {
-    const float g = g_loss[0];
+    const ScaleUnit &u = a.u[blockIdx.z];
+    const float g = u.g_loss[0];
     if (blockIdx.y == gridDim.y - 1) {            // the extra row of blocks scales grad_T
         const int i = blockIdx.x * 256 + threadIdx.x;
-        if (i < nT) gT[i] = gT_raw[i] * g;
+        if (i < a.nT) u.gT[i] = u.gT_raw[i] * g;
         return;
     }
     const int b = blockIdx.y;
-    const float den = stats[b * 4 + 1];
-    const float smooth_b = stats[b * 4 + 2] + stats[b * 4 + 3];
-    const float shift = (smoothness * smooth_b / (float)N) / den;
+    const int N = a.N, N4 = a.N4;
+    const float den = u.stats[b * 4 + 1];
+    const float smooth_b = u.stats[b * 4 + 2] + u.stats[b * 4 + 3];
+    const float shift = (a.smoothness * smooth_b / (float)N) / den;
+    const float *in = u.g_raw + (size_t)b * u.in_stride;
+    float *out = u.g_disp + (size_t)b * u.out_stride;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < N4) {
-        const float4 v = reinterpret_cast<const float4 *>(g_raw + (size_t)b * N)[i];
-        reinterpret_cast<float4 *>(g_disp + (size_t)b * N)[i] =
+        const float4 v = reinterpret_cast<const float4 *>(in)[i];
+        reinterpret_cast<float4 *>(out)[i] =
             make_float4((v.x - shift) * g, (v.y - shift) * g, (v.z - shift) * g, (v.w - shift) * g);
     } else {
         for (int k = 4 * i; k < N && k < 4 * i + 4; ++k)
-            if (k >= 4 * N4) g_disp[(size_t)b * N + k] = (g_raw[(size_t)b * N + k] - shift) * g;
+            if (k >= 4 * N4) out[k] = (in[k] - shift) * g;
     }
 }
 
@@ -958,11 +997,134 @@ __global__ void __launch_bounds__(256) k_fb_scale(const float *__restrict__ g_ra
 
 // per-image mean partials of the disparity (mvf_photo.hip)
 namespace mvf_photo {
-void launch_disp_mean(const float *disp, float *ws, int B, int N, hipStream_t st);
+void launch_disp_mean(const float *disp, size_t image_stride, float *ws, int B, int N, hipStream_t st);
 }
+
+namespace {
+// floats of workspace: mean partials | loss partials | grad_P partials | per-image folds (doubles)
+struct WsLayout {
+    size_t mean, part, gp, img, total;
+};
+WsLayout ws_layout(int U, int B, int H, int W)
+{
+    const size_t tiles = (size_t)((W + OW - 1) / OW) * ((H + OH - 1) / OH);
+    WsLayout l;
+    l.mean = 0;
+    l.part = l.mean + (size_t)U * B * NMEAN;
+    l.gp = l.part + (size_t)U * B * tiles * NPART;
+    l.img = l.gp + (size_t)2 * U * B * tiles * 12;
+    l.img = (l.img + 1) & ~(size_t)1;                   // doubles: 8-byte aligned
+    l.total = l.img + (size_t)U * B * NIMG * 2;
+    return l;
+}
+}  // namespace
 
 extern "C" {
 
+size_t mvf_units_workspace_floats(int n_units, int B, int H, int W)
+{
+    return ws_layout(n_units, B, H, W).total + 2;
+}
+
+size_t mvf_units_ticket_ints(int n_units, int B) { (void)B; return (size_t)n_units; }
+
+int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, float smoothness,
+                     float min_disp, float range, float eps, float *workspace, int32_t *tickets, int B,
+                     int H, int W, void *stream)
+{
+    if (n_units < 1 || n_units > MVF_MAX_UNITS || !units) return (int)hipErrorInvalidValue;
+    if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
+    if (!workspace || !tickets) return (int)hipErrorInvalidValue;
+    if (B * H * W <= 0) return 0;
+    if ((double)H * W * 3.0 * 4.0 >= 4294967296.0 || H >= (1 << 22) || W >= (1 << 22))
+        return (int)hipErrorInvalidValue;                        // 32-bit byte offsets inside an image
+    if ((((uintptr_t)workspace) & 7) != 0) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const int N = H * W;
+    const bool automask = !(flags & MVF_NO_AUTOMASK);
+    FbArgs a = {};
+    a.nunits = n_units; a.flags = flags; a.B = B; a.H = H; a.W = W;
+    a.tiles_x = (W + OW - 1) / OW; a.tiles_y = (H + OH - 1) / OH;
+    a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
+    const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
+    const WsLayout l = ws_layout(n_units, B, H, W);
+    a.part = workspace + l.part;
+    a.gp_ws = workspace + l.gp;
+    a.img_ws = reinterpret_cast<double *>(workspace + l.img);
+    a.tickets = tickets;
+    for (int i = 0; i < n_units; ++i) {
+        const mvf_unit_desc &d = units[i];
+        if (!d.disp || !d.tgt || !d.src[0] || (S > 1 && !d.src[1]) || !d.T || !d.K || !d.inv_K ||
+            !d.g_disp_raw || !d.g_T_raw || !d.loss || !d.stats)
+            return (int)hipErrorInvalidValue;
+        UnitArgs &u = a.u[i];
+        u.disp = d.disp; u.tgt = d.tgt; u.src0 = d.src[0]; u.src1 = S > 1 ? d.src[1] : d.src[0];
+        u.mask = d.mask_rec; u.T = d.T; u.K = d.K; u.invK = d.inv_K; u.noise = d.noise;
+        u.ident_in = automask ? d.ident_in : nullptr; u.ident_out = automask ? d.ident_out : nullptr;
+        u.disp_stride = d.disp_stride ? (size_t)d.disp_stride : (size_t)N;
+        u.tgt_stride = d.tgt_stride ? (size_t)d.tgt_stride : (size_t)3 * N;
+        u.src0_stride = d.src_stride[0] ? (size_t)d.src_stride[0] : (size_t)3 * N;
+        u.src1_stride = S > 1 ? (d.src_stride[1] ? (size_t)d.src_stride[1] : (size_t)3 * N) : u.src0_stride;
+        u.mask_stride = d.mask_stride ? (size_t)d.mask_stride : (size_t)N;
+        u.g_stride = d.g_stride ? (size_t)d.g_stride : (size_t)N;
+        u.g_disp = d.g_disp_raw; u.g_T = d.g_T_raw; u.loss = d.loss; u.stats = d.stats;
+        u.argmin_out = d.argmin; u.auto_mask_out = d.auto_mask; u.to_opt_out = d.to_opt;
+        u.noise_out = d.noise_out; u.idx_xy = d.idx_xy;
+        u.seed0 = (uint32_t)d.noise_seed; u.seed1 = (uint32_t)(d.noise_seed >> 32);
+        if (d.disp_mean_partials) u.mean_ws = d.disp_mean_partials;
+        else {
+            float *mw = workspace + l.mean + (size_t)i * B * NMEAN;
+            u.mean_ws = mw;
+            mvf_photo::launch_disp_mean(d.disp, u.disp_stride, mw, B, N, st);
+        }
+    }
+    {
+        ProfScope ps(MVF_PROF_UNIT_FWDBWD, st, (int64_t)n_units * B * N);
+        const dim3 grid((unsigned)(ntiles * B * n_units));
+        const bool avg = flags & MVF_AVG_REPROJ;
+        if (S == 1 && !avg) hipLaunchKernelGGL((k_unit_fb<1, false>), grid, dim3(NT), fb_smem(), st, a);
+        else if (S == 1) hipLaunchKernelGGL((k_unit_fb<1, true>), grid, dim3(NT), fb_smem(), st, a);
+        else if (!avg) hipLaunchKernelGGL((k_unit_fb<2, false>), grid, dim3(NT), fb_smem(), st, a);
+        else hipLaunchKernelGGL((k_unit_fb<2, true>), grid, dim3(NT), fb_smem(), st, a);
+    }
+    hipLaunchKernelGGL(k_units_finish, dim3((unsigned)(n_units * B)), dim3(256), 0, st, a, S);
+    return hip_check_launch();
+}
+
+int mvf_units_fwdbwd_scale(const mvf_unit_scale_desc *units, int n_units, float smoothness, int B, int S,
+                           int H, int W, void *stream)
+{
+    if (n_units < 1 || n_units > MVF_MAX_UNITS || !units) return (int)hipErrorInvalidValue;
+    if (B * H * W <= 0) return 0;
+    const int N = H * W;
+    ScaleArgs a = {};
+    bool vec = (N % 4 == 0);
+    for (int i = 0; i < n_units; ++i) {
+        const mvf_unit_scale_desc &d = units[i];
+        if (!d.g_disp_raw || !d.g_T_raw || !d.stats || !d.g_loss || !d.g_disp || !d.g_T)
+            return (int)hipErrorInvalidValue;
+        ScaleUnit &u = a.u[i];
+        u.g_raw = d.g_disp_raw; u.gT_raw = d.g_T_raw; u.stats = d.stats; u.g_loss = d.g_loss;
+        u.g_disp = d.g_disp; u.gT = d.g_T;
+        u.in_stride = d.in_stride ? (size_t)d.in_stride : (size_t)N;
+        u.out_stride = d.out_stride ? (size_t)d.out_stride : (size_t)N;
+        // float4 path needs 16-B aligned image rows: N % 4 == 0, aligned bases and strides
+        vec = vec && ((((uintptr_t)d.g_disp_raw) | ((uintptr_t)d.g_disp)) % 16 == 0) &&
+              (u.in_stride % 4 == 0) && (u.out_stride % 4 == 0);
+    }
+    a.smoothness = smoothness;
+    a.N = N;
+    a.N4 = vec ? N / 4 : 0;
+    a.nT = S * B * 16;
+    const int per = vec ? a.N4 : (N + 3) / 4;
+    const unsigned gx = (unsigned)((max(per, a.nT) + 255) / 256);
+    hipLaunchKernelGGL(k_fb_scale, dim3(gx, (unsigned)B + 1, (unsigned)n_units), dim3(256), 0,
+                       (hipStream_t)stream, a);
+    return hip_check_launch();
+}
+
+// one unit, contiguous tensors (the round-2 entry point; kept for C callers -- INTEGRATION.md).
+// The ticket counters live at the end of the workspace and are zeroed here (one memset node).
 int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src, const float *T,
                     const float *K, const float *inv_K, const float *noise, const float *mask_rec,
                     int S, int flags, float smoothness, float min_disp, float range, float eps,
@@ -970,40 +1132,23 @@ int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *const *src
                     int32_t *idx_xy, float *g_disp, float *g_T, float *workspace, int B, int H, int W,
                     uint64_t noise_seed, float *noise_out, const float *disp_mean_partials, void *stream)
 {
-    if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
+    if (S < 1 || S > 2) return (int)hipErrorInvalidValue;
     if (!g_disp || !g_T || !loss || !stats || !workspace) return (int)hipErrorInvalidValue;
     if (B * H * W <= 0) return 0;
-    hipStream_t st = (hipStream_t)stream;
-    const int N = H * W;
-    FbArgs a = {};
-    a.disp = disp; a.tgt = tgt; a.mask = mask_rec; a.T = T; a.K = K; a.invK = inv_K;
-    for (int k = 0; k < S; ++k) a.src.p[k] = src[k];
-    a.flags = flags; a.B = B; a.H = H; a.W = W;
-    a.tiles_x = (W + OW - 1) / OW; a.tiles_y = (H + OH - 1) / OH;
-    a.smoothness = smoothness; a.min_disp = min_disp; a.range = range; a.eps = eps;
-    const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
-    // workspace: [B*NMEAN] mean partials | [B*ntiles*NPART] loss partials | [S*B*ntiles*12] grad_P
-    a.mean_ws = disp_mean_partials ? disp_mean_partials : workspace;
-    a.part = workspace + (size_t)B * NMEAN;
-    a.gp_ws = a.part + (size_t)B * ntiles * NPART;
-    a.noise = noise; a.argmin_out = argmin; a.auto_mask_out = auto_mask; a.to_opt_out = to_opt;
-    a.noise_out = noise_out;
-    a.seed0 = (uint32_t)noise_seed; a.seed1 = (uint32_t)(noise_seed >> 32);
-    a.idx_xy = idx_xy;
-    a.g_disp = g_disp;
-    if (!disp_mean_partials) mvf_photo::launch_disp_mean(disp, workspace, B, N, st);
-    {
-        ProfScope ps(MVF_PROF_UNIT_FWDBWD, st);
-        const dim3 grid((unsigned)(ntiles * B));
-        const bool avg = flags & MVF_AVG_REPROJ;
-        if (S == 1 && !avg) hipLaunchKernelGGL((k_unit_fb<1, false>), grid, dim3(NT), fb_smem(), st, a);
-        else if (S == 1) hipLaunchKernelGGL((k_unit_fb<1, true>), grid, dim3(NT), fb_smem(), st, a);
-        else if (!avg) hipLaunchKernelGGL((k_unit_fb<2, false>), grid, dim3(NT), fb_smem(), st, a);
-        else hipLaunchKernelGGL((k_unit_fb<2, true>), grid, dim3(NT), fb_smem(), st, a);
-    }
-    hipLaunchKernelGGL(k_fb_finish, dim3((unsigned)(B * S + 1)), dim3(256), 0, st, a.mean_ws, a.part,
-                       a.gp_ws, K, loss, stats, g_T, B, S, H, W, (int)ntiles, smoothness);
-    return hip_check_launch();
+    mvf_unit_desc d = {};
+    d.disp = disp; d.tgt = tgt; d.src[0] = src[0]; d.src[1] = S > 1 ? src[1] : nullptr;
+    d.T = T; d.K = K; d.inv_K = inv_K; d.mask_rec = mask_rec; d.noise = noise;
+    d.disp_mean_partials = disp_mean_partials; d.noise_seed = noise_seed;
+    d.loss = loss; d.stats = stats; d.g_disp_raw = g_disp; d.g_T_raw = g_T;
+    d.argmin = argmin; d.auto_mask = auto_mask; d.to_opt = to_opt; d.idx_xy = idx_xy; d.noise_out = noise_out;
+    // workspace = mvf_workspace_floats(B,H,W) floats (mvf_geom.hip), larger than one unit needs:
+    // the tickets go behind the unit workspace
+    const size_t wsf = (mvf_units_workspace_floats(1, B, H, W) + 1) & ~(size_t)1;
+    int32_t *tickets = reinterpret_cast<int32_t *>(workspace + wsf);
+    hipError_t e = hipMemsetAsync(tickets, 0, mvf_units_ticket_ints(1, B) * sizeof(int32_t), (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    return mvf_units_fwdbwd(&d, 1, S, flags, smoothness, min_disp, range, eps, workspace, tickets, B, H, W,
+                            stream);
 }
 
 int mvf_unit_fwdbwd_scale(const float *g_disp_raw, const float *g_T_raw, const float *stats,
@@ -1011,17 +1156,10 @@ int mvf_unit_fwdbwd_scale(const float *g_disp_raw, const float *g_T_raw, const f
                           int S, int H, int W, void *stream)
 {
     if (B * H * W <= 0) return 0;
-    if (!g_disp_raw || !g_T_raw || !stats || !g_loss || !g_disp || !g_T) return (int)hipErrorInvalidValue;
-    const int N = H * W;
-    // float4 path needs 16-B aligned image rows: N % 4 == 0 and aligned bases, else scalar
-    const bool vec = (N % 4 == 0) && ((((uintptr_t)g_disp_raw) | ((uintptr_t)g_disp)) % 16 == 0);
-    const int N4 = vec ? N / 4 : 0;
-    const int per = vec ? N4 : (N + 3) / 4;
-    const int nT = S * B * 16;
-    const unsigned gx = (unsigned)((max(per, nT) + 255) / 256);
-    hipLaunchKernelGGL(k_fb_scale, dim3(gx, (unsigned)B + 1), dim3(256), 0, (hipStream_t)stream,
-                       g_disp_raw, g_T_raw, stats, g_loss, smoothness, g_disp, g_T, N4, N, nT);
-    return hip_check_launch();
+    mvf_unit_scale_desc d = {};
+    d.g_disp_raw = g_disp_raw; d.g_T_raw = g_T_raw; d.stats = stats; d.g_loss = g_loss;
+    d.g_disp = g_disp; d.g_T = g_T;
+    return mvf_units_fwdbwd_scale(&d, 1, smoothness, B, S, H, W, stream);
 }
 
 }  // extern "C"

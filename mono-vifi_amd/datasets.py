@@ -25,6 +25,14 @@ class SyntheticTripletDataset(Dataset):
         self.height, self.width, self.length = height, width, length
         self.use_affine, self.seed = use_affine, seed
         self.device_augment = bool(device_augment)
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        """The reference redraws flip / ColorJitter parameters on every access
+        (datasets/mono_dataset.py:214-256); here the draw is a function of (seed, epoch, index), so
+        an item is augmented differently in every epoch and identically on resume.  Called by
+        `Trainer.run_epoch` before the loader's workers are created."""
+        self.epoch = int(epoch)
 
     def __len__(self):
         return self.length
@@ -34,7 +42,7 @@ class SyntheticTripletDataset(Dataset):
         item = {}
         if self.device_augment:
             from . import augment
-            draw = augment.draw_params(np.random.default_rng(self.seed * 7919 + index), 1)
+            draw = augment.draw_params(np.random.default_rng([self.seed, self.epoch, index]), 1)
             b = {k: v for k, v in b.items()
                  if not (isinstance(k, tuple) and k[0] in ("color_aug", "color_affine", "color_affine_aug"))}
             b.update(draw)

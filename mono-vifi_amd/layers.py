@@ -142,7 +142,8 @@ def upsample(x, scale_factor=2, mode="nearest"):
     """reference: layers.py:225-228.  On the HIP device (fp32) bilinear (Lite-Mono decoder) and
     integer-factor nearest (DHRNet decoder) run as element-parallel kernels with gather adjoints:
     ATen's NCHW kernels take one thread per output POSITION and loop over batch x channels."""
-    if FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled():
+    if (FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and not torch.is_autocast_enabled()):
         if mode == "bilinear":
             return ops.resize_bilinear(x, scale_factor=scale_factor, align_corners=False)
         if mode == "nearest" and int(scale_factor) == scale_factor and scale_factor >= 1:
@@ -180,7 +181,10 @@ def conv_bias_act(conv, x, act="none", act_module=None, res=None):
     slope = act_module.weight if act == "prelu" else None
     need_grad = torch.is_grad_enabled() and (x.requires_grad or conv.weight.requires_grad or
                                              (slope is not None and slope.requires_grad))
+    # (NCHW-contiguous inputs only: under --channels_last the convolution's output is channels-last
+    # and the epilogue kernel would first make an NCHW copy of it -- the stock ops are faster there)
     fused = (FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and conv.bias is not None and
+             x.is_contiguous() and
              conv.weight.dtype == torch.float32 and not torch.is_autocast_enabled() and
              getattr(conv, "padding_mode", "zeros") == "zeros" and not (act == "prelu" and need_grad))
     if fused:

@@ -73,7 +73,7 @@ class HotPathLosses:
             *imgs_src_tgt, *srcs)
         return loss, (None if o.disable_automasking else auto_mask)
 
-    # ------------------------------------------------------------------ fused unit
+    # ------------------------------------------------------------------ fused units
     def compute_unit(self, disp_tgt, img_tgt, poses, imgs_src, K, inv_K, mask_rec=None,
                      want_auto_mask=False):
         """``len(poses)`` x generate_images_pred + compute_losses_base in one fused
@@ -93,3 +93,45 @@ class HotPathLosses:
         loss, auto_mask, _, _, _ = ops.Unit.apply(disp, img_tgt, T, K, inv_K, mask_rec, noise, cfg,
                                                   *imgs_src)
         return loss, (auto_mask if want_auto_mask and not o.disable_automasking else None)
+
+    def compute_units(self, units, want_ident=False, want_auto_mask=False):
+        """Several mutually independent units of one shape as ONE launch (reference: the three
+        calls of each group in process_batch, train.py:747-760 / 795-810 / 837-882).
+
+        ``units``: list of dicts with keys disp_tgt, img_tgt, poses, imgs_src, K, inv_K and
+        optionally mask_rec, ident (the identity maps another unit with the same target and
+        sources returned).  Returns (losses [n], idents list | None, auto_masks list | None).
+        Falls back to one `compute_unit` per entry when the forward+backward kernel cannot take
+        them (S > 2, no gradient wanted, an injected noise tensor...)."""
+        o = self.opt
+        n = len(units)
+        prepared = []
+        for un in units:
+            disp = un["disp_tgt"][("disp", 0)]
+            poses = un["poses"]
+            T = poses if torch.is_tensor(poses) else torch.stack(list(poses), 0)
+            prepared.append((disp, T))
+        S = prepared[0][1].shape[0]
+        batched = (n <= ops.nat.MAX_UNITS and getattr(o, "batch_units", True) and
+                   all(ops.unit_uses_fwdbwd(S, d, T) and T.shape[0] == S and d.shape == prepared[0][0].shape
+                       for d, T in prepared))
+        if not batched:
+            out = [self.compute_unit(un["disp_tgt"], un["img_tgt"], un["poses"], un["imgs_src"], un["K"],
+                                     un["inv_K"], un.get("mask_rec"), want_auto_mask) for un in units]
+            return torch.stack([l for l, _ in out]), None, ([m for _, m in out] if want_auto_mask else None)
+        in_kernel = getattr(o, "inkernel_noise", True) and getattr(self, "tie_break_noise", None) is None
+        flat, mean_parts = [], []
+        for un, (disp, T) in zip(units, prepared):
+            noise = None if in_kernel else self._tie_break_noise(disp, S)
+            flat += [disp, un["img_tgt"], T, un["K"], un["inv_K"], un.get("mask_rec"), noise,
+                     un.get("ident"), *un["imgs_src"]]
+            mean_parts.append(un["disp_tgt"].get(("disp_mean_partials", 0)))
+        cfg = dict(n=n, S=S, flags=self._loss_flags(), smoothness=float(o.disparity_smoothness),
+                   min_depth=o.min_depth, max_depth=o.max_depth, eps=1e-7,
+                   want_mask=bool(want_auto_mask), want_idx=False, want_ident=bool(want_ident),
+                   mean_parts=mean_parts if any(m is not None for m in mean_parts) else None)
+        res = ops.Units.apply(cfg, *flat)
+        losses, per = res[0], res[2:]
+        idents = [per[4 * u + 3] for u in range(n)] if want_ident and not o.disable_automasking else None
+        masks = [per[4 * u + 0] for u in range(n)] if want_auto_mask and not o.disable_automasking else None
+        return losses, idents, masks

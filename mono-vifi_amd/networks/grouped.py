@@ -27,6 +27,11 @@ import torch.nn as nn
 from ..consts import const_tensor
 
 
+def _count(kind):
+    from ..parallel import count_collective
+    count_collective(kind)
+
+
 def merge_groups(tensors):
     """G tensors [B, ...] -> [B*G, ...] interleaved (sample n = b*G + g)."""
     return torch.stack(list(tensors), 1).flatten(0, 1)
@@ -94,6 +99,7 @@ class _AllReduceSyncBN(torch.autograd.Function):
         xd = x.double()              # E[x^2] - mean^2 cancels: accumulate the moments in fp64
         stats = torch.cat([xd.sum(red), (xd * xd).sum(red), xd.new_full((1,), float(n_local))])
         dist.all_reduce(stats, group=group)
+        _count("bn_all_reduce_fwd")
         n = stats[-1]
         mean = stats[:C] / n
         var = (stats[C:2 * C] / n - mean * mean).clamp_min(0.0)
@@ -115,6 +121,7 @@ class _AllReduceSyncBN(torch.autograd.Function):
         s_gy, s_gyx = gy.sum(red), (gy * xhat).sum(red)
         both = torch.cat([s_gy, s_gyx])
         dist.all_reduce(both, group=ctx.group)
+        _count("bn_all_reduce")
         m_gy, m_gyx = both[:C] / n, both[C:] / n
         gx = (gy - m_gy.view(shape) - xhat * m_gyx.view(shape)) * (weight * invstd).view(shape)
         return gx, s_gyx, s_gy, None, None
@@ -144,6 +151,7 @@ class _FusedSyncBN(torch.autograd.Function):
             flat = torch.empty(world * combined.numel(), dtype=combined.dtype, device=combined.device)
             dist.all_gather_into_tensor(flat, combined, group)
             allc = flat.view(world, combined.numel())
+        _count("bn_all_gather")
         mean_all, invstd_all, count_all = torch.split(allc, C, dim=1)
         counts = count_all.reshape(-1)
         mean, invstd = torch.batch_norm_gather_stats_with_counts(
@@ -165,6 +173,7 @@ class _FusedSyncBN(torch.autograd.Function):
             C = sum_dy.shape[0]
             both = torch.cat([sum_dy, sum_dy_xmu])
             dist.all_reduce(both, op=dist.ReduceOp.SUM, group=ctx.group)
+            _count("bn_all_reduce")
             sum_dy, sum_dy_xmu = torch.split(both, C)
             gx = torch.batch_norm_backward_elemt(gy, x, mean, invstd, weight, sum_dy, sum_dy_xmu, counts)
         return gx, gw, gb, None, None, None, None, None, None, None

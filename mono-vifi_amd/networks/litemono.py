@@ -34,6 +34,10 @@ class _TokenLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         gx = gw = gb = None
+        if g.dtype != weight.dtype:          # mixed precision around the call: compute in the weight's type
+            g = g.to(weight.dtype)
+        if x.dtype != weight.dtype:
+            x = x.to(weight.dtype)
         if ctx.needs_input_grad[0]:
             gx = g @ weight
         B = x.shape[0]
@@ -51,7 +55,10 @@ SPLIT_TOKEN_GRAD = True      # False: stock nn.Linear backward (tests compare bo
 def token_linear(lin, x):
     """``lin(x)`` for an ``nn.Linear`` over [B, tokens..., C]; on the device with many tokens per
     image the weight gradient takes the per-image batched form."""
+    # (not under autocast: backward() runs outside the autocast context, where a bf16 gradient
+    # would meet the fp32 weight / activation in `g @ weight` and the batched GEMM)
     if (SPLIT_TOKEN_GRAD and x.is_cuda and x.dim() >= 3 and x.shape[0] > 1 and torch.is_grad_enabled()
+            and not torch.is_autocast_enabled() and x.dtype == lin.weight.dtype
             and lin.weight.requires_grad and x[0].numel() // x.shape[-1] >= 1024):
         return _TokenLinear.apply(x, lin.weight, lin.bias)
     return lin(x)

@@ -21,7 +21,8 @@ def _add_relu(out, idt):
     pass (ops.bias_act with a residual, in place on the batch-norm output) instead of add + clamp."""
     from .. import layers
     if (RESIDUAL_EPILOGUE and layers.FUSED_EPILOGUE and out.is_cuda and out.dtype == torch.float32 and idt.dtype == torch.float32
-            and out.shape == idt.shape and not torch.is_autocast_enabled()):
+            and out.shape == idt.shape and not torch.is_autocast_enabled()
+            and out.is_contiguous() and idt.is_contiguous()):      # (channels_last: the stock ops, no NCHW copy)
         from .. import ops
         return ops.bias_act(out, None, "relu", res=idt, inplace=True)
     return F.relu(out + idt)
@@ -120,7 +121,7 @@ def _stem_pool(trunk, f0):
     (ops.maxpool3s2) instead of ATen's int64-index kernels."""
     mp = trunk.maxpool
     if (STEM_POOL_KERNEL and f0.is_cuda and f0.dtype == torch.float32 and not torch.is_autocast_enabled()
-            and isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode)
+            and f0.is_contiguous() and isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode)
             == (3, 2, 1, 1, False)):
         from .. import ops
         return ops.maxpool3s2(f0)

@@ -365,9 +365,10 @@ class LossesBase(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------ fused unit
-# When a gradient will be asked for (training), a unit with one source pair runs its forward
-# and backward as ONE tile kernel (mvf_unit_fwdbwd): the gradients for an upstream gradient of
-# 1 are produced alongside the loss and only scaled in backward().  Set to False to force the
+# When a gradient will be asked for (training), units with one source pair run their forward
+# and backward as ONE tile kernel (mvf_units_fwdbwd): the gradients for an upstream gradient of
+# 1 are produced alongside the loss and only scaled in backward().  Several mutually independent
+# units of the same shape go out as one launch (`Units`).  Set UNIT_FWDBWD to False to force the
 # separate forward / backward kernels (the tests compare both).
 UNIT_FWDBWD = True
 
@@ -378,20 +379,198 @@ def unit_uses_fwdbwd(S, disp, T):
                 (disp.requires_grad or T.requires_grad))
 
 
-class Unit(torch.autograd.Function):
+def _img(t):
+    """fp32 [B,C,H,W] whose images are contiguous planes -> (tensor, image stride in floats).
+    A view that strides over the batch only (one group of a grouped network call's interleaved
+    output) is passed as it lies; anything else is made contiguous."""
+    if t is None:
+        return None, 0
+    if t.dtype != torch.float32:
+        t = t.float()
+    B, Cc, H, W = t.shape
+    st = t.stride()
+    inner_ok = st[3] == 1 and st[2] == W and (Cc == 1 or st[1] == H * W)
+    if not inner_ok or (B > 1 and st[0] < Cc * H * W) or t.data_ptr() % 4:
+        t = t.contiguous()
+        st = t.stride()
+    return t, (int(st[0]) if B > 1 else Cc * H * W)
+
+
+_TICKETS = {}
+
+
+def _tickets(dev, n):
+    """Zeroed int32 counters for the in-kernel finishing folds: one persistent buffer per
+    (device, stream) -- launches on a stream are ordered and each leaves the counters zero."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None or t.numel() < n:
+        t = torch.zeros(max(n, 1024), dtype=torch.int32, device=dev)
+        _TICKETS[key] = t
+    return t
+
+
+UNIT_FIELDS = 8      # tensors per unit in Units.apply before its sources
+
+
+class Units(torch.autograd.Function):
+    """n mutually independent hot-path units of one shape in ONE launch (reference: the three
+    single-frame units train.py:747-760, the three multi-frame ones 795-810, the three affine
+    ones 837-882), each = S x generate_images_pred + compute_losses_base with the warped images
+    kept in LDS (train.py:956-1051).
+
+    apply(cfg, disp_0, tgt_0, T_0, K_0, inv_K_0, mask_0, noise_0, ident_in_0, *src_0 (S), disp_1, ...)
+    cfg = dict(n, S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx,
+               want_ident, noise_out (list|None), mean_parts (list|None))
+    returns (losses [n], terms [n,2] (photo, smooth), then per unit: auto_mask, argmin, idx,
+             ident) -- absent outputs are empty tensors."""
+
+    @staticmethod
+    def forward(ctx, cfg, *flat):
+        n, S = cfg["n"], cfg["S"]
+        flags, smoothness = cfg["flags"], cfg["smoothness"]
+        per = UNIT_FIELDS + S
+        assert len(flat) == n * per and 1 <= n <= nat.MAX_UNITS
+        md, rg = depth_consts(cfg["min_depth"], cfg["max_depth"])
+        want_mask, want_idx, want_ident = cfg.get("want_mask", False), cfg.get("want_idx", False), \
+            cfg.get("want_ident", False)
+        noise_outs = cfg.get("noise_out") or [None] * n
+        mean_parts = cfg.get("mean_parts") or [None] * n
+        automask = not (flags & NO_AUTOMASK)
+        d0 = flat[0]
+        B, _, H, W = d0.shape
+        dev = d0.device
+        descs = (nat.UnitDesc * n)()
+        keep = []
+        loss3 = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        stats = torch.empty((n, B, 4), dtype=torch.float32, device=dev)
+        g_disp = torch.empty((n, B, 1, H, W), dtype=torch.float32, device=dev)
+        g_T = torch.empty((n, S, B, 4, 4), dtype=torch.float32, device=dev)
+        outs = []
+        needs = []
+        for u in range(n):
+            disp, tgt, T, K, inv_K, mask_rec, noise, ident_in = flat[u * per:u * per + UNIT_FIELDS]
+            src = flat[u * per + UNIT_FIELDS:(u + 1) * per]
+            if tuple(disp.shape) != (B, 1, H, W):
+                raise RuntimeError("the units of one launch must share the shape [B,1,H,W]")
+            nat.require_device(disp, tgt, T, K, inv_K, mask_rec, noise, ident_in, *src)
+            disp, ds = _img(disp)
+            tgt, ts = _img(tgt)
+            mask_rec, ms = _img(mask_rec)
+            srcs = [_img(t) for t in src]
+            T, K, inv_K, noise, ident_in = _c(T), _c(K), _c(inv_K), _c(noise), _c(ident_in)
+            mp = _c(mean_parts[u]) if mean_parts[u] is not None else None
+            if mp is not None and tuple(mp.shape) != (B, 32):
+                raise RuntimeError("disp_mean_partials must be [B,32]")
+            if tuple(T.shape) != (S, B, 4, 4):
+                raise RuntimeError(f"T must be [S,B,4,4] = {(S, B, 4, 4)}, got {tuple(T.shape)}")
+            if ident_in is not None and tuple(ident_in.shape) != (B, H, W, 2):
+                raise RuntimeError("ident_in must be [B,H,W,2]")
+            argmin = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+            auto_mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_mask else None
+            idx = torch.empty((S, B, H, W, 2), dtype=torch.int32, device=dev) if want_idx else None
+            ident = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) \
+                if (want_ident and automask) else None
+            seed = 0
+            if noise is None and automask:
+                # tie-break draw of train.py:1023-1024 generated in the kernel: one 64-bit key per
+                # unit from torch's CPU generator (reproducible under torch.manual_seed)
+                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+            d = descs[u]
+            d.disp, d.disp_stride = disp.data_ptr(), ds
+            d.tgt, d.tgt_stride = tgt.data_ptr(), ts
+            for k in range(S):
+                d.src[k], d.src_stride[k] = srcs[k][0].data_ptr(), srcs[k][1]
+            d.T, d.K, d.inv_K = T.data_ptr(), K.data_ptr(), inv_K.data_ptr()
+            if mask_rec is not None:
+                d.mask_rec, d.mask_stride = mask_rec.data_ptr(), ms
+            d.noise = noise.data_ptr() if noise is not None else None
+            d.disp_mean_partials = mp.data_ptr() if mp is not None else None
+            d.ident_in = ident_in.data_ptr() if ident_in is not None else None
+            d.noise_seed = seed
+            d.ident_out = ident.data_ptr() if ident is not None else None
+            d.loss, d.stats = loss3[u].data_ptr(), stats[u].data_ptr()
+            d.g_disp_raw, d.g_stride = g_disp[u].data_ptr(), H * W
+            d.g_T_raw = g_T[u].data_ptr()
+            d.argmin = argmin.data_ptr()
+            d.auto_mask = auto_mask.data_ptr() if auto_mask is not None else None
+            d.idx_xy = idx.data_ptr() if idx is not None else None
+            d.noise_out = noise_outs[u].data_ptr() if noise_outs[u] is not None else None
+            keep += [disp, tgt, mask_rec, T, K, inv_K, noise, ident_in, mp, srcs]
+            empty = torch.empty(0, device=dev)
+            outs += [auto_mask if auto_mask is not None else empty, argmin,
+                     idx if idx is not None else empty, ident if ident is not None else empty]
+            needs.append((ctx.needs_input_grad[1 + u * per], ctx.needs_input_grad[1 + u * per + 2]))
+        ws = torch.empty(nat.lib().mvf_units_workspace_floats(n, B, H, W), dtype=torch.float32, device=dev)
+        tk = _tickets(dev, nat.lib().mvf_units_ticket_ints(n, B))
+        nat.check(nat.lib().mvf_units_fwdbwd(C.cast(descs, C.c_void_p), n, S, flags, smoothness, md, rg,
+                                             cfg["eps"], nat.ptr(ws), nat.ptr(tk), B, H, W, _stream()),
+                  "units_fwdbwd")
+        ctx.save_for_backward(g_disp, g_T, stats)
+        ctx.n, ctx.S, ctx.smoothness, ctx.per, ctx.needs = n, S, smoothness, per, needs
+        res = (loss3[:, 0], loss3[:, 1:], *outs)
+        ctx.mark_non_differentiable(*res[1:])
+        return res
+
+    @staticmethod
+    def backward(ctx, g_losses, *_unused):
+        # raw gradients for an upstream gradient of 1; one pass applies the per-image constant of
+        # the mean-normalised smoothness term and each unit's upstream gradient
+        g_raw, gT_raw, stats = ctx.saved_tensors
+        n, S = ctx.n, ctx.S
+        _, B, _, H, W = g_raw.shape
+        g_losses = _c(g_losses).reshape(n)
+        g_disp, g_T = torch.empty_like(g_raw), torch.empty_like(gT_raw)
+        descs = (nat.UnitScaleDesc * n)()
+        for u in range(n):
+            d = descs[u]
+            d.g_disp_raw, d.in_stride = g_raw[u].data_ptr(), H * W
+            d.g_T_raw, d.stats = gT_raw[u].data_ptr(), stats[u].data_ptr()
+            d.g_loss = g_losses.data_ptr() + 4 * u
+            d.g_disp, d.out_stride = g_disp[u].data_ptr(), H * W
+            d.g_T = g_T[u].data_ptr()
+        nat.check(nat.lib().mvf_units_fwdbwd_scale(C.cast(descs, C.c_void_p), n, ctx.smoothness, B, S, H, W,
+                                                   _stream()), "units_fwdbwd_scale")
+        grads = [None]
+        for u in range(n):
+            gu = [None] * ctx.per
+            if ctx.needs[u][0]:
+                gu[0] = g_disp[u]
+            if ctx.needs[u][1]:
+                gu[2] = g_T[u]
+            grads += gu
+        return tuple(grads)
+
+
+class Unit:
     """One hot-path unit: S x generate_images_pred + compute_losses_base with the warped
     images kept in LDS (reference: train.py:956-1051).
     inputs: disp, tgt, T [S,B,4,4], K, inv_K, mask_rec|None, noise|None, cfg, *src(S)
-    outputs: loss (0-dim), auto_mask [B,1,H,W] (or None), argmin uint8"""
+    outputs: loss (0-dim), auto_mask [B,1,H,W] (or None), argmin uint8
+    Training route (a gradient is wanted, S <= 2): `Units` with one unit; this class holds the
+    route through the separate forward / backward kernels (S > 2, no gradient, UNIT_FWDBWD off)."""
+
+    @staticmethod
+    def apply(disp, tgt, T, K, inv_K, mask_rec, noise, cfg, *src):     # noqa: D102
+        S = cfg[0]
+        if unit_uses_fwdbwd(S, disp, T):
+            flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx = cfg[1:8]
+            ucfg = dict(n=1, S=S, flags=flags, smoothness=smoothness, min_depth=min_depth,
+                        max_depth=max_depth, eps=eps, want_mask=want_mask, want_idx=want_idx,
+                        noise_out=[cfg[8]] if len(cfg) > 8 and cfg[8] is not None else None,
+                        mean_parts=[cfg[9]] if len(cfg) > 9 and cfg[9] is not None else None)
+            losses, terms, auto_mask, argmin, idx, _ = Units.apply(
+                ucfg, disp, tgt, T, K, inv_K, mask_rec, noise, None, *src)
+            return losses[0], auto_mask, argmin, idx, terms[0]
+        return _UnitStaged.apply(disp, tgt, T, K, inv_K, mask_rec, noise, cfg, *src)
+
+
+class _UnitStaged(torch.autograd.Function):
+    """The unit through mvf_unit_fwd / mvf_unit_bwd (separate forward and backward kernels)."""
 
     @staticmethod
     def forward(ctx, disp, tgt, T, K, inv_K, mask_rec, noise, cfg, *src):
         S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx = cfg[:8]
-        noise_out = cfg[8] if len(cfg) > 8 else None     # tests: receives the in-kernel draw
-        # [B,32] per-image partial sums of disp from the decoder's disparity-head epilogue
-        mean_part = _c(cfg[9]) if len(cfg) > 9 and cfg[9] is not None else None
-        if mean_part is not None and tuple(mean_part.shape) != (disp.shape[0], 32):
-            raise RuntimeError("disp_mean_partials must be [B,32]")
         src = [_c(t) for t in src]
         nat.require_device(disp, tgt, T, K, inv_K, mask_rec, noise, *src)
         disp, tgt, T, K, inv_K = _c(disp), _c(tgt), _c(T), _c(K), _c(inv_K)
@@ -406,29 +585,6 @@ class Unit(torch.autograd.Function):
         stats = torch.empty((B, 4), dtype=torch.float32, device=dev)
         ws = _ws(disp, B, H, W)
         sp, skeep = nat.ptr_array(src)
-        ctx.fwdbwd = bool(UNIT_FWDBWD and S <= 2 and
-                          (ctx.needs_input_grad[0] or ctx.needs_input_grad[2]))
-        if ctx.fwdbwd:
-            g_disp = torch.empty_like(disp)
-            g_T = torch.empty_like(T)
-            automask = not (flags & NO_AUTOMASK)
-            seed = 0
-            if noise is None and automask:
-                # tie-break draw of train.py:1023-1024 generated in the kernel: one 64-bit key per
-                # call from torch's CPU generator (reproducible under torch.manual_seed)
-                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-            nat.check(nat.lib().mvf_unit_fwdbwd(
-                nat.ptr(disp), nat.ptr(tgt), sp, nat.ptr(T), nat.ptr(K), nat.ptr(inv_K), nat.ptr(noise),
-                nat.ptr(mask_rec), S, flags, smoothness, md, rg, eps, nat.ptr(loss), nat.ptr(argmin),
-                nat.ptr(auto_mask), None, nat.ptr(stats), nat.ptr(idx), nat.ptr(g_disp), nat.ptr(g_T),
-                nat.ptr(ws), B, H, W, seed, nat.ptr(noise_out), nat.ptr(mean_part), _stream()), "unit_fwdbwd")
-            ctx.save_for_backward(g_disp, g_T, stats)
-            ctx.n_src = S
-            ctx.smoothness = smoothness
-            outs = [loss[0], auto_mask if want_mask else torch.empty(0, device=dev), argmin,
-                    idx if want_idx else torch.empty(0, device=dev), loss[1:]]
-            ctx.mark_non_differentiable(*outs[1:])
-            return tuple(outs)
         if noise is None and not (flags & NO_AUTOMASK):
             raise RuntimeError("mvf_unit_fwd needs the tie-break noise tensor (only the "
                                "forward+backward kernel draws it itself)")
@@ -446,17 +602,6 @@ class Unit(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
-        if ctx.fwdbwd:
-            # raw gradients for an upstream gradient of 1; one pass applies the per-image
-            # constant of the mean-normalised smoothness term and the upstream gradient
-            g_raw, gT_raw, stats = ctx.saved_tensors
-            B, _, H, W = g_raw.shape
-            g_loss = _c(g_loss).reshape(1)
-            g_disp, g_T = torch.empty_like(g_raw), torch.empty_like(gT_raw)
-            nat.check(nat.lib().mvf_unit_fwdbwd_scale(
-                nat.ptr(g_raw), nat.ptr(gT_raw), nat.ptr(stats), nat.ptr(g_loss), ctx.smoothness,
-                nat.ptr(g_disp), nat.ptr(g_T), B, ctx.n_src, H, W, _stream()), "unit_fwdbwd_scale")
-            return (g_disp, None, g_T, None, None, None, None, None, *([None] * ctx.n_src))
         disp, tgt, T, K, inv_K, mask_rec, argmin, stats, *src = ctx.saved_tensors
         S, flags, smoothness, md, rg, eps = ctx.cfg
         B, _, H, W = disp.shape

@@ -106,6 +106,13 @@ def build_parser():
     p.add_argument("--fused_units", type=_str2bool, default=True,
                    help="fused unit kernels (warped images in LDS) instead of the staged "
                         "generate_images_pred + compute_losses_base pair")
+    p.add_argument("--batch_units", type=_str2bool, default=True,
+                   help="the three mutually independent hot-path units of each group of a step "
+                        "(single-frame / multi-frame / affine) as ONE kernel launch instead of three")
+    p.add_argument("--share_identity", type=_str2bool, default=True,
+                   help="the multi-frame unit of a target takes the identity-reprojection maps the "
+                        "single-frame unit of the same target and sources computed (train.py:747-749 vs "
+                        "795-797) instead of re-evaluating them")
     p.add_argument("--device_augment", type=_str2bool, default=True,
                    help="flip / ColorJitter / affine views of a batch on the device (augment.py) instead "
                         "of per item on the host (reference: datasets/mono_dataset.py:102-184)")
@@ -113,10 +120,18 @@ def build_parser():
                    help="auto-mask tie-break noise (train.py:1023-1024) drawn inside the unit kernel "
                         "from a counter-based generator instead of a torch.randn tensor per unit")
     p.add_argument("--hip_graph", type=_str2bool, default=False,
-                   help="capture the device work of an optimisation step (networks, hot-path units, "
-                        "backward, clipping, AdamW) once into a HIP graph and replay it: one launch "
-                        "per step instead of thousands (needs static shapes; trainer._StepGraph)")
+                   help="EXPERIMENTAL: capture the device work of an optimisation step (networks, "
+                        "hot-path units, backward, clipping, AdamW) once into a HIP graph and replay it: "
+                        "one launch per step instead of thousands (needs static shapes; "
+                        "trainer._StepGraph).  See DESIGN.md section 7 for which stages of the step are "
+                        "captured on this ROCm stack; a GPU memory fault during a replay cannot be caught")
     p.add_argument("--bucket_mb", type=float, default=32.0, help="gradient all-reduce bucket size")
+    p.add_argument("--grad_exchange", type=str, default="all_reduce", choices=["all_reduce", "reduce_scatter"],
+                   help="per gradient bucket: one RCCL all-reduce, or its two halves issued explicitly on "
+                        "the flat buffer (reduce_scatter_tensor + all_gather_into_tensor; SURVEY.md 8f-3)")
+    p.add_argument("--no_overlap", type=_str2bool, default=False,
+                   help="reduce the gradient buckets after backward instead of from the hooks during it "
+                        "(measurement aid: the overlapped step beside the serial one)")
     p.add_argument("--force_collectives", type=_str2bool, default=False,
                    help="issue the data-parallel collectives (bucketed gradient all-reduce, "
                         "SyncBatchNorm statistics) even when world_size is 1 -- exercises the RCCL "

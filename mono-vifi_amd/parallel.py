@@ -17,12 +17,42 @@ trainable parameters:
   the rest of backward; ``finish()`` waits, and also reduces buckets whose parameters got
   no gradient this step (so every rank issues the same collectives -- no
   ``find_unused_parameters`` graph walk);
-* works unchanged on ``gloo`` (CPU) -- that is how tests/test_parallel.py covers N > 1.
+* works unchanged on ``gloo`` (CPU) -- that is how tests/test_parallel.py covers N > 1;
+* ``exchange="reduce_scatter"`` replaces each bucket's all-reduce by the two halves a ring
+  all-reduce consists of, issued explicitly on the flat buffer: ``reduce_scatter_tensor``
+  (each rank receives the averaged 1/N-th of the bucket it owns, in place) followed by
+  ``all_gather_into_tensor``.  Same bytes on the links, same result
+  (the reduction order per element is RCCL's in both forms); what it buys is a point between
+  the halves where a rank holds exactly its shard -- the place a sharded optimiser step goes --
+  and two smaller collectives per bucket for the scheduler to interleave with backward.
+
+Every collective this package issues is counted in ``COMM_COUNTS`` (by kind), so that "one
+collective per BatchNorm layer per grouped call" and "one exchange per bucket" are tested
+numbers (tests/test_parallel.py, tests/test_trainer_gpu.py) and ``bench.py`` can report
+collectives per step.
 """
 from __future__ import annotations
 
+import collections
+
 import torch
 import torch.distributed as dist
+
+# kind -> number of collectives issued since reset_comm_counts(); kinds: grad_all_reduce,
+# grad_reduce_scatter, grad_all_gather, bn_all_gather, bn_all_reduce, broadcast, loss_all_reduce
+COMM_COUNTS = collections.Counter()
+
+
+def count_collective(kind, n=1):
+    COMM_COUNTS[kind] += n
+
+
+def reset_comm_counts():
+    COMM_COUNTS.clear()
+
+
+def comm_counts():
+    return dict(COMM_COUNTS)
 
 
 def init_distributed(opts, backend=None):
@@ -87,6 +117,7 @@ def broadcast_module_states(modules, src=0):
     for group in by_dev.values():
         flat = torch.cat([t.reshape(-1) for t in group])
         dist.broadcast(flat, src)
+        count_collective("broadcast")
         off = 0
         for t in group:
             n = t.numel()
@@ -95,23 +126,33 @@ def broadcast_module_states(modules, src=0):
 
 
 class _Bucket:
-    __slots__ = ("buf", "params", "pending", "handle", "launched")
+    __slots__ = ("buf", "params", "pending", "handle", "launched", "shard")
 
     def __init__(self, buf, params):
         self.buf, self.params = buf, params
         self.pending, self.handle, self.launched = len(params), None, False
+        self.shard = None       # reduce_scatter exchange: this rank's 1/N-th of `buf` (a view)
 
 
 class BucketedGradReducer:
     """Flat-bucket gradient averaging overlapped with backward (see module docstring)."""
 
+    EXCHANGES = ("all_reduce", "reduce_scatter")
+
     def __init__(self, params, world_size=None, bucket_mb=32.0, process_group=None,
-                 always_reduce=False):
+                 always_reduce=False, exchange="all_reduce", overlap=True):
+        if exchange not in self.EXCHANGES:
+            raise ValueError(f"exchange must be one of {self.EXCHANGES}, got {exchange!r}")
         self.group = process_group
         # always_reduce: issue the collectives even for a group of one (RCCL smoke on one GPU)
         self.always_reduce = bool(always_reduce)
+        self.exchange = exchange
+        # overlap=False: nothing is issued from the hooks, finish() reduces every bucket after
+        # backward (the measurement bench.py --no-overlap puts beside the overlapped step)
+        self.overlap = bool(overlap)
         self.world = world_size if world_size is not None else (
             dist.get_world_size(process_group) if dist.is_initialized() else 1)
+        self._rank = dist.get_rank(process_group) if (dist.is_initialized() and self.world > 1) else 0
         self.params = list(params)
         self.buckets = []
         self._owner = {}
@@ -129,12 +170,18 @@ class BucketedGradReducer:
 
     def _seal(self, params):
         n = sum(p.numel() for p in params)
-        buf = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        # reduce_scatter exchange: every rank owns an equal slice, so the flat buffer is padded
+        # to a multiple of the group size (the padding stays zero)
+        n_pad = -(-n // self.world) * self.world if self.exchange == "reduce_scatter" else n
+        buf = torch.zeros(n_pad, dtype=torch.float32, device=params[0].device)
         off = 0
         for p in params:
             p.grad = buf[off:off + p.numel()].view_as(p)
             off += p.numel()
         b = _Bucket(buf, params)
+        if self.exchange == "reduce_scatter":
+            per = n_pad // self.world
+            b.shard = buf[self._rank * per:(self._rank + 1) * per]
         for p in params:
             self._owner[id(p)] = b
         self.buckets.append(b)
@@ -151,16 +198,33 @@ class BucketedGradReducer:
                     p.grad = b.buf[off:off + p.numel()].view_as(p)
                 off += p.numel()
 
+    def _chained(self):
+        """True when two collectives issued back to back on the group run in issue order
+        (RCCL: one communicator stream).  gloo's worker threads give no such guarantee."""
+        return dist.get_backend(self.group) == "nccl"
+
     def _launch(self, b):
         b.launched = True
-        if self.world > 1 or self.always_reduce:
-            b.buf.div_(self.world)
+        if not (self.world > 1 or self.always_reduce):
+            return
+        b.buf.div_(self.world)
+        if self.exchange == "all_reduce":
             b.handle = dist.all_reduce(b.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            count_collective("grad_all_reduce")
+            return
+        # in place: rank r's output is slice r of its own input (RCCL's in-place form)
+        h = dist.reduce_scatter_tensor(b.shard, b.buf, op=dist.ReduceOp.SUM, group=self.group,
+                                       async_op=True)
+        count_collective("grad_reduce_scatter")
+        if self._chained():
+            h = dist.all_gather_into_tensor(b.buf, b.shard, group=self.group, async_op=True)
+            count_collective("grad_all_gather")
+        b.handle = h
 
     def _on_grad(self, p):
         b = self._owner[id(p)]
         b.pending -= 1
-        if b.pending == 0 and not b.launched:
+        if b.pending == 0 and not b.launched and self.overlap:
             self._launch(b)
 
     def finish(self):
@@ -169,10 +233,15 @@ class BucketedGradReducer:
         for b in self.buckets:
             if not b.launched:
                 self._launch(b)
+        gather_late = self.exchange == "reduce_scatter" and (self.world > 1 or self.always_reduce) \
+            and not self._chained()
         for b in self.buckets:
             if b.handle is not None:
                 b.handle.wait()
                 b.handle = None
+                if gather_late:
+                    dist.all_gather_into_tensor(b.buf, b.shard, group=self.group)
+                    count_collective("grad_all_gather")
 
     def remove(self):
         for h in self._hooks:

@@ -198,6 +198,10 @@ class Trainer(HotPathLosses):
         use_graph = bool(getattr(o, "hip_graph", False)) and self.device.type == "cuda"
         if use_graph and o.optimizer not in ("adamw", "adam"):
             raise ValueError("--hip_graph needs a capturable optimizer (adamw / adam)")
+        if use_graph:
+            logging.warning("--hip_graph is EXPERIMENTAL: the optimisation step is captured into a HIP graph "
+                            "and replayed; a GPU memory fault during a replay cannot be caught (DESIGN.md "
+                            "section 7 lists what is captured on this ROCm stack)")
         # under a HIP graph the step counter and the learning rate live on the device: the
         # schedulers then update the rate in place (fill_) and the replayed launch reads it
         gkw = {"capturable": True, "foreach": True} if use_graph else {}
@@ -229,15 +233,29 @@ class Trainer(HotPathLosses):
             # and the dead ImageNet fc head (train.py:198-200), this one holds each parameter
             # once.  A foreign optimiser state is therefore dropped (fresh moments, schedule
             # fast-forwarded to the checkpoint's step) instead of raising.
-            try:
-                self.model_optimizer.load_state_dict(checkpoint["optimizer"])
+            # A foreign state is recognised by its parameter count, not by catching whatever
+            # load_state_dict raises: a truncated / corrupt checkpoint of THIS trainer still fails loudly.
+            saved = checkpoint.get("optimizer", {})
+            n_saved = sum(len(g.get("params", ())) for g in saved.get("param_groups", ()))
+            n_mine = sum(len(g["params"]) for g in self.model_optimizer.param_groups)
+            if n_saved == n_mine:
+                self.model_optimizer.load_state_dict(saved)
                 self.model_lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
+                if use_graph:
+                    # the saved groups carry the eager settings (capturable=False, float lr, host-side
+                    # step counters): restore what a captured optimiser step needs
+                    for g in self.model_optimizer.param_groups:
+                        g["capturable"], g["foreach"] = True, True
+                    for st in self.model_optimizer.state.values():
+                        if "step" in st:
+                            st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(self.device)
                 if self._lr_shadow is not None:
                     self._lr_shadow.param_groups[0]["lr"] = float(self.model_lr_scheduler.get_last_lr()[0])
-            except (ValueError, KeyError, RuntimeError) as e:
-                logging.warning("optimizer state of the checkpoint does not match this trainer's "
-                                "parameter list (%s): restarting the optimizer moments, keeping "
-                                "weights, epoch and step", e)
+            else:
+                logging.warning("optimizer state of the checkpoint holds %d parameters, this trainer %d (the "
+                                "reference's optimiser lists the aliased encoder_mf / depth_mf parameters twice "
+                                "and the ImageNet fc head): restarting the optimizer moments, keeping weights, "
+                                "epoch and step", n_saved, n_mine)
                 sched = checkpoint.get("lr_scheduler", {})
                 last = int(sched.get("last_epoch", 0)) if isinstance(sched, dict) else 0
                 if o.lr_sche_type == "cos":
@@ -251,7 +269,9 @@ class Trainer(HotPathLosses):
         self._push_lr()
 
         self.reducer = parallel.BucketedGradReducer(self.parameters_to_train, o.world_size,
-                                                    o.bucket_mb, always_reduce=o.force_collectives)
+                                                    o.bucket_mb, always_reduce=o.force_collectives,
+                                                    exchange=getattr(o, "grad_exchange", "all_reduce"),
+                                                    overlap=not getattr(o, "no_overlap", False))
         self._step_graph = _StepGraph(self) if use_graph else None
 
         # ---- hot-path modules (reference: train.py:248-256)
@@ -338,6 +358,8 @@ class Trainer(HotPathLosses):
     def run_epoch(self, max_steps=None):
         logging.info("Training epoch %d\n", self.epoch)
         self.sampler.set_epoch(self.epoch)
+        if hasattr(self.train_loader.dataset, "set_epoch"):
+            self.train_loader.dataset.set_epoch(self.epoch)      # fresh augmentation draws per epoch
         self.sampler.set_start_iter(self.batch_start * self.opt.batch_size)
         self.set_train()
         if self.opt.world_size > 1:
@@ -352,6 +374,7 @@ class Trainer(HotPathLosses):
                 if self.opt.world_size > 1:
                     stacked = torch.stack([losses[k].detach().float() for k in sorted(losses)])
                     dist.all_reduce(stacked, op=dist.ReduceOp.SUM)
+                    parallel.count_collective("loss_all_reduce")
                     stacked /= self.opt.world_size
                     for i, k in enumerate(sorted(losses)):
                         losses[k] = stacked[i]
@@ -397,6 +420,20 @@ class Trainer(HotPathLosses):
         warped = [self.generate_images_pred(disp, poses[k], srcs[k], K, inv_K) for k in range(len(srcs))]
         loss, _ = self.compute_losses_base(disp, tgt, warped, srcs, mask_rec)
         return loss
+
+    def _units(self, units, want_ident=False):
+        """Mutually independent hot-path units of one group (reference: e.g. train.py:747-760):
+        ONE launch of the forward+backward tile kernel for all of them.  units: dicts as for
+        `compute_units`.  Returns (sum of their losses, identity maps per unit | None)."""
+        if self.opt.fused_units:
+            losses, idents, _ = self.compute_units(units, want_ident=want_ident)
+            return losses.sum(), idents
+        total = None
+        for un in units:
+            l = self._unit(un["disp_tgt"], un["img_tgt"], un["poses"], un["imgs_src"], un["K"], un["inv_K"],
+                           un.get("mask_rec"))
+            total = l if total is None else total + l
+        return total, None
 
     def _affine_pose(self, pose, Rc, Rc_inv):
         """Pose of the affine-augmented view: [Rc R Rc^-1 | Rc t] (reference: train.py:820-823)."""
@@ -535,9 +572,17 @@ class Trainer(HotPathLosses):
         depth_0, depth_pt, depth_nt = to_depth(disp_0), to_depth(disp_pt), to_depth(disp_nt)
 
         srcs = [img_n1, img_p1]
-        losses["loss_base"] = losses["loss_base"] + self._unit(disp_0, img_0, [pose_0_n1, pose_0_p1], srcs, K, inv_K)
-        losses["loss_base"] = losses["loss_base"] + self._unit(disp_pt, img_pt, [pose_pt_n1, pose_pt_p1], srcs, K, inv_K)
-        losses["loss_base"] = losses["loss_base"] + self._unit(disp_nt, img_nt, [pose_nt_n1, pose_nt_p1], srcs, K, inv_K)
+
+        def unit(disp, tgt, poses, sources=srcs, **kw):
+            return dict(disp_tgt=disp, img_tgt=tgt, poses=poses, imgs_src=sources, K=K, inv_K=inv_K, **kw)
+        # the three single-frame units (train.py:747-760): one launch.  Each also hands the identity
+        # maps of its (target, sources) to the multi-frame unit of the same target below
+        share = bool(getattr(o, "share_identity", True)) and not o.disable_automasking
+        l_sf, idents = self._units([unit(disp_0, img_0, [pose_0_n1, pose_0_p1]),
+                                    unit(disp_pt, img_pt, [pose_pt_n1, pose_pt_p1]),
+                                    unit(disp_nt, img_nt, [pose_nt_n1, pose_nt_p1])], want_ident=share)
+        losses["loss_base"] = losses["loss_base"] + l_sf
+        id_0, id_pt, id_nt = idents if idents is not None else (None, None, None)
 
         # ---- multi-frame depths
         if o.fuse_model_type == "separate_all":
@@ -552,11 +597,13 @@ class Trainer(HotPathLosses):
         disp_0_fuse, disp_nt_fuse, disp_pt_fuse = fused
         depth_0_fuse, depth_nt_fuse, depth_pt_fuse = (to_depth(d) for d in fused)
 
-        losses["loss_base"] = losses["loss_base"] + self._unit(disp_0_fuse, img_0, [pose_0_n1, pose_0_p1], srcs, K, inv_K)
+        # the three multi-frame units (train.py:795-810): one launch, identity maps handed over
+        l_mf, _ = self._units([unit(disp_0_fuse, img_0, [pose_0_n1, pose_0_p1], ident=id_0),
+                               unit(disp_nt_fuse, img_nt, [pose_nt_n1, pose_nt_p1], ident=id_nt),
+                               unit(disp_pt_fuse, img_pt, [pose_pt_n1, pose_pt_p1], ident=id_pt)])
+        losses["loss_base"] = losses["loss_base"] + l_mf
         losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_0, depth_0_fuse)
-        losses["loss_base"] = losses["loss_base"] + self._unit(disp_nt_fuse, img_nt, [pose_nt_n1, pose_nt_p1], srcs, K, inv_K)
         losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_nt, depth_nt_fuse)
-        losses["loss_base"] = losses["loss_base"] + self._unit(disp_pt_fuse, img_pt, [pose_pt_n1, pose_pt_p1], srcs, K, inv_K)
         losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_pt, depth_pt_fuse)
 
         # ---- affine-augmentation losses
@@ -568,12 +615,16 @@ class Trainer(HotPathLosses):
             mask_rec = inputs["valid_mask_rec"]
             todo = ((pose_0_n1, pose_0_p1, depth_0, depth_0_fuse), (pose_nt_n1, pose_nt_p1, depth_nt, depth_nt_fuse),
                     (pose_pt_n1, pose_pt_p1, depth_pt, depth_pt_fuse))
+            # the three affine units (train.py:837-882): one launch
+            units_a = []
             for (pa, pb, depth_s, depth_f), tgt, disp_a in zip(todo, tgts_a, dec[3:]):
-                depth_a = to_depth(disp_a)
                 poses_a = [self._affine_pose(pa, Rc, Rc_inv), self._affine_pose(pb, Rc, Rc_inv)]
-                losses["loss_base"] = losses["loss_base"] + self._unit(disp_a, tgt, poses_a, srcs_a, K, inv_K, mask_rec)
+                units_a.append(unit(disp_a, tgt, poses_a, srcs_a, mask_rec=mask_rec))
+            l_af, _ = self._units(units_a)
+            losses["loss_base"] = losses["loss_base"] + l_af
+            for (pa, pb, depth_s, depth_f), disp_a in zip(todo, dec[3:]):
                 losses["loss_dc"] = losses["loss_dc"] + self.compute_depth_consistency_loss_affine(
-                    depth_a, depth_s, depth_f, inputs)
+                    to_depth(disp_a), depth_s, depth_f, inputs)
 
         losses["loss"] = losses["loss_base"] + o.lamda * losses["loss_dc"]
         return None, losses

@@ -1,0 +1,68 @@
+"""CPU: `bench.py --gpus N` starts its N ranks itself (reference launcher:
+train.py:1178-1185, README.md:130-133 -- world = visible GPUs, one process each).
+
+The mock workload is a toy CPU step over gloo: only the launcher, the process group and the
+`comm` report are under test here, never a number."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=300):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT,
+                          capture_output=True, text=True, timeout=timeout)
+
+
+def _line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"expected ONE JSON line, got {len(lines)}:\n{out}"
+    return json.loads(lines[0])
+
+
+def test_gpus_2_spawns_two_ranks_and_reports_the_group():
+    r = _run(["--gpus", "2", "--workload", "mock", "--steps", "4", "--warmup", "1", "--batch", "4"],
+             {"MVF_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 8
+    c = d["comm"]
+    assert c["backend"] == "gloo" and c["world_size"] == 2 and c["distinct_processes"] == 2
+    assert c["grad_buckets"] >= 2 and c["grad_bucket_bytes"] > 0
+    # one exchange per bucket per step
+    assert c["collectives_per_step"] == {"grad_all_reduce": float(c["grad_buckets"])}
+    assert c["no_overlap"]["ms_per_step"] > 0 and c["overlap_with_backward"] is True
+    assert "launching" in r.stderr          # it re-executed itself under torch.distributed.run
+
+
+def test_reduce_scatter_exchange_is_reported():
+    r = _run(["--gpus", "2", "--workload", "mock", "--steps", "3", "--warmup", "1", "--grad-exchange",
+              "reduce_scatter", "--no-overlap"], {"MVF_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    c = _line(r.stdout)["comm"]
+    nb = float(c["grad_buckets"])
+    assert c["grad_exchange"] == "reduce_scatter" and c["overlap_with_backward"] is False
+    assert c["collectives_per_step"] == {"grad_all_gather": nb, "grad_reduce_scatter": nb}
+    assert "overlapped" in c
+
+
+def test_more_ranks_than_gpus_fails_loudly():
+    """On a box with fewer GPUs than --gpus the benchmark refuses (it used to run ONE rank and
+    print n_gpus: 1)."""
+    import torch
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    r = _run(["--gpus", str(have + 2), "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0
+    assert "needs" in (r.stderr + r.stdout) and "GPUs" in (r.stderr + r.stdout)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_world_size_must_match_gpus():
+    """A torchrun environment whose WORLD_SIZE differs from --gpus is refused, not relabelled."""
+    r = _run(["--gpus", "1", "--workload", "mock", "--steps", "1", "--warmup", "0"],
+             {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
+    assert r.returncode != 0 and "refusing" in r.stderr

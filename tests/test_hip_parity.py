@@ -656,7 +656,7 @@ def test_reflect_pad1(dev, shape):
 
 # ------------------------------------------------------------------ in-kernel tie-break noise
 @pytest.mark.parametrize("shape,flags,S", [((2, 33, 70), 0, 2), ((1, 64, 200), 2, 2), ((2, 17, 65), 0, 1),
-                                           ((4, 192, 640), 0, 2)])
+                                           ((4, 192, 640), 0, 2), ((12, 192, 640), 0, 2), ((8, 320, 1024), 0, 2)])
 def test_inkernel_noise_replayed_through_the_oracle(dev, shape, flags, S):
     """noise=None: the forward+backward kernel draws the tie-break noise of train.py:1023-1024
     itself (counter-based generator keyed by a per-call seed).  The draw is written out and

@@ -132,3 +132,45 @@ def test_batched_affine_helpers_match_per_sample_loops():
     want = O.affine_restore(img.numpy(), angle.numpy(), box.numpy(), ratio.numpy())
     got = tr.rotate_bilinear(tr.paste_resized(img, box), -angle) * ratio.view(-1, 1, 1, 1)
     assert np.max(np.abs(got.numpy() - want)) <= 2e-5
+
+
+def test_token_linear_backward_under_bf16_autocast():
+    """`_TokenLinear` (Lite-Mono's per-image weight gradient) ran its backward outside the
+    autocast context with a bf16 gradient against fp32 weight / activation -> dtype error under
+    --amp_bf16.  The gate now skips it under autocast, and its backward computes in the weight's
+    type whatever reaches it."""
+    import torch
+    import torch.nn as nn
+    from mono_vifi_amd.networks import litemono as lm
+    torch.manual_seed(0)
+    lin = nn.Linear(8, 12)
+    x = torch.randn(2, 40, 8, requires_grad=True)
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y = lm._TokenLinear.apply(x, lin.weight, lin.bias)
+    assert y.dtype == torch.bfloat16
+    y.float().pow(2).sum().backward()            # backward outside autocast, bf16 upstream gradient
+    gx, gw = x.grad.clone(), lin.weight.grad.clone()
+    x.grad = lin.weight.grad = lin.bias.grad = None
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        y2 = lin(x)
+    y2.float().pow(2).sum().backward()
+    assert gw.dtype == torch.float32 and gx.dtype == torch.float32
+    assert torch.allclose(gx, x.grad, rtol=0.05, atol=0.05)
+    assert torch.allclose(gw, lin.weight.grad, rtol=0.05, atol=0.2)
+
+
+def test_dataset_augmentation_draw_changes_with_the_epoch():
+    """the device-augment draw was a function of (seed, index) only: the same flip and
+    jitter for an item in every epoch."""
+    import torch
+    from mono_vifi_amd import datasets
+    ds = datasets.SyntheticTripletDataset(32, 64, 8, True, 3, device_augment=True)
+    keys = [k for k, v in ds[1].items() if not isinstance(k, tuple) and torch.is_tensor(v)]
+    a = ds[1]
+    ds.set_epoch(1)
+    b = ds[1]
+    ds.set_epoch(0)
+    c = ds[1]
+    draw_keys = [k for k in keys if k not in ("Rc", "angle", "box", "ratio_local", "valid_mask_rec", "valid_mask_cons")]
+    assert any(not torch.equal(a[k], b[k]) for k in draw_keys), draw_keys
+    assert all(torch.equal(a[k], c[k]) for k in keys)

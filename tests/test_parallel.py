@@ -26,7 +26,7 @@ def _net():
     return net
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange="all_reduce", overlap=True):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from mono_vifi_amd import parallel
@@ -41,8 +41,10 @@ def _worker(rank, world, port, q):
         parallel.broadcast_module_states([net], src=0)
         params = parallel.unique_parameters(net.values())
         assert len(params) == 6            # alias de-duplicated
-        red = parallel.BucketedGradReducer(params, world, bucket_mb=0.0001)   # many tiny buckets
+        red = parallel.BucketedGradReducer(params, world, bucket_mb=0.0001,   # many tiny buckets
+                                           exchange=exchange, overlap=overlap)
         assert red.num_buckets > 1
+        parallel.reset_comm_counts()
         torch.manual_seed(100)
         x_all = torch.randn(4 * world, 8)
         x = x_all[rank * 4:(rank + 1) * 4]
@@ -52,16 +54,28 @@ def _worker(rank, world, port, q):
             y.pow(2).mean().backward()
             red.finish()
         grads = [p.grad.clone() for p in params]
+        # exactly one exchange per bucket per step, whichever form it takes
+        cnt, nb = parallel.comm_counts(), red.num_buckets
+        if exchange == "all_reduce":
+            assert cnt == {"grad_all_reduce": 2 * nb}, cnt
+        else:
+            assert cnt == {"grad_reduce_scatter": 2 * nb, "grad_all_gather": 2 * nb}, cnt
+            assert all(b.buf.numel() % world == 0 for b in red.buckets)
         q.put((rank, [g.tolist() for g in grads], [p.detach().tolist() for p in params]))
     finally:
         dist.destroy_process_group()
 
 
-def test_bucketed_reducer_matches_full_batch_gradient():
+@pytest.mark.parametrize("exchange,overlap", [("all_reduce", True), ("all_reduce", False),
+                                              ("reduce_scatter", True), ("reduce_scatter", False)])
+def test_bucketed_reducer_matches_full_batch_gradient(exchange, overlap):
+    """Both forms of the bucket exchange (one all-reduce; reduce-scatter + all-gather on the flat
+    buffer), issued from the hooks during backward or after it, give the
+    full-batch gradient on every rank with one exchange per bucket."""
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(world))

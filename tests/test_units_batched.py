@@ -1,0 +1,229 @@
+"""-m gpu: several hot-path units in ONE launch (mvf_units_fwdbwd) against the same units launched
+one at a time, against the oracle, and the identity-map hand-over between the two units of a
+(single-frame, multi-frame) pair (reference: train.py:747-760, 795-810, 837-882).
+
+Bars: batched == one-at-a-time bit for bit (argmin, loss, gradients: the folds inside the launch
+run in a fixed order whoever performs them); identity maps == the oracle's bit for bit; a unit fed
+with handed-over identity maps == the same unit evaluating them itself, bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_grad_close, rel_err
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from mono_vifi_amd import _native
+    _native.lib()
+    return torch.device("cuda:0")
+
+
+def T(a, dev, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return t.requires_grad_(True) if grad else t
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def _inputs(seed, B, H, W, flags, with_mask):
+    from mono_vifi_amd import synthetic
+    inp = synthetic.unit_inputs(seed, B, H, W, pose_scale=0.03, with_mask=True,
+                                disp_mode="smooth" if H * W > 10000 else "noise")
+    inp["T"] = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
+                         for k in range(2)], 0)
+    inp["noise_used"] = np.ascontiguousarray(inp["noise"][:, :1] if flags & 2 else inp["noise"])
+    if not with_mask:
+        inp["mask_rec"] = None
+    return inp
+
+
+def _cfg(n, flags, **kw):
+    return dict(n=n, S=2, flags=flags, smoothness=1e-3, min_depth=0.1, max_depth=100.0, eps=1e-7,
+                want_mask=True, want_idx=True, **kw)
+
+
+def _flat(inp, dev, flags, disp=None, ident=None):
+    d = disp if disp is not None else T(inp["disp"], dev, True)
+    Tt = T(inp["T"], dev, True)
+    noise = None if flags & 4 else T(inp["noise_used"], dev)
+    mask = T(inp["mask_rec"], dev) if inp["mask_rec"] is not None else None
+    return d, Tt, [d, T(inp["tgt"], dev), Tt, T(inp["K"], dev), T(inp["inv_K"], dev), mask, noise, ident,
+                   T(inp["src"][0], dev), T(inp["src"][1], dev)]
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 70), (1, 64, 200), (12, 192, 640)])
+@pytest.mark.parametrize("flags", [0, 1, 2, 4])
+def test_batched_units_equal_single_launches(dev, shape, flags):
+    """Three different units in one launch -- one of them reading its disparity out of an
+    interleaved [B*G,1,H,W] tensor (image stride G*H*W, as a grouped decoder call leaves it) --
+    against the same three launched one at a time; the first also against the oracle."""
+    from mono_vifi_amd import ops
+    B, H, W = shape
+    use_mask = not (flags & 4 and flags & 2)
+    inps = [_inputs(4100 + 13 * u + H + flags, B, H, W, flags, use_mask) for u in range(3)]
+    # unit 1 takes a strided view
+    G = 3
+    inter = torch.zeros((B * G, 1, H, W), device=dev)
+    inter.view(B, G, 1, H, W)[:, 1] = T(inps[1]["disp"], dev)
+    inter.requires_grad_(True)
+    view = torch.unbind(inter.view(B, G, 1, H, W), 1)[1]
+    assert not view.is_contiguous() or B == 1
+
+    flat, leaves = [], []
+    for u, inp in enumerate(inps):
+        d, Tt, f = _flat(inp, dev, flags, disp=view if u == 1 else None)
+        flat += f
+        leaves.append((d if u != 1 else inter, Tt))
+    res = ops.Units.apply(_cfg(3, flags), *flat)
+    losses, per = res[0], res[2:]
+    losses.sum().backward()
+    got = []
+    for u in range(3):
+        gd = leaves[u][0].grad
+        if u == 1:
+            gd = gd.view(B, G, 1, H, W)[:, 1]
+        got.append((float(losses[u].detach()), N(per[4 * u + 1]), N(gd), N(leaves[u][1].grad), N(per[4 * u + 2]),
+                    N(per[4 * u + 0])))
+    if B > 1:       # nothing leaked into the other groups of the interleaved tensor
+        other = inter.grad.view(B, G, 1, H, W)[:, [0, 2]]
+        assert float(other.abs().max()) == 0.0
+
+    for u, inp in enumerate(inps):
+        d, Tt, f = _flat(inp, dev, flags)
+        r1 = ops.Units.apply(_cfg(1, flags), *f)
+        r1[0].sum().backward()
+        one = (float(r1[0][0].detach()), N(r1[2 + 1]), N(d.grad), N(Tt.grad), N(r1[2 + 2]), N(r1[2 + 0]))
+        assert got[u][0] == one[0], f"unit {u}: loss {got[u][0]} != {one[0]}"
+        assert np.array_equal(got[u][1], one[1]), f"unit {u}: argmin"
+        assert np.array_equal(got[u][2], one[2]), f"unit {u}: grad_disp"
+        assert np.array_equal(got[u][3], one[3]), f"unit {u}: grad_T"
+        assert np.array_equal(got[u][4], one[4]), f"unit {u}: sampling indices"
+        assert np.array_equal(got[u][5], one[5]), f"unit {u}: auto mask"
+
+    inp = inps[0]
+    ref = O.unit(inp["disp"], inp["tgt"], inp["src"], inp["T"], inp["K"], inp["inv_K"], inp["noise_used"],
+                 inp["mask_rec"], flags, want_grads=True)
+    am = got[0][1].astype(np.int32)
+    am[am == 255] = -1
+    assert np.array_equal(am, ref["idx"])
+    assert abs(got[0][0] - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+    assert_grad_close(got[0][2], ref["grad_disp"], TOL, "grad_disp vs oracle")
+    assert rel_err(got[0][3], ref["grad_T"]) <= TOL
+    for k in range(2):
+        assert np.array_equal(got[0][4][k, ..., 0], ref["x0"][k]) and np.array_equal(got[0][4][k, ..., 1], ref["y0"][k])
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 70), (3, 17, 65), (12, 192, 640)])
+@pytest.mark.parametrize("flags", [0, 1, 2])
+def test_identity_maps_handed_over(dev, shape, flags):
+    """Unit A (disparity 1) writes its identity maps; unit B (disparity 2; same target, sources,
+    poses -- the multi-frame unit of the same target, train.py:795-797) takes them.  The maps are
+    the oracle's identity-reprojection maps bit for bit, and B's results are bit-equal to B
+    evaluating the identity pair itself and match the oracle."""
+    from mono_vifi_amd import ops, synthetic
+    B, H, W = shape
+    inp = _inputs(5200 + H + flags, B, H, W, flags, True)
+    other = synthetic.unit_inputs(77, B, H, W, disp_mode="smooth" if H * W > 10000 else "noise")
+    inp_b = dict(inp)
+    inp_b["disp"] = other["disp"]
+    inp_b["noise_used"] = np.ascontiguousarray(other["noise"][:, :1] if flags & 2 else other["noise"])
+
+    _, _, fa = _flat(inp, dev, flags)
+    ra = ops.Units.apply(_cfg(1, flags, want_ident=True), *fa)
+    ident = ra[2 + 3]
+    assert tuple(ident.shape) == (B, H, W, 2)
+    ref_a = O.unit(inp["disp"], inp["tgt"], inp["src"], inp["T"], inp["K"], inp["inv_K"], inp["noise_used"],
+                   inp["mask_rec"], flags)
+    idl = np.moveaxis(ref_a["idl"], 1, -1)          # [B,H,W,S]
+    assert np.array_equal(N(ident), idl), "identity maps differ from the oracle's"
+
+    out = []
+    for handed in (ident, None):
+        d, Tt, fb = _flat(inp_b, dev, flags, ident=handed)
+        rb = ops.Units.apply(_cfg(1, flags), *fb)
+        rb[0].sum().backward()
+        out.append((float(rb[0][0].detach()), N(rb[2 + 1]), N(d.grad), N(Tt.grad), N(rb[2 + 0])))
+    for a, b, what in zip(out[0], out[1], ("loss", "argmin", "grad_disp", "grad_T", "auto_mask")):
+        assert np.array_equal(a, b), f"{what}: handed-over identity maps change the result"
+    ref_b = O.unit(inp_b["disp"], inp["tgt"], inp["src"], inp["T"], inp["K"], inp["inv_K"], inp_b["noise_used"],
+                   inp["mask_rec"], flags, want_grads=True)
+    am = out[0][1].astype(np.int32)
+    am[am == 255] = -1
+    assert np.array_equal(am, ref_b["idx"])
+    assert abs(out[0][0] - ref_b["loss"]) <= 1e-5 * abs(ref_b["loss"])
+    assert_grad_close(out[0][2], ref_b["grad_disp"], TOL, "grad_disp vs oracle (handed-over identity maps)")
+    assert rel_err(out[0][3], ref_b["grad_T"]) <= TOL
+
+
+def test_per_unit_upstream_gradients_and_repeatability(dev):
+    """backward() with a different upstream gradient per unit of a launch; two identical launches
+    give identical bits (the in-kernel folds do not depend on which workgroup arrives last); the
+    ticket counters are left zeroed."""
+    from mono_vifi_amd import ops
+    B, H, W = 3, 40, 100
+    inps = [_inputs(6100 + u, B, H, W, 0, u == 2) for u in range(3)]
+    wts = [0.5, 2.0, -1.25]
+
+    def run():
+        flat, leaves = [], []
+        for inp in inps:
+            d, Tt, f = _flat(inp, dev, 0)
+            flat += f
+            leaves.append((d, Tt))
+        res = ops.Units.apply(_cfg(3, 0), *flat)
+        sum(w * res[0][u] for u, w in enumerate(wts)).backward()
+        return [float(v) for v in res[0].detach()], [(N(d.grad), N(t.grad)) for d, t in leaves]
+
+    l1, g1 = run()
+    l2, g2 = run()
+    assert l1 == l2
+    for (a, b), (c, d) in zip(g1, g2):
+        assert np.array_equal(a, c) and np.array_equal(b, d)
+    for u, inp in enumerate(inps):
+        ref = O.unit(inp["disp"], inp["tgt"], inp["src"], inp["T"], inp["K"], inp["inv_K"], inp["noise_used"],
+                     inp["mask_rec"], 0, want_grads=True, gloss=wts[u])
+        assert abs(l1[u] - ref["loss"]) <= 1e-5 * abs(ref["loss"])
+        assert_grad_close(g1[u][0], ref["grad_disp"], TOL, f"unit {u} grad_disp (upstream {wts[u]})")
+        assert rel_err(g1[u][1], ref["grad_T"]) <= TOL
+    for t in ops._TICKETS.values():
+        assert int(t.abs().sum()) == 0, "ticket counters not left zeroed"
+
+
+def test_trainer_losses_batched_equal_unbatched(dev):
+    """HotPathLosses.compute_units (one launch, identity maps handed over) against one
+    compute_unit per entry: losses and gradients bit-equal for an injected noise tensor."""
+    from types import SimpleNamespace
+    from mono_vifi_amd.losses import HotPathLosses
+    B, H, W = 2, 64, 96
+    inps = [_inputs(7000 + u, B, H, W, 0, False) for u in range(3)]
+
+    class L(HotPathLosses):
+        pass
+    res = {}
+    for batched in (True, False):
+        s = L()
+        s.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False, avg_reprojection=False,
+                                disable_automasking=False, disparity_smoothness=1e-3, batch_units=batched)
+        s.tie_break_noise = T(inps[0]["noise_used"], dev)
+        units, leaves = [], []
+        for inp in inps:
+            d, Tt = T(inp["disp"], dev, True), T(inp["T"], dev, True)
+            units.append(dict(disp_tgt={("disp", 0): d}, img_tgt=T(inp["tgt"], dev), poses=Tt,
+                              imgs_src=[T(inp["src"][0], dev), T(inp["src"][1], dev)], K=T(inp["K"], dev),
+                              inv_K=T(inp["inv_K"], dev)))
+            leaves.append((d, Tt))
+        losses, idents, _ = s.compute_units(units, want_ident=batched)
+        assert (idents is not None) == batched
+        losses.sum().backward()
+        res[batched] = ([float(v) for v in losses.detach()], [(N(d.grad), N(t.grad)) for d, t in leaves])
+    assert res[True][0] == res[False][0]
+    for (a, b), (c, d) in zip(res[True][1], res[False][1]):
+        assert np.array_equal(a, c) and np.array_equal(b, d)
