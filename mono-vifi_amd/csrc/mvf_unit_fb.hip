@@ -875,7 +875,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 }
 
 // ---- finishing kernel: ONE launch for all units of a unit launch ------------------------------
-// block (unit, image): folds the image's tile partials (27 values x ntiles; tiles strided over 8
+// block (unit, image): folds the image's tile partials (27 values x ntiles; tiles strided over 32
 // slices in fp64, then the slices in order) into grad_T of both sources (= K^T [grad_P ; 0]),
 // stats[b] and the image's loss terms; the block of a unit that finishes LAST (device-scope
 // ticket) folds the images in index order into loss[3].  Every fold reads its inputs in index
@@ -885,9 +885,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 //  round: with release/acquire fences 545 us per unit instead of 102 -- buffer_wbl2 / buffer_inv
 //  act on the whole L2 --, with device-scope sc1 accesses instead of fences 107: every workgroup
 //  then waits for a write-through and a ticket round trip while it holds 40 KB of LDS.)
-__global__ void __launch_bounds__(256) k_units_finish(FbArgs a, int S)
+constexpr int FIN_SLICES = 32;          // tile slices per (unit, image) block: 32 values x 32 slices = 1024 lanes
+constexpr int FIN_UNROLL = 4;           // independent loads in flight per lane
+__global__ void __launch_bounds__(32 * FIN_SLICES) k_units_finish(FbArgs a, int S)
 {
-    __shared__ double red[8 * 32];
+    __shared__ double red[FIN_SLICES * 32];
     __shared__ int s_last;
     const int ub = blockIdx.x, unit = ub / a.B, b = ub - unit * a.B;
     const UnitArgs &u = a.u[unit];
@@ -903,15 +905,27 @@ __global__ void __launch_bounds__(256) k_units_finish(FbArgs a, int S)
         if (q < 12) { srcp = a.gp_ws + ((size_t)ub * ntiles) * 12 + q; stride = 12; }
         else if (q < 24) { srcp = a.gp_ws + ((UB + ub) * ntiles) * 12 + (q - 12); stride = 12; }
         else { srcp = a.part + ((size_t)ub * ntiles) * NPART + (q - 24); stride = NPART; }
-        if (q < 12 || q >= 24 || S > 1)
-            for (size_t t = slice; t < ntiles; t += 8) acc += (double)srcp[t * stride];
+        if (q < 12 || q >= 24 || S > 1) {
+            // a lane's tiles slice, slice + 32, ...: FIN_UNROLL loads issued before the first add (the
+            // round-2 form walked 39 tiles per lane one exposed memory latency at a time: 17 us)
+            for (size_t t0 = slice; t0 < ntiles; t0 += (size_t)FIN_SLICES * FIN_UNROLL) {
+                float v[FIN_UNROLL];
+#pragma unroll
+                for (int k = 0; k < FIN_UNROLL; ++k) {
+                    const size_t t = t0 + (size_t)k * FIN_SLICES;
+                    v[k] = (t < ntiles) ? srcp[t * stride] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < FIN_UNROLL; ++k) acc += (double)v[k];
+            }
+        }
     }
     red[slice * 32 + q] = acc;
     __syncthreads();
     if (threadIdx.x < 32) {
         double v = 0.0;
 #pragma unroll
-        for (int sl = 0; sl < 8; ++sl) v += red[sl * 32 + q];
+        for (int sl = 0; sl < FIN_SLICES; ++sl) v += red[sl * 32 + q];
         red[q] = v;          // slice 0's row now holds the totals (each lane wrote only its own q)
     }
     __syncthreads();
@@ -1087,7 +1101,7 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
         else if (!avg) hipLaunchKernelGGL((k_unit_fb<2, false>), grid, dim3(NT), fb_smem(), st, a);
         else hipLaunchKernelGGL((k_unit_fb<2, true>), grid, dim3(NT), fb_smem(), st, a);
     }
-    hipLaunchKernelGGL(k_units_finish, dim3((unsigned)(n_units * B)), dim3(256), 0, st, a, S);
+    hipLaunchKernelGGL(k_units_finish, dim3((unsigned)(n_units * B)), dim3(32 * FIN_SLICES), 0, st, a, S);
     return hip_check_launch();
 }
 

@@ -345,12 +345,15 @@ class LossesBase(torch.autograd.Function):
         ctx.save_for_backward(disp, tgt, mask_rec, argmin, stats, *warped)
         ctx.cfg = (S, flags, smoothness)
         ctx.mark_non_differentiable(auto_mask, to_opt, argmin)
+        ctx.set_materialize_grads(False)     # no zero tensors for the three maps in backward()
         return loss[0], auto_mask, to_opt, argmin
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
         disp, tgt, mask_rec, argmin, stats, *warped = ctx.saved_tensors
         S, flags, smoothness = ctx.cfg
+        if g_loss is None:
+            return (None,) * (7 + 2 * S)
         B, _, H, W = disp.shape
         g_loss = _c(g_loss).reshape(1)
         g_warped = [torch.empty_like(w) for w in warped]
@@ -510,12 +513,18 @@ class Units(torch.autograd.Function):
         ctx.n, ctx.S, ctx.smoothness, ctx.per, ctx.needs = n, S, smoothness, per, needs
         res = (loss3[:, 0], loss3[:, 1:], *outs)
         ctx.mark_non_differentiable(*res[1:])
+        # the engine would otherwise hand backward() a ZERO tensor for every output that received no
+        # gradient -- argmin (uint8 [B,H,W]), the identity maps, ... : 16 fill launches per step
+        # (profiles/r03_hotpath_kernel_stats_before_nomaterialize.csv: 747 + 581 fills in 83 steps)
+        ctx.set_materialize_grads(False)
         return res
 
     @staticmethod
     def backward(ctx, g_losses, *_unused):
         # raw gradients for an upstream gradient of 1; one pass applies the per-image constant of
         # the mean-normalised smoothness term and each unit's upstream gradient
+        if g_losses is None:
+            return (None,) * (1 + ctx.n * ctx.per)
         g_raw, gT_raw, stats = ctx.saved_tensors
         n, S = ctx.n, ctx.S
         _, B, _, H, W = g_raw.shape
@@ -598,12 +607,15 @@ class _UnitStaged(torch.autograd.Function):
         outs = [loss[0], auto_mask if want_mask else torch.empty(0, device=dev), argmin,
                 idx if want_idx else torch.empty(0, device=dev), loss[1:]]
         ctx.mark_non_differentiable(*outs[1:])
+        ctx.set_materialize_grads(False)     # no zero tensors for the outputs without a gradient
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, g_loss, *_unused):
         disp, tgt, T, K, inv_K, mask_rec, argmin, stats, *src = ctx.saved_tensors
         S, flags, smoothness, md, rg, eps = ctx.cfg
+        if g_loss is None:
+            return (None,) * (8 + S)
         B, _, H, W = disp.shape
         g_loss = _c(g_loss).reshape(1)
         g_disp = torch.empty_like(disp)
@@ -1003,13 +1015,19 @@ class DispHead(torch.autograd.Function):
         ctx.save_for_backward(disp)
         ctx.consts = (md, rg)
         ctx.mark_non_differentiable(part)
+        # no zero tensors for outputs without a gradient: `part` never has one, and a decoder output whose
+        # depth is unused would otherwise hand backward() a full-size zero g_depth (a fill launch, and a
+        # plane the adjoint kernel then reads)
+        ctx.set_materialize_grads(False)
         return disp, (depth if want_depth else torch.empty(0, device=logit.device)), part
 
     @staticmethod
     def backward(ctx, g_disp, g_depth, _g_part):
         (disp,) = ctx.saved_tensors
         md, rg = ctx.consts
-        g_disp = _c(g_disp)
+        if g_disp is None and g_depth is None:
+            return None, None, None, None
+        g_disp = _c(g_disp) if g_disp is not None else torch.zeros_like(disp)
         g_depth = _c(g_depth) if (g_depth is not None and g_depth.numel() == disp.numel()) else None
         g = torch.empty_like(disp)
         nat.check(nat.lib().mvf_disp_head_bwd(nat.ptr(disp), nat.ptr(g_disp), nat.ptr(g_depth), nat.ptr(g),

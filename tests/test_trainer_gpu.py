@@ -300,6 +300,13 @@ def _rccl_worker(port, log_dir, q):
         calls["all_gather"] += 1
         return real_ag(*a, **k)
     out = {}
+    # forward invocations per BatchNorm layer in the forced pass: with grouped invocation a layer runs once
+    # per GROUPED call (the 8 depth-encoder / 6 pose-encoder calls of a step interleaved), not once per call
+    from mono_vifi_amd import parallel
+    bn_calls = {id(m): 0 for m in bns}
+    hooks = [m.register_forward_hook(lambda mod, *_: bn_calls.__setitem__(id(mod), bn_calls[id(mod)] + 1))
+             for m in bns]
+    counted = None
     for forced in (True, False):
         for k, m in t.models.items():
             m.load_state_dict(state0[k])
@@ -308,6 +315,10 @@ def _rccl_worker(port, log_dir, q):
             m.force_sync = forced
         if forced:
             dist.all_reduce, dist.all_gather_into_tensor = ar, ag
+            parallel.reset_comm_counts()
+        else:
+            for h in hooks:
+                h.remove()
         try:
             _, losses = t.process_batch(dict(batch))
             t.reducer.zero_grad()
@@ -316,14 +327,20 @@ def _rccl_worker(port, log_dir, q):
         finally:
             dist.all_reduce, dist.all_gather_into_tensor = real_ar, real_ag
         torch.cuda.synchronize()
+        if forced:
+            counted = parallel.comm_counts()
         bufs = torch.cat([b.flatten().float() for m in t._modules_unique.values() for b in m.buffers()])
         out[forced] = (float(losses["loss"]),
                        torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone(), bufs.clone())
     dl = abs(out[True][0] - out[False][0]) / abs(out[False][0])
     dg = float((out[True][1] - out[False][1]).norm() / out[False][1].norm())
     db = bool(torch.allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-5))
+    def layers_of(name):
+        return [m for m in t.models[name].modules() if isinstance(m, grouped.GroupedBatchNorm2d)]
+    per_layer = {name: sorted({bn_calls[id(m)] for m in layers_of(name)}) for name in ("encoder", "pose_encoder")}
     q.put((dl, dg, db, calls["all_reduce"], calls["all_gather"], t.reducer.num_buckets,
-           dist.get_backend()))
+           dist.get_backend(), sum(bn_calls.values()), counted, per_layer,
+           {name: len(layers_of(name)) for name in per_layer}))
     dist.destroy_process_group()
 
 
@@ -339,8 +356,20 @@ def test_rccl_collectives_on_one_gpu(tmp_path):
     p.start()
     p.join(900)
     assert p.exitcode == 0
-    dl, dg, same_bufs, n_ar, n_ag, n_buckets, backend = q.get(timeout=10)
+    dl, dg, same_bufs, n_ar, n_ag, n_buckets, backend, bn_invocations, counted, per_layer, n_layers = \
+        q.get(timeout=10)
     assert backend == "nccl"
-    assert n_ar >= n_buckets            # every gradient bucket went through RCCL
-    assert n_ar + n_ag > n_buckets      # and the SyncBatchNorm layers issued theirs
+    # EXACT collective counts of one step ("~40 instead of 280 per direction"):
+    # forward: one all-gather per BatchNorm layer per GROUPED call; backward: one all-reduce per such
+    # invocation + one per gradient bucket; nothing else
+    assert n_ag == bn_invocations == counted["bn_all_gather"]
+    assert n_ar == bn_invocations + n_buckets
+    assert counted["bn_all_reduce"] == bn_invocations and counted["grad_all_reduce"] == n_buckets
+    assert set(counted) == {"bn_all_gather", "bn_all_reduce", "grad_all_reduce"}
+    # the ResNet18 depth encoder (shared_encoder: 8 calls per step in the reference, train.py:745-868) and
+    # the pose encoder (6 calls, train.py:724-731) each run as ONE grouped call: 20 + 20 = 40 collectives
+    # per direction where the per-call form issues 20 x 8 + 20 x 6 = 280
+    assert n_layers == {"encoder": 20, "pose_encoder": 20}
+    assert per_layer == {"encoder": [1], "pose_encoder": [1]}
+    assert bn_invocations == 40
     assert dl <= 1e-5 and dg <= 2e-3 and same_bufs
