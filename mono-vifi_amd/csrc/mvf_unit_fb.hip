@@ -49,6 +49,9 @@
 #ifndef MVF_FB_TH
 #define MVF_FB_TH 16
 #endif
+#ifndef MVF_FB_PACKROWS
+#define MVF_FB_PACKROWS 1     // tap rows x weight pairs as packed multiplies (0: scalar products; timing variant)
+#endif
 #define MVF_TILE_TW MVF_FB_TW
 #define MVF_TILE_PX MVF_FB_PX
 #define MVF_TILE_TH MVF_FB_TH
@@ -100,22 +103,28 @@ inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(PoseLds) + MVF
 // keyed by (seed, element index): two rounds of a 32-bit avalanche hash per uniform, Box-Muller
 // for the pair of identity candidates of a pixel.  A tie-breaker, not a statistics engine; the
 // draw can be written out (noise_out) so that a test can replay it through the oracle.
-MVF_DEV uint32_t mix32(uint32_t x)
+// One 32-bit avalanche hash per pixel (two xorshift-multiply rounds, the second keyed by seed1) gives
+// both uniforms: 16 bits each -- 65,536 radius levels up to 4.7 sigma and 65,536 angles, ample for a
+// tie-breaker scaled by 1e-5.  The transcendental steps are the hardware's own: v_log_f32 (base 2),
+// v_sqrt_f32, v_sin_f32 / v_cos_f32 (argument in revolutions, so u2 goes in as it is).  Round 2 drew
+// two hashes (four quarter-rate 32-bit multiplies) and went through libm's sqrtf / sincosf (correctly
+// rounded square root, range reduction for arguments that never exceed 2 pi): ~50 instructions per pixel
+// more for the same purpose.
+MVF_DEV uint32_t mix32(uint32_t x, uint32_t key)
 {
     x ^= x >> 16; x *= 0x7feb352dU;
+    x ^= key;
     x ^= x >> 15; x *= 0x846ca68bU;
     x ^= x >> 16;
     return x;
 }
 MVF_DEV f2 normal_pair(uint32_t seed0, uint32_t seed1, uint32_t idx)
 {
-    const uint32_t a = mix32(idx * 2u + seed0), bq = mix32((idx * 2u + 1u) ^ seed1);
+    const uint32_t a = mix32(idx + seed0, seed1);
     // u1 in (0,1], u2 in [0,1)
-    const float u1 = ((float)(a >> 8) + 1.0f) * 0x1p-24f, u2 = (float)(bq >> 8) * 0x1p-24f;
-    const float r = __builtin_sqrtf(-2.0f * __logf(u1));
-    float sn, cs;
-    __sincosf(6.28318530717958647692f * u2, &sn, &cs);
-    return mk2(r * cs, r * sn);
+    const float u1 = ((float)(a >> 16) + 1.0f) * 0x1p-16f, u2 = (float)(a & 0xffffu) * 0x1p-16f;
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1)
+    return mk2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
 }
 
 // SSIM value (exact: reference layers.py:281-290, literal order) AND its x-side partial
@@ -265,13 +274,19 @@ struct WarpCtx {
     int H, W, py0, px0, oy0, ox0;
     float min_disp, range, eps;
     int32_t *idx_a, *idx_b;
+    bool inner;        // the staged plane lies inside the image: no reflect mapping (workgroup-uniform)
 };
 
-// one batch of U plane positions: chain + tap loads issued (issue), bilinear combine + store (finish)
+// one batch of U plane positions: chain + tap loads issued (issue), bilinear combine + store (finish).
+// The tap rows stay the 8-byte pairs they were loaded as: (west, east) x (west weight, east weight)
+// is ONE packed multiply per row, and the right-border case (pair anchored one pixel left, both taps
+// its second element, east weight 0 there) becomes a swap of the WEIGHT pair -- once per source and
+// position instead of two selects per channel.  Same products, same left-to-right sum:
+// nw*wnw + ne*wne + sw*wsw + se*wse, with exact zeros where a weight is 0.
 template <int U>
 struct WarpBatch {
     WarpSlot s[U];
-    float a[U][3][4], bq[U][3][4];
+    float2 a0[U][3], a1[U][3], b0[U][3], b1[U][3];     // rows y0 / y1 of source a / b
 };
 
 #ifdef MVF_ABL_FB_LDSTAPS
@@ -291,20 +306,33 @@ MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
 #pragma unroll
     for (int u = 0; u < U; ++u)
         w.s[u] = warp_slot((int)threadIdx.x + (slot0 + u) * NT, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0,
-                           k.min_disp, k.range, k.eps);
+                           k.min_disp, k.range, k.eps, k.inner);
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
 #ifdef MVF_ABL_FB_LDSTAPS   // timing ablation: every tap pair from an LDS plane (upper bound of what an
                            // LDS-staged source window could gain -- at NO cost in LDS capacity)
-            lds_taps(k.dispP, w.s[u].x0a - k.px0, w.s[u].y0a - k.py0, ch, w.a[u][ch]);
-            lds_taps(k.dispP, w.s[u].x0b - k.px0, w.s[u].y0b - k.py0, ch, w.bq[u][ch]);
+            float ta[4], tb[4];
+            lds_taps(k.dispP, w.s[u].x0a - k.px0, w.s[u].y0a - k.py0, ch, ta);
+            lds_taps(k.dispP, w.s[u].x0b - k.px0, w.s[u].y0b - k.py0, ch, tb);
+            w.a0[u][ch] = make_float2(ta[0], ta[1]); w.a1[u][ch] = make_float2(ta[2], ta[3]);
+            w.b0[u][ch] = make_float2(tb[0], tb[1]); w.b1[u][ch] = make_float2(tb[2], tb[3]);
 #else
-            load_taps(k.sa + ch * N, w.s[u].qa.q, w.a[u][ch][0], w.a[u][ch][1], w.a[u][ch][2], w.a[u][ch][3]);
-            load_taps(k.sb + ch * N, w.s[u].qb.q, w.bq[u][ch][0], w.bq[u][ch][1], w.bq[u][ch][2], w.bq[u][ch][3]);
+            w.a0[u][ch] = ldg2_at(k.sa + ch * N, w.s[u].qa.q.o0);
+            w.a1[u][ch] = ldg2_at(k.sa + ch * N, w.s[u].qa.q.o1);
+            w.b0[u][ch] = ldg2_at(k.sb + ch * N, w.s[u].qb.q.o0);
+            w.b1[u][ch] = ldg2_at(k.sb + ch * N, w.s[u].qb.q.o1);
 #endif
         }
+}
+
+// (west, east) weight pairs of the two tap rows; at the right border the pair sits one pixel left
+// of x0 and the tap is its second element (whose partner weight is exactly 0 there: wx == 0)
+MVF_DEV void row_weights(const Taps4 &q, f2 &top, f2 &bot)
+{
+    top = q.q.sh ? mk2(0.0f, q.wnw) : mk2(q.wnw, q.wne);
+    bot = q.q.sh ? mk2(0.0f, q.wsw) : mk2(q.wsw, q.wse);
 }
 
 template <int U>
@@ -313,13 +341,20 @@ MVF_DEV void warp_finish(const WarpCtx &k, const WarpBatch<U> &w)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         if (!w.s[u].live) continue;
-        const Taps4 &qa = w.s[u].qa, &qb = w.s[u].qb;
+        f2 wat, wab, wbt, wbb;
+        row_weights(w.s[u].qa, wat, wab);
+        row_weights(w.s[u].qb, wbt, wbb);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            float va = w.a[u][ch][0] * qa.wnw + w.a[u][ch][1] * qa.wne + w.a[u][ch][2] * qa.wsw +
-                       w.a[u][ch][3] * qa.wse;
-            float vb = w.bq[u][ch][0] * qb.wnw + w.bq[u][ch][1] * qb.wne + w.bq[u][ch][2] * qb.wsw +
-                       w.bq[u][ch][3] * qb.wse;
+#if MVF_FB_PACKROWS
+            const f2 ta = mk2(w.a0[u][ch].x, w.a0[u][ch].y) * wat, ba = mk2(w.a1[u][ch].x, w.a1[u][ch].y) * wab;
+            const f2 tb = mk2(w.b0[u][ch].x, w.b0[u][ch].y) * wbt, bb = mk2(w.b1[u][ch].x, w.b1[u][ch].y) * wbb;
+            const float va = ((ta.x + ta.y) + ba.x) + ba.y;
+            const float vb = ((tb.x + tb.y) + bb.x) + bb.y;
+#else
+            const float va = w.a0[u][ch].x * wat.x + w.a0[u][ch].y * wat.y + w.a1[u][ch].x * wab.x + w.a1[u][ch].y * wab.y;
+            const float vb = w.b0[u][ch].x * wbt.x + w.b0[u][ch].y * wbt.y + w.b1[u][ch].x * wbb.x + w.b1[u][ch].y * wbb.y;
+#endif
             k.pairP[ch * PPLANE + w.s[u].r * LDW + w.s[u].c] = mk2(va, vb);
         }
         if (k.idx_a) {
@@ -416,11 +451,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
 
     // ---- 1: target, disparity (and the identity pair) -> LDS
+    // tiles whose staged plane lies inside the image need no reflect / clamp mapping of the
+    // coordinates they stage and warp (scalar branch; 240 of 308 tiles at 640x192)
+    const bool inner = (py0 >= 0) && (px0 >= 0) && (py0 + PH <= H) && (px0 + PW <= W);
     if (automask && !ident_given) {
-        stage_first(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, H, W, py0, px0);
+        stage_first(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, H, W, py0, px0, inner);
     } else {
-        stage_planes3(tgtP, tgt_b, N, H, W, py0, px0);
-        stage_plane(dispP, disp_b, H, W, py0, px0);
+        stage_planes3(tgtP, tgt_b, N, H, W, py0, px0, inner);
+        stage_plane(dispP, disp_b, H, W, py0, px0, inner);
     }
     __syncthreads();
 
@@ -436,6 +474,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         k.min_disp = a.min_disp; k.range = a.range; k.eps = a.eps;
         k.idx_a = u.idx_xy ? u.idx_xy + ((size_t)b) * N * 2 : nullptr;
         k.idx_b = u.idx_xy ? u.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
+        k.inner = inner;
     }
 
     // ---- 2: identity candidates of every region pixel
@@ -783,9 +822,9 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             const WarpPair w = warp_point_pair(dispP[e], iK, P2, xx, yy, H, W, a.min_disp,
                                                a.range, a.eps);
             float dxa[3], dya[3], dxb[3], dyb[3];
+#ifdef MVF_ABL_FB_LDSTAPS
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
-#ifdef MVF_ABL_FB_LDSTAPS
                 float ta4[4], tb4[4];
                 lds_taps(dispP, w.ta.x0 - px0, w.ta.y0 - py0, ch, ta4);
                 lds_taps(dispP, w.tb.x0 - px0, w.tb.y0 - py0, ch, tb4);
@@ -793,11 +832,39 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 dya[ch] = (ta4[2] - ta4[0]) * (1.0f - w.ta.wx) + (ta4[3] - ta4[1]) * w.ta.wx;
                 dxb[ch] = (tb4[1] - tb4[0]) * (1.0f - w.tb.wy) + (tb4[3] - tb4[2]) * w.tb.wy;
                 dyb[ch] = (tb4[2] - tb4[0]) * (1.0f - w.tb.wx) + (tb4[3] - tb4[1]) * w.tb.wx;
-#else
-                bilerp_grad(sa + ch * N, W, w.ta, dxa[ch], dya[ch]);
-                bilerp_grad(sb + ch * N, W, w.tb, dxb[ch], dyb[ch]);
-#endif
             }
+#else
+            {
+                // the tap rows as the 8-byte pairs they are loaded as: d/dy of the bilinear sample is
+                // (row1 - row0) . (e, w) -- one packed subtract and one packed multiply per channel; at
+                // the right border (pair anchored one pixel left, both taps its second element, w == 0)
+                // the weight pair is swapped instead of selecting taps.  d/dx there is masked by `inx`.
+                const TapRows qa = taprows_of(w.ta, W), qb = taprows_of(w.tb, W);
+                float2 ra0[3], ra1[3], rb0[3], rb1[3];
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    ra0[ch] = ldg2_at(sa + ch * N, qa.o0); ra1[ch] = ldg2_at(sa + ch * N, qa.o1);
+                    rb0[ch] = ldg2_at(sb + ch * N, qb.o0); rb1[ch] = ldg2_at(sb + ch * N, qb.o1);
+                }
+                const float na = w.ta.wy, sna = 1.0f - na, nb = w.tb.wy, snb = 1.0f - nb;
+                const f2 ewa = qa.sh ? mk2(w.ta.wx, 1.0f - w.ta.wx) : mk2(1.0f - w.ta.wx, w.ta.wx);
+                const f2 ewb = qb.sh ? mk2(w.tb.wx, 1.0f - w.tb.wx) : mk2(1.0f - w.tb.wx, w.tb.wx);
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    dxa[ch] = (ra0[ch].y - ra0[ch].x) * sna + (ra1[ch].y - ra1[ch].x) * na;
+                    dxb[ch] = (rb0[ch].y - rb0[ch].x) * snb + (rb1[ch].y - rb1[ch].x) * nb;
+#if MVF_FB_PACKROWS
+                    const f2 va = (mk2(ra1[ch].x, ra1[ch].y) - mk2(ra0[ch].x, ra0[ch].y)) * ewa;
+                    const f2 vb = (mk2(rb1[ch].x, rb1[ch].y) - mk2(rb0[ch].x, rb0[ch].y)) * ewb;
+                    dya[ch] = va.x + va.y;
+                    dyb[ch] = vb.x + vb.y;
+#else
+                    dya[ch] = (ra1[ch].x - ra0[ch].x) * ewa.x + (ra1[ch].y - ra0[ch].y) * ewa.y;
+                    dyb[ch] = (rb1[ch].x - rb0[ch].x) * ewb.x + (rb1[ch].y - rb0[ch].y) * ewb.y;
+#endif
+                }
+            }
+#endif
             const f2 gix = g0 * mk2(dxa[0], dxb[0]) + g1 * mk2(dxa[1], dxb[1]) + g2 * mk2(dxa[2], dxb[2]);
             const f2 giy = g0 * mk2(dya[0], dyb[0]) + g1 * mk2(dya[1], dyb[1]) + g2 * mk2(dya[2], dyb[2]);
             // adjoint of unnormalise / normalise ((W-1)/2 * 2/(W-1) = 1) and of the perspective

@@ -608,37 +608,57 @@ MVFO_API void mvfo_smooth_bwd(const float *disp, const float *img, float *gdisp,
             for (long i = 0; i < N; ++i) m += d[i];
             denom = (float)(m / (double)N) + 1e-7f;
         }
-        memset(gn, 0, sizeof(float) * N);
+        /* Gather form of the scatter `gn[i] += g; gn[i+1] -= g` (x term of pixel i) and
+         * `gn[i] += g; gn[i+W] -= g` (y term): pixel i receives, in the scatter's own order,
+         * -gy(i-W), -gx(i-1), +gx(i), +gy(i) -- the same additions in the same order, so the same
+         * bits, and every pixel is independent (parallel over rows; the scatter was serial). */
+#pragma omp parallel for schedule(static)
         for (int y = 0; y < H; ++y)
             for (int x = 0; x < W; ++x) {
                 long i = (long)y * W + x;
+                float acc = 0.0f;
+                if (y >= 1) {           /* y term of pixel i - W */
+                    long j = i - W;
+                    float df = d[j] / denom - d[i] / denom;
+                    float gi = ((fabsf(im[j] - im[i]) + fabsf(im[N + j] - im[N + i])) +
+                                fabsf(im[2 * N + j] - im[2 * N + i])) / 3.0f;
+                    float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+                    acc -= (float)cy * expf(-gi) * sg;
+                }
+                if (x >= 1) {           /* x term of pixel i - 1 */
+                    long j = i - 1;
+                    float df = d[j] / denom - d[i] / denom;
+                    float gi = ((fabsf(im[j] - im[i]) + fabsf(im[N + j] - im[N + i])) +
+                                fabsf(im[2 * N + j] - im[2 * N + i])) / 3.0f;
+                    float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+                    acc -= (float)cx * expf(-gi) * sg;
+                }
                 float nd = d[i] / denom;
                 if (x + 1 < W) {
                     float df = nd - d[i + 1] / denom;
                     float gi = ((fabsf(im[i] - im[i + 1]) + fabsf(im[N + i] - im[N + i + 1])) +
                                 fabsf(im[2 * N + i] - im[2 * N + i + 1])) / 3.0f;
                     float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
-                    float g = (float)cx * expf(-gi) * sg;
-                    gn[i] += g;
-                    gn[i + 1] -= g;
+                    acc += (float)cx * expf(-gi) * sg;
                 }
                 if (y + 1 < H) {
                     float df = nd - d[i + W] / denom;
                     float gi = ((fabsf(im[i] - im[i + W]) + fabsf(im[N + i] - im[N + i + W])) +
                                 fabsf(im[2 * N + i] - im[2 * N + i + W])) / 3.0f;
                     float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
-                    float g = (float)cy * expf(-gi) * sg;
-                    gn[i] += g;
-                    gn[i + W] -= g;
+                    acc += (float)cy * expf(-gi) * sg;
                 }
+                gn[i] = acc;
             }
         if (normalise) {
             /* nd = d/denom, denom = mean+eps : g_d = gn/denom - (sum gn*d)/denom^2 / N */
             double dot = 0.0;
             for (long i = 0; i < N; ++i) dot += (double)gn[i] * d[i];
             float corr = (float)(dot / ((double)denom * denom) / (double)N);
+#pragma omp parallel for schedule(static)
             for (long i = 0; i < N; ++i) gdisp[b * N + i] += gn[i] / denom - corr;
         } else {
+#pragma omp parallel for schedule(static)
             for (long i = 0; i < N; ++i) gdisp[b * N + i] += gn[i];
         }
     }
@@ -735,11 +755,20 @@ MVFO_API void mvfo_losses_base_bwd(const float *tgt, const float *const *warped,
     for (int k = 0; k < S; ++k) {
         float *gw = gwarped[k];
         memset(gw, 0, sizeof(float) * B * 3 * N);
-#pragma omp parallel for schedule(static)
-        for (int bc = 0; bc < B * 3; ++bc) {
+        /* The 3x3 scatter of a pixel reaches one row up and down, so row bands of one colour (every
+         * second band) never touch the same row: all (plane, band) tasks of a colour run in parallel
+         * (the per-plane loop alone stopped scaling at B*3 = 36 threads).  Within a row the additions
+         * keep the sequential order; a band's first row receives its upper neighbour's contribution
+         * after its own instead of before (gradients are tolerance-level quantities). */
+        const int BAND = 8, nband = (H + BAND - 1) / BAND;
+        for (int colour = 0; colour < 2; ++colour) {
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+        for (int bc = 0; bc < B * 3; ++bc)
+        for (int band = colour; band < nband; band += 2) {
             int b = bc / 3, c = bc % 3;
             const float *xb = warped[k] + bc * N, *yb = tgt + bc * N;
-            for (int py = 0; py < H; ++py)
+            int py_end = (band + 1) * BAND < H ? (band + 1) * BAND : H;
+            for (int py = band * BAND; py < py_end; ++py)
                 for (int px = 0; px < W; ++px) {
                     long i = (long)py * W + px;
                     int sel = idx ? idx[b * N + i] : -1;
@@ -769,6 +798,8 @@ MVFO_API void mvfo_losses_base_bwd(const float *tgt, const float *const *warped,
                         }
                     }
                 }
+            (void)c;
+        }
         }
     }
 }
