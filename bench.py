@@ -353,7 +353,7 @@ def cpu_baseline(args):
     # parallel regions cover (image x row band) / (plane x row band) tasks since round 3 (its adjoint was
     # 36-way parallel and the smoothness adjoint serial: 16 of 256 cores was the optimum)
     best = (float("inf"), 1)
-    for nt in sorted({c for c in (8, 16, 32, 64, 128, host_cores) if c <= host_cores}):
+    for nt in sorted({c for c in (8, 16, 32, 64) if c <= host_cores}):      # beyond 64 threads every run got slower (measured)
         O.set_threads(nt)
         one()
         t0 = time.perf_counter()
@@ -401,7 +401,7 @@ def cpu_baseline_unfused(args):
     old = torch.get_num_threads()
     best = (float("inf"), 1)
     try:
-        for nt in sorted({c for c in (16, 32, 64, host_cores) if c <= host_cores} or {host_cores}):
+        for nt in sorted({c for c in (16, 32, 64) if c <= host_cores} or {host_cores}):
             torch.set_num_threads(nt)
             one()
             t0 = time.perf_counter()

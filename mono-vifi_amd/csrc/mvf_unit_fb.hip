@@ -50,7 +50,9 @@
 #define MVF_FB_TH 16
 #endif
 #ifndef MVF_FB_PACKROWS
-#define MVF_FB_PACKROWS 1     // tap rows x weight pairs as packed multiplies (0: scalar products; timing variant)
+#define MVF_FB_PACKROWS 0     // 1: tap rows x weight pairs as packed multiplies.  Measured (profiles/r03_unit_kernel_variants.log):
+                              // +0.8 % VALU instructions -- the compiler pairs the sums of the two sources instead and
+                              // pays register moves either way; the scalar products with the swapped weight pair win
 #endif
 #define MVF_TILE_TW MVF_FB_TW
 #define MVF_TILE_PX MVF_FB_PX
