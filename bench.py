@@ -48,6 +48,10 @@ if ROOT not in sys.path:
 for _d in ("FWD", "BWD", "WRW"):
     os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _d, "0")
 
+# before torch: importing the package puts the shipped MIOpen find-db and DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
+# (whole-step HIP graphs) into the environment; the HIP runtime reads the latter at its
+# first call
+import mono_vifi_amd  # noqa: E402,F401
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -96,10 +100,12 @@ def parse():
                     help="train workload: the timed steps replay the whole optimisation step as ONE "
                          "HIP graph (trainer --hip_graph); the unit kernel's events cannot be recorded "
                          "inside a graph, so `roofline` then comes from the hot-path-only leg")
-    ap.add_argument("--graph-leg", dest="graph_leg", action="store_true",
-                    help="train workload: add a HIP-graph measurement of the step as an extra object "
-                         "(opt-in: at the full BASELINE shapes the replay of a captured step faulted on "
-                         "ROCm 7.2 -- DESIGN.md section 7 -- and a GPU memory fault cannot be caught)")
+    ap.add_argument("--hip-graph-scope", dest="hip_graph_scope", default="step", choices=["step", "backward"],
+                    help="what --hip-graph / --graph-leg capture (trainer --hip_graph_scope)")
+    ap.add_argument("--no-graph-leg", dest="graph_leg", action="store_false", default=True,
+                    help="train workload, N = 1: skip the HIP-graph measurement of the step (`hip_graph_step`, "
+                         "run in a child process under a timeout: a fault or hang of a replay cannot be caught "
+                         "and must not take the line down)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-batch-units", dest="no_batch_units", action="store_true",
                     help="one launch per unit (round-2 launch structure) instead of one per group of three")
@@ -149,7 +155,9 @@ def launch_ranks_if_needed(args):
     import subprocess
     if args.workload != "mock":
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
-        if have < args.gpus:
+        # MVF_BENCH_SHARE_GPU=1: plumbing test only (tests/test_bench_launch.py: two gloo ranks on the one
+        # GPU of the test box); RCCL needs one GPU per rank and comm_report refuses shared devices under it
+        if have < args.gpus and not (have > 0 and os.environ.get("MVF_BENCH_SHARE_GPU") == "1"):
             sys.exit(f"[bench] --gpus {args.gpus} needs {args.gpus} GPUs (one process per GPU); this "
                      f"box has {have}.  Not running {args.gpus} ranks on fewer devices.")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
@@ -574,29 +582,34 @@ def hotpath_leg(args, rank, dev, nat, steps=20, warmup=5):
             "roofline": dom, "hip_graph_replay": graph_replay_leg(step)}
 
 
-def graph_step_leg(args, rank, world, dev, steps=20):
+def graph_step_leg(args, steps=20, timeout_s=150):
     """The same optimisation step with its device work captured into ONE HIP graph
-    (mono-vifi_amd/trainer.py:_StepGraph) and replayed: extra to the eager, event-timed figure."""
+    (mono-vifi_amd/trainer.py:_StepGraph) and replayed: extra to the eager, event-timed headline.  Runs as a
+    CHILD process (this script with --hip-graph): a GPU fault or a hang during a replay cannot be caught and
+    must not take the headline line down."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "train", "--hip-graph",
+           "--hip-graph-scope", args.hip_graph_scope, "--steps", str(steps), "--warmup", "6", "--no-cpu-baseline",
+           "--no-hotpath-leg", "--also-configs", "none", "--no-graph-leg", "--batch", str(args.batch), "--height",
+           str(args.height), "--width", str(args.width), "--backbone", args.backbone]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.perf_counter()
     try:
-        import copy
-        from mono_vifi_amd.bench_train import TrainStep
-        a = copy.copy(args)
-        a.hip_graph = True
-        step = TrainStep(a, rank, world, dev)
-        for _ in range(step.trainer._step_graph.WARMUP + 3):
-            step()
-        assert step.trainer._step_graph.graph is not None
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        return {"value": round(step.images_per_step * steps / dt, 2), "unit": "images/sec",
-                "ms_per_step": round(dt / steps * 1e3, 4), "steps": steps,
-                "note": "whole optimisation step (networks, 9 units, backward, clip, AdamW) replayed as one "
-                        "HIP graph per step; tie-break noise from torch.randn (graph-safe) instead of the "
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return {"error": f"child rc {r.returncode}: " + (r.stderr.strip().splitlines() or [""])[-1][:200]}
+        d = json.loads(lines[-1])
+        return {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                "scope": args.hip_graph_scope, "leg_seconds": round(time.perf_counter() - t0, 1),
+                "note": "the optimisation step replayed as one HIP graph per step (networks, 9 units, backward, "
+                        "gradient exchange" + (", clipping, capturable AdamW" if args.hip_graph_scope == "step" else
+                                               "; clipping + AdamW eager") +
+                        "), measured in a child process with the HIP runtime's graph packet capture off "
+                        "(DESIGN.md section 7); tie-break noise from torch.randn (graph-safe) instead of the "
                         "in-kernel generator"}
+    except subprocess.TimeoutExpired:
+        return {"error": f"child did not finish within {timeout_s} s (killed)"}
     except Exception as e:      # noqa: BLE001 -- an optional leg must never take the bench line down
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
@@ -738,10 +751,6 @@ def main():
             {"skipped": "time budget"}
 
     graph_leg = None
-    if workload == "train" and rank == 0 and world == 1 and not args.hip_graph and args.graph_leg:
-        del step.trainer        # the eager trainer's activations are not needed any more
-        torch.cuda.empty_cache()
-        graph_leg = graph_step_leg(args, rank, world, dev)
     if args.hip_graph and workload == "train" and dominant is None and hotpath_only and hotpath_only.get("roofline"):
         dominant = dict(hotpath_only["roofline"])
         dominant["note"] = "measured in the hot-path-only leg of this run (HIP events are not recorded inside a graph replay)"
@@ -780,6 +789,15 @@ def main():
             def describe():
                 return describe_headline
         step = _Done()
+
+    # ---- the step under a HIP graph: last GPU leg, in a child process (N = 1 headline run only)
+    if default_headline and rank == 0 and args.graph_leg:
+        if hasattr(step, "trainer"):
+            del step.trainer        # the eager trainer's activations are not needed any more
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        graph_leg = graph_step_leg(args) if not over_budget(args, 40) else {"skipped": "time budget"}
 
     if rank == 0:
         n_gpus = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1

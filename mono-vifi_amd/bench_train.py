@@ -28,6 +28,7 @@ class TrainStep:
             amp_bf16=getattr(args, "amp_bf16", False), channels_last=getattr(args, "channels_last", False),
             inkernel_noise=getattr(args, "noise", "kernel") == "kernel",
             hip_graph=bool(getattr(args, "hip_graph", False)),
+            hip_graph_scope=getattr(args, "hip_graph_scope", "step"),
             batch_units=not getattr(args, "no_batch_units", False),
             share_identity=not getattr(args, "no_share_identity", False),
             grad_exchange=getattr(args, "grad_exchange", "all_reduce"),
@@ -49,7 +50,7 @@ class TrainStep:
                 f"{'grouped' if o.group_calls else 'one-at-a-time'} network calls with per-call "
                 f"BatchNorm statistics, AdamW, random-init weights, device-resident synthetic batch "
                 f"(data loading excluded), nets {'bf16 autocast' if o.amp_bf16 else 'fp32'}"
-                f"{', device work of the step replayed as one HIP graph' if o.hip_graph else ''}")
+                f"{(', forward + backward + gradient exchange replayed as one HIP graph, clipping + AdamW eager' if o.hip_graph_scope != 'step' else ', device work of the whole step replayed as one HIP graph') if o.hip_graph else ''}")
 
     def __call__(self):
         return self.trainer.optimisation_step(dict(self.batch))

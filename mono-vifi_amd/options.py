@@ -120,11 +120,17 @@ def build_parser():
                    help="auto-mask tie-break noise (train.py:1023-1024) drawn inside the unit kernel "
                         "from a counter-based generator instead of a torch.randn tensor per unit")
     p.add_argument("--hip_graph", type=_str2bool, default=False,
-                   help="EXPERIMENTAL: capture the device work of an optimisation step (networks, "
-                        "hot-path units, backward, clipping, AdamW) once into a HIP graph and replay it: "
-                        "one launch per step instead of thousands (needs static shapes; "
-                        "trainer._StepGraph).  See DESIGN.md section 7 for which stages of the step are "
-                        "captured on this ROCm stack; a GPU memory fault during a replay cannot be caught")
+                   help="capture the device work of an optimisation step (networks, hot-path units, backward, "
+                        "clipping, AdamW) once into a HIP graph and replay it: one launch per step instead of "
+                        "thousands (needs static shapes; trainer._StepGraph).  Runs with the HIP runtime's graph "
+                        "packet capture switched off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, set when the package is "
+                        "imported): with it the replay faults at the BASELINE shapes on ROCm 7.2 (DESIGN.md "
+                        "section 7).  A GPU memory fault during a replay cannot be caught")
+    p.add_argument("--hip_graph_scope", type=str, default="step", choices=["step", "backward"],
+                   help="--hip_graph: what the captured graph holds.  step (default): everything incl. clipping "
+                        "and the capturable AdamW (learning rate resident on the device).  backward: networks, "
+                        "hot-path units, backward pass and gradient exchange; clipping and the ordinary optimiser "
+                        "stay ~20 eager launches")
     p.add_argument("--bucket_mb", type=float, default=32.0, help="gradient all-reduce bucket size")
     p.add_argument("--grad_exchange", type=str, default="all_reduce", choices=["all_reduce", "reduce_scatter"],
                    help="per gradient bucket: one RCCL all-reduce, or its two halves issued explicitly on "

@@ -196,16 +196,24 @@ class Trainer(HotPathLosses):
 
         # ---- optimiser (reference: train.py:229-246)
         use_graph = bool(getattr(o, "hip_graph", False)) and self.device.type == "cuda"
-        if use_graph and o.optimizer not in ("adamw", "adam"):
-            raise ValueError("--hip_graph needs a capturable optimizer (adamw / adam)")
+        # scope "step" (default) also captures clipping + AdamW, which needs the capturable optimiser
+        # (device-resident step counters and learning rate); scope "backward" leaves the update eager with
+        # the ordinary optimiser and schedulers
+        graph_opt = use_graph and getattr(o, "hip_graph_scope", "step") == "step"
+        if graph_opt and o.optimizer not in ("adamw", "adam"):
+            raise ValueError("--hip_graph_scope step needs a capturable optimizer (adamw / adam)")
         if use_graph:
-            logging.warning("--hip_graph is EXPERIMENTAL: the optimisation step is captured into a HIP graph "
-                            "and replayed; a GPU memory fault during a replay cannot be caught (DESIGN.md "
-                            "section 7 lists what is captured on this ROCm stack)")
+            from . import ensure_graph_replay_env
+            ensure_graph_replay_env(strict=True)      # the runtime's graph packet capture must be off
+        if use_graph:
+            logging.warning("--hip_graph: the optimisation step is captured into a HIP graph and replayed (with the "
+                            "HIP runtime's graph packet capture switched off, DESIGN.md section 7); a GPU memory "
+                            "fault during a replay cannot be caught")
         # under a HIP graph the step counter and the learning rate live on the device: the
         # schedulers then update the rate in place (fill_) and the replayed launch reads it
-        gkw = {"capturable": True, "foreach": True} if use_graph else {}
-        lr0 = torch.tensor(float(o.learning_rate), device=self.device) if use_graph else o.learning_rate
+        use_graph_sched = graph_opt
+        gkw = {"capturable": True, "foreach": True} if graph_opt else {}
+        lr0 = torch.tensor(float(o.learning_rate), device=self.device) if graph_opt else o.learning_rate
         if o.optimizer == "adamw":
             self.model_optimizer = torch.optim.AdamW(self.parameters_to_train, lr=lr0,
                                                      betas=(o.beta1, o.beta2), weight_decay=o.weight_decay,
@@ -219,8 +227,8 @@ class Trainer(HotPathLosses):
         # graph mode: the schedule runs on a host-side shadow optimiser (plain float arithmetic) and
         # `_sched_step` pushes the new rate into the device-resident one -- a scheduler bound to a
         # tensor rate would read it back (.item()) on every step
-        self._lr_shadow = torch.optim.SGD([torch.zeros(1)], lr=o.learning_rate) if use_graph else None
-        sched_opt = self._lr_shadow if use_graph else self.model_optimizer
+        self._lr_shadow = torch.optim.SGD([torch.zeros(1)], lr=o.learning_rate) if use_graph_sched else None
+        sched_opt = self._lr_shadow if use_graph_sched else self.model_optimizer
         if o.lr_sche_type == "cos":
             self.model_lr_scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(
                 sched_opt, T_max=max(self.num_total_steps, 1), eta_min=o.eta_min)
@@ -241,7 +249,7 @@ class Trainer(HotPathLosses):
             if n_saved == n_mine:
                 self.model_optimizer.load_state_dict(saved)
                 self.model_lr_scheduler.load_state_dict(checkpoint["lr_scheduler"])
-                if use_graph:
+                if graph_opt:
                     # the saved groups carry the eager settings (capturable=False, float lr, host-side
                     # step counters): restore what a captured optimiser step needs
                     for g in self.model_optimizer.param_groups:
@@ -343,16 +351,25 @@ class Trainer(HotPathLosses):
                 g["lr"] = torch.tensor(lr, device=self.device)
             g["lr"].fill_(lr)
 
-    def _device_step(self, inputs):
-        """Everything of a step that runs on the device (no host read-back anywhere)."""
+    def _forward_backward(self, inputs):
+        """Networks, hot-path units, backward pass and gradient exchange (no host read-back)."""
         _, losses = self.process_batch(inputs)
         self.reducer.zero_grad()
         losses["loss"].backward()
         self.reducer.finish()
+        return losses
+
+    def _update(self):
+        """Gradient clipping and the optimiser update (reference: train.py:661-667)."""
         if self.opt.clip_grad != -1:
             for group in self.model_optimizer.param_groups:
                 nn.utils.clip_grad_norm_(group["params"], max_norm=self.opt.clip_grad)
         self.model_optimizer.step()
+
+    def _device_step(self, inputs):
+        """Everything of a step that runs on the device (no host read-back anywhere)."""
+        losses = self._forward_backward(inputs)
+        self._update()
         return losses
 
     def run_epoch(self, max_steps=None):
@@ -748,6 +765,9 @@ class _StepGraph:
 
     def __init__(self, trainer):
         self.t = trainer
+        # "step": the whole device work of a step; "backward": the graph ends after the gradient exchange,
+        # clipping + optimiser run eagerly after every replay
+        self.scope = getattr(trainer.opt, "hip_graph_scope", "step")
         self.calls = 0
         self.graph = None
         self.static = None
@@ -788,10 +808,12 @@ class _StepGraph:
                 return losses
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.stream):
-                self.losses = t._device_step(dict(self.static))
+                self.losses = (t._device_step if self.scope == "step" else t._forward_backward)(dict(self.static))
             self.graph = g
-            logging.info("optimisation step captured into a HIP graph")
+            logging.info("optimisation step captured into a HIP graph (scope: %s)", self.scope)
         self.graph.replay()
+        if self.scope != "step":
+            t._update()
         return self.losses
 
 

@@ -8,6 +8,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -66,3 +68,45 @@ def test_world_size_must_match_gpus():
     r = _run(["--gpus", "1", "--workload", "mock", "--steps", "1", "--warmup", "0"],
              {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"})
     assert r.returncode != 0 and "refusing" in r.stderr
+
+
+def _free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("launcher", ["self", "torchrun"])
+def test_train_workload_with_two_ranks_on_the_test_gpu(launcher):
+    """The REAL benchmark step (trainer, grouped SyncBatchNorm, bucketed reducer, timing with the maximum
+    over ranks, `comm` report with its second issue order) with two ranks -- on the one GPU of the test box
+    over gloo (MVF_BENCH_SHARE_GPU=1; RCCL needs a GPU per rank), small shapes.  Both launch forms: the
+    script starting its own ranks, and the driver's `python -m torch.distributed.run ... bench.py --gpus 2`."""
+    args = ["--gpus", "2", "--workload", "train", "--batch", "2", "--height", "64", "--width", "96", "--steps", "2",
+            "--warmup", "1", "--no-cpu-baseline", "--comm-leg-steps", "1"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MVF_DIST_BACKEND="gloo", MVF_BENCH_SHARE_GPU="1")
+    if launcher == "self":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py")] + args
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and d["roofline"]["launches"] == 2 * 3
+    c = d["comm"]
+    assert c["world_size"] == 2 and c["distinct_processes"] == 2 and c["backend"] == "gloo"
+    per = c["collectives_per_step"]
+    # per step: one exchange per gradient bucket, one statistics collective per BatchNorm layer per grouped
+    # call and direction (the CPU/gloo branch of the synchronised batch norm all-reduces in both directions
+    # on a CPU tensor; on the GPU it all-gathers forward) -- 40 per direction for ResNet18
+    assert per["grad_all_reduce"] == float(c["grad_buckets"])
+    assert per.get("bn_all_gather", per.get("bn_all_reduce_fwd")) == 40.0 and per["bn_all_reduce"] == 40.0
+    assert c["no_overlap"]["ms_per_step"] > 0
+    assert "other_configs" not in d and "cpu_baseline" not in d

@@ -65,55 +65,42 @@ def test_fused_units_equal_staged_path(tmp_path):
     assert float(num / out[False][2].norm()) <= 1e-4
 
 
-@pytest.mark.skipif(os.environ.get("MVF_TEST_HIP_GRAPH") != "1",
-                    reason="experimental --hip_graph step: opt-in (MVF_TEST_HIP_GRAPH=1).  Capture + replay "
-                           "pass at this test's 96x64 shapes, but at the BASELINE shapes the first replay "
-                           "ends in a GPU memory access fault on ROCm 7.2 (DESIGN.md section 7) -- a fault "
-                           "kills the process and cannot be caught, so the default suite does not risk it")
-def test_hip_graph_step_follows_the_eager_step(tmp_path):
-    """--hip_graph: three eager warm-up steps, then the device work of the step is captured once
-    and replayed.  The loss trajectory and the (device-resident) learning rate follow an eager
-    trainer fed the same batches (training random-init nets is chaotic and the capturable AdamW
-    rounds differently: measured deviation 2.7 % after 7 steps, bar 5 %); the replayed steps
-    move the parameters; checkpoints written in graph mode resume in eager mode."""
-    from mono_vifi_amd.trainer import _StepGraph
-    dev = torch.device("cuda", 0)
-    batches = [device_batch(2, 64, 96, dev, seed=5 + i) for i in range(7)]
-    g = torch.Generator(device=dev).manual_seed(3)
-    noise = torch.randn((2, 2, 64, 96), device=dev, generator=g)
-    out = {}
-    for graph in (False, True):
-        t = make_trainer(tmp_path / ("graph" if graph else "eager"), hip_graph=graph, inkernel_noise=False,
-                         lr_sche_type="cos", learning_rate=1e-3)
-        t.set_train()
-        t.tie_break_noise = noise
-        assert (t._step_graph is not None) == graph
-        losses, snap = [], None
-        for i, b in enumerate(batches):
-            if i == _StepGraph.WARMUP:
-                snap = [p.detach().clone() for p in t.parameters_to_train]
-            l = t.optimisation_step(dict(b))
-            losses.append([float(l[k]) for k in ("loss", "loss_base", "loss_dc")])
-        if graph:
-            assert t._step_graph.graph is not None and t._step_graph.calls == len(batches)
-            assert torch.is_tensor(t.model_optimizer.param_groups[0]["lr"])
-        delta = torch.cat([(p.detach() - q).flatten() for p, q in zip(t.parameters_to_train, snap)])
-        out[graph] = (np.array(losses), delta, float(t.model_optimizer.param_groups[0]["lr"]), t)
-    le, lg = out[False][0], out[True][0]
+@pytest.mark.parametrize("backbone,B,H,W,scope", [("ResNet18", 2, 64, 96, "step"), ("ResNet18", 12, 192, 640, "step"),
+                                                  ("ResNet18", 12, 192, 640, "backward"),
+                                                  ("DHRNet", 12, 192, 640, "step")])
+def test_hip_graph_step_follows_the_eager_step(tmp_path, backbone, B, H, W, scope):
+    """--hip_graph at a test shape and at the BASELINE shapes of the ResNet18 and HRNet18 configurations: three
+    eager warm-up steps, then the device work of the step is captured once and replayed (scope "step": networks,
+    hot-path units, backward, gradient exchange, clipping, capturable AdamW; scope "backward": the update stays
+    eager with the ordinary optimiser).  The loss trajectory follows an eager trainer fed the same batches
+    (training random-init nets is chaotic and the capturable AdamW rounds differently: bar 5 %), the replayed
+    steps move the parameters, the cosine schedule moves both rates alike, a graph-mode checkpoint resumes in an
+    eager trainer.  Runs in a child process (tests/hip_graph_worker.py): a GPU fault during a replay cannot be
+    caught.  Round 2 skipped this test above 96x64: the replay faulted at the BASELINE shapes -- the HIP runtime's
+    graph packet capture, switched off by the package since round 3 (DESIGN.md section 7,
+    tools/graph_flow_probe.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.setdefault("MIOPEN_FIND_MODE", "FAST")
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "hip_graph_worker.py"), backbone, str(B), str(H),
+                        str(W), str(tmp_path), scope], env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
+    assert line, p.stdout[-2000:]
+    r = json.loads(line[-1][len("RESULT "):])
+    e, g = r["eager"], r["graph"]
+    le, lg = np.array(e["losses"]), np.array(g["losses"])
+    assert g["captured"] and g["calls"] == len(lg)
     assert np.all(np.isfinite(lg))
     np.testing.assert_allclose(lg[:2], le[:2], rtol=1e-4)       # eager warm-up steps of both
     np.testing.assert_allclose(lg, le, rtol=5e-2, atol=1e-6)
-    # the replayed steps (capture call included) really trained
-    de, dg = out[False][1], out[True][1]
-    assert float(dg.norm()) > 0.5 * float(de.norm())
-    assert abs(out[True][2] - out[False][2]) <= 1e-9 and out[True][2] < 1e-3     # cosine schedule moved both
-    # a graph-mode checkpoint carries a float rate and resumes in an eager trainer
-    tg = out[True][3]
-    tg.save_model(batch_idx=1)
-    t2 = make_trainer(tmp_path / "graph", resume=True, lr_sche_type="cos", learning_rate=1e-3)
-    for a, b in zip(tg.parameters_to_train, t2.parameters_to_train):
-        assert torch.equal(a.detach().cpu(), b.detach().cpu())
-    assert isinstance(t2.model_optimizer.param_groups[0]["lr"], float)
+    assert g["delta_norm"] > 0.5 * e["delta_norm"] > 0           # the replayed steps really trained
+    assert abs(g["lr"] - e["lr"]) <= 1e-9 and g["lr"] < 1e-3     # cosine schedule moved both
+    assert g["lr_is_tensor"] == (scope == "step")                # device-resident rate only with the captured AdamW
+    assert r["resume_equal"] and r["resume_lr_is_float"]
 
 
 def test_checkpoint_roundtrip_reference_format(tmp_path):
