@@ -223,6 +223,14 @@ def comm_report(args, world, rank, dev, backend, step, counts_per_step):
            "grad_buckets": red.num_buckets if red else 0,
            "grad_bucket_bytes": red.total_bytes if red else 0,
            "collectives_per_step": counts_per_step}
+    if red is not None:
+        # of the last step: where its exchanges were issued, and (GPU) how much of the backward pass was still
+        # ahead on the compute stream when each bucket went out
+        rep["exchanges_issued_during_backward"] = red.issued_from_hook
+        rep["exchanges_issued_after_backward"] = red.issued_from_finish
+        tl = red.timeline_ms() if hasattr(red, "timeline_ms") else []
+        if tl:
+            rep["backward_ms_remaining_at_issue"] = tl
     return rep
 
 
@@ -714,6 +722,9 @@ def main():
         nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
         nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
     parallel.reset_comm_counts()
+    red0 = getattr(getattr(step, "trainer", step), "reducer", None)
+    if red0 is not None and (world > 1 or args.force_collectives):
+        red0.timeline = True          # two event records per bucket and step
     elapsed = timed_steps(step, args.steps, world)
     counts = {k: round(v / args.steps, 2) for k, v in sorted(parallel.comm_counts().items())}
     if nat:
@@ -846,9 +857,20 @@ def main():
                 "cpu_port_openmp": out["cpu_baseline"]["value"],
                 "cpu_unfused_torch_ops": out["cpu_baseline_unfused"].get("value")}
         out["wall_seconds"] = round(time.perf_counter() - T_START, 1)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
+    else:
+        line = None
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
+    if line is not None:
+        # the ONE JSON line is the last thing on stdout: RCCL writes its version banner through C stdio, which
+        # is block-buffered on a pipe and would otherwise land after the line when the process exits
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

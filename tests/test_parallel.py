@@ -44,6 +44,9 @@ def _worker(rank, world, port, q, exchange="all_reduce", overlap=True):
         red = parallel.BucketedGradReducer(params, world, bucket_mb=0.0001,   # many tiny buckets
                                            exchange=exchange, overlap=overlap)
         assert red.num_buckets > 1
+        used = {id(p) for k in ("a", "b") for p in net[k].parameters()}
+        nb_used = sum(all(id(p) in used for p in b.params) for b in red.buckets)      # buckets that fill
+        nb_unused = red.num_buckets - nb_used
         parallel.reset_comm_counts()
         torch.manual_seed(100)
         x_all = torch.randn(4 * world, 8)
@@ -52,7 +55,15 @@ def _worker(rank, world, port, q, exchange="all_reduce", overlap=True):
             red.zero_grad()
             y = net["b"](torch.relu(net["a"](x)) + net["a_alias"](x))   # shared module used twice
             y.pow(2).mean().backward()
+            # where the exchanges were issued: every bucket that filled went out from a hook DURING
+            # backward (the overlapped case); finish() only issues what never filled (the unused module)
+            in_backward = red.issued_from_hook
             red.finish()
+            if overlap:
+                assert in_backward >= nb_used and red.issued_from_finish == red.num_buckets - in_backward
+                assert red.issued_from_finish <= nb_unused
+            else:
+                assert in_backward == 0 and red.issued_from_finish == red.num_buckets
         grads = [p.grad.clone() for p in params]
         # exactly one exchange per bucket per step, whichever form it takes
         cnt, nb = parallel.comm_counts(), red.num_buckets

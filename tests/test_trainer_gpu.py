@@ -303,6 +303,7 @@ def _rccl_worker(port, log_dir, q):
         if forced:
             dist.all_reduce, dist.all_gather_into_tensor = ar, ag
             parallel.reset_comm_counts()
+            t.reducer.timeline = True
         else:
             for h in hooks:
                 h.remove()
@@ -316,6 +317,7 @@ def _rccl_worker(port, log_dir, q):
         torch.cuda.synchronize()
         if forced:
             counted = parallel.comm_counts()
+            issue = (t.reducer.issued_from_hook, t.reducer.issued_from_finish, t.reducer.timeline_ms())
         bufs = torch.cat([b.flatten().float() for m in t._modules_unique.values() for b in m.buffers()])
         out[forced] = (float(losses["loss"]),
                        torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone(), bufs.clone())
@@ -327,7 +329,7 @@ def _rccl_worker(port, log_dir, q):
     per_layer = {name: sorted({bn_calls[id(m)] for m in layers_of(name)}) for name in ("encoder", "pose_encoder")}
     q.put((dl, dg, db, calls["all_reduce"], calls["all_gather"], t.reducer.num_buckets,
            dist.get_backend(), sum(bn_calls.values()), counted, per_layer,
-           {name: len(layers_of(name)) for name in per_layer}))
+           {name: len(layers_of(name)) for name in per_layer}, issue))
     dist.destroy_process_group()
 
 
@@ -343,7 +345,7 @@ def test_rccl_collectives_on_one_gpu(tmp_path):
     p.start()
     p.join(900)
     assert p.exitcode == 0
-    dl, dg, same_bufs, n_ar, n_ag, n_buckets, backend, bn_invocations, counted, per_layer, n_layers = \
+    dl, dg, same_bufs, n_ar, n_ag, n_buckets, backend, bn_invocations, counted, per_layer, n_layers, issue = \
         q.get(timeout=10)
     assert backend == "nccl"
     # EXACT collective counts of one step ("~40 instead of 280 per direction"):
@@ -359,4 +361,9 @@ def test_rccl_collectives_on_one_gpu(tmp_path):
     assert n_layers == {"encoder": 20, "pose_encoder": 20}
     assert per_layer == {"encoder": [1], "pose_encoder": [1]}
     assert bn_invocations == 40
+    # overlap with backward: every bucket went out from a post-accumulate-grad hook, i.e. DURING the backward
+    # pass, and when the first one was issued part of the backward pass was still ahead on the compute stream
+    from_hook, from_finish, ms_ahead = issue
+    assert from_hook + from_finish == n_buckets and from_hook >= max(n_buckets - 1, 1), issue
+    assert len(ms_ahead) == from_hook and ms_ahead[0] >= ms_ahead[-1] >= 0.0 and ms_ahead[0] > 0.5, issue
     assert dl <= 1e-5 and dg <= 2e-3 and same_bufs
