@@ -482,18 +482,20 @@ MVF_DEV Taps4 taps_of(const Tap &t, int W)
 struct WarpSlot {
     Taps4 qa, qb;
     int r, c, x0a, y0a, x0b, y0b;
+    float wxa, wya, wxb, wyb;     // fractional tap position of both sources
+    unsigned fla, flb;            // bit 2: x strictly inside (gradient passes), bit 3: y strictly inside
     bool live;
 };
 
-MVF_DEV WarpSlot warp_slot(int idx, const float *__restrict__ dispP, const float *__restrict__ iK,
-                           const f2 P2[12], int H, int W, int py0, int px0, float min_disp,
-                           float range, float eps, bool inner = false)
+// the warp of plane position (r, c); `inner`: the plane lies inside the image (no reflect mapping)
+MVF_DEV WarpSlot warp_slot_rc(int r, int c, bool live, const float *__restrict__ dispP,
+                              const float *__restrict__ iK, const f2 P2[12], int H, int W, int py0, int px0,
+                              float min_disp, float range, float eps, bool inner)
 {
     WarpSlot s;
-    s.live = idx < PH * PW;
-    idx = min(idx, PH * PW - 1);
-    s.r = idx / PW;
-    s.c = idx - s.r * PW;
+    s.live = live;
+    s.r = r;
+    s.c = c;
     int gy, gx;
     if (inner) {        // plane inside the image (workgroup-uniform): no reflect mapping
         gy = py0 + s.r; gx = px0 + s.c;
@@ -515,7 +517,20 @@ MVF_DEV WarpSlot warp_slot(int idx, const float *__restrict__ dispP, const float
     s.qa.wnw = s.qb.wnw = dispP[s.r * LDW + s.c];
 #endif
     s.x0a = w.ta.x0; s.y0a = w.ta.y0; s.x0b = w.tb.x0; s.y0b = w.tb.y0;
+    s.wxa = w.ta.wx; s.wya = w.ta.wy; s.wxb = w.tb.wx; s.wyb = w.tb.wy;
+    s.fla = (w.ta.inx ? 4u : 0u) | (w.ta.iny ? 8u : 0u);
+    s.flb = (w.tb.inx ? 4u : 0u) | (w.tb.iny ? 8u : 0u);
     return s;
+}
+// plane positions in row-major order: position idx = row * PW + col
+MVF_DEV WarpSlot warp_slot(int idx, const float *__restrict__ dispP, const float *__restrict__ iK,
+                           const f2 P2[12], int H, int W, int py0, int px0, float min_disp,
+                           float range, float eps, bool inner = false)
+{
+    const bool live = idx < PH * PW;
+    idx = min(idx, PH * PW - 1);
+    const int r = idx / PW;
+    return warp_slot_rc(r, idx - r * PW, live, dispP, iK, P2, H, W, py0, px0, min_disp, range, eps, inner);
 }
 
 template <int U>   // plane positions per iteration (1: fewest registers, 2: more overlap)

@@ -269,6 +269,62 @@ MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restric
 // warp of the source pair into the pair planes: plane positions tid + k*NT, k < NSTAGE.  Full
 // iterations take U positions at a time (their divide chains interleave, all taps in flight);
 // the last position runs alone, and waves whose positions all lie beyond the plane skip it.
+#ifndef MVF_FB_KEEPTAPS
+#define MVF_FB_KEEPTAPS 1     // the adjoint takes the forward's taps from registers (0: re-runs the projection chain)
+#endif
+
+// What phase 7 needs of the forward's projection chain at an output pixel, kept in FOUR registers per
+// position: per source the byte offset of the row-y0 tap pair (< 2^28) with four flags above it (pair
+// anchored one pixel left, row y1 below y0, x / y strictly inside) and the fractional tap position as two
+// 16-bit fixed-point numbers (the adjoint is tolerance arithmetic: 1.5e-5 on a bilinear weight).  For this to
+// work a lane must warp in phase 3 the pixels whose adjoint it evaluates in phases 7 + 8: the warp walks the
+// 30 x 14 interior first, in the lane order of phase 7, then the border ring of the 34 x 18 plane.
+struct TapStash {
+    uint32_t oa, ob, wa, wb;
+};
+constexpr uint32_t kOffMask = 0x0fffffffu;
+MVF_DEV uint32_t pack_w(float wx, float wy)
+{
+    return (uint32_t)(wx * 65536.0f) | ((uint32_t)(wy * 65536.0f) << 16);      // wx, wy in [0, 1): truncation
+}
+MVF_DEV TapStash pack_taps(const WarpSlot &s)
+{
+    TapStash t;
+    t.oa = s.qa.q.o0 | (s.qa.q.sh ? 1u << 28 : 0u) | (s.qa.q.o1 != s.qa.q.o0 ? 1u << 29 : 0u) | (s.fla << 28);
+    t.ob = s.qb.q.o0 | (s.qb.q.sh ? 1u << 28 : 0u) | (s.qb.q.o1 != s.qb.q.o0 ? 1u << 29 : 0u) | (s.flb << 28);
+    t.wa = pack_w(s.wxa, s.wya);
+    t.wb = pack_w(s.wxb, s.wyb);
+    return t;
+}
+// plane position (r, c) of warp slot q (0 .. NSTAGE-1) of this lane; false beyond the plane
+MVF_DEV bool fb_slot_pos(int q, int &r, int &c)
+{
+#if MVF_FB_KEEPTAPS
+    constexpr int NI = (TW - 2) * (TH - 2);              // interior positions, phase-7 order
+    constexpr int OWc = TW - 2;
+    const int s = (int)threadIdx.x + q * NT;
+    if (s < NI) {
+        const int pr = s / OWc;
+        r = pr + 2; c = s - pr * OWc + 2;
+        return true;
+    }
+    const int j = s - NI;                                // the ring: rows 0, 1, PH-2, PH-1, then the side columns
+    if (j < 4 * PW) {
+        const int rr = j / PW;
+        r = (rr < 2) ? rr : rr + (PH - 4); c = j - rr * PW;
+        return true;
+    }
+    const int jj = min(j - 4 * PW, 4 * (PH - 4) - 1), rr = jj >> 2, cc = jj & 3;
+    r = rr + 2; c = (cc < 2) ? cc : cc + (PW - 4);
+    return j - 4 * PW < 4 * (PH - 4);
+#else
+    const int idx = (int)threadIdx.x + q * NT;
+    const int ic = min(idx, PH * PW - 1);
+    r = ic / PW; c = ic - r * PW;
+    return idx < PH * PW;
+#endif
+}
+
 struct WarpCtx {
     f2 *pairP;
     const float *dispP, *sa, *sb, *iK;
@@ -277,6 +333,7 @@ struct WarpCtx {
     float min_disp, range, eps;
     int32_t *idx_a, *idx_b;
     bool inner;        // the staged plane lies inside the image: no reflect mapping (workgroup-uniform)
+    TapStash *stash;   // [2] registers of the lane: taps of its (up to) two interior positions
 };
 
 // one batch of U plane positions: chain + tap loads issued (issue), bilinear combine + store (finish).
@@ -306,9 +363,15 @@ MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
 {
     const size_t N = (size_t)k.H * k.W;
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-        w.s[u] = warp_slot((int)threadIdx.x + (slot0 + u) * NT, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0,
-                           k.min_disp, k.range, k.eps, k.inner);
+    for (int u = 0; u < U; ++u) {
+        int r, c;
+        const bool live = fb_slot_pos(slot0 + u, r, c);
+        w.s[u] = warp_slot_rc(r, c, live, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0, k.min_disp, k.range, k.eps,
+                              k.inner);
+#if MVF_FB_KEEPTAPS
+        if (slot0 + u < 2) k.stash[slot0 + u] = pack_taps(w.s[u]);
+#endif
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -478,6 +541,8 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         k.idx_b = u.idx_xy ? u.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
         k.inner = inner;
     }
+    TapStash stash[2] = {};
+    wk_ctx.stash = stash;
 
     // ---- 2: identity candidates of every region pixel
     f2 vid[PX];
@@ -819,10 +884,51 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         const bool live = (g0.x != 0.0f) || (g1.x != 0.0f) || (g2.x != 0.0f) ||
                           (hasb && ((g0.y != 0.0f) || (g1.y != 0.0f) || (g2.y != 0.0f)));
         if (live) {
+#if MVF_FB_KEEPTAPS && !defined(MVF_ABL_FB_LDSTAPS)
+            // the forward's taps come out of the registers phase 3 left them in (same lane, same position);
+            // what the projection adjoint needs besides -- the camera point, z, u, v -- is tolerance
+            // arithmetic: one v_rcp each for the depth (one Newton step) and for z
+            WarpPair w;
+            {
+                const TapStash ts = stash[k];
+                ray_of(iK, (float)xx, (float)yy, w.r);
+                const float scaled = a.min_disp + a.range * dispP[e];
+                float rd = __builtin_amdgcn_rcpf(scaled);
+                rd = fmaf(fmaf(-scaled, rd, 1.0f), rd, rd);
+                w.depth = rd;
+                w.X[0] = rd * w.r[0]; w.X[1] = rd * w.r[1]; w.X[2] = rd * w.r[2];
+                f2 c[3];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    f2 acc = P2[i * 4 + 0] * f2s(w.X[0]);
+                    acc = pk_fma(P2[i * 4 + 1], f2s(w.X[1]), acc);
+                    acc = pk_fma(P2[i * 4 + 2], f2s(w.X[2]), acc);
+                    c[i] = acc + P2[i * 4 + 3];
+                }
+                w.z = c[2] + f2s(a.eps);
+                const f2 rzz = mk2(__builtin_amdgcn_rcpf(w.z.x), __builtin_amdgcn_rcpf(w.z.y));
+                w.u = c[0] * rzz;
+                w.v = c[1] * rzz;
+                w.ta.wx = (float)(ts.wa & 0xffffu) * 0x1p-16f; w.ta.wy = (float)(ts.wa >> 16) * 0x1p-16f;
+                w.tb.wx = (float)(ts.wb & 0xffffu) * 0x1p-16f; w.tb.wy = (float)(ts.wb >> 16) * 0x1p-16f;
+                w.ta.inx = ts.oa & (1u << 30); w.ta.iny = ts.oa & (1u << 31);
+                w.tb.inx = ts.ob & (1u << 30); w.tb.iny = ts.ob & (1u << 31);
+            }
+            const unsigned W4 = (unsigned)W * 4u;
+            TapRows qa, qb;
+            qa.o0 = stash[k].oa & kOffMask; qa.o1 = qa.o0 + ((stash[k].oa & (1u << 29)) ? W4 : 0u);
+            qa.sh = stash[k].oa & (1u << 28);
+            qb.o0 = stash[k].ob & kOffMask; qb.o1 = qb.o0 + ((stash[k].ob & (1u << 29)) ? W4 : 0u);
+            qb.sh = stash[k].ob & (1u << 28);
+#else
             // the exact chain again: the taps must be the forward's (a flipped cell would flip the
             // bilinear gradient)
             const WarpPair w = warp_point_pair(dispP[e], iK, P2, xx, yy, H, W, a.min_disp,
                                                a.range, a.eps);
+#if !defined(MVF_ABL_FB_LDSTAPS)
+            const TapRows qa = taprows_of(w.ta, W), qb = taprows_of(w.tb, W);
+#endif
+#endif
             float dxa[3], dya[3], dxb[3], dyb[3];
 #ifdef MVF_ABL_FB_LDSTAPS
 #pragma unroll
@@ -841,7 +947,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 // (row1 - row0) . (e, w) -- one packed subtract and one packed multiply per channel; at
                 // the right border (pair anchored one pixel left, both taps its second element, w == 0)
                 // the weight pair is swapped instead of selecting taps.  d/dx there is masked by `inx`.
-                const TapRows qa = taprows_of(w.ta, W), qb = taprows_of(w.tb, W);
                 float2 ra0[3], ra1[3], rb0[3], rb1[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
@@ -1119,8 +1224,8 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
     if (S < 1 || S > 2) return (int)hipErrorInvalidValue;      // one source pair
     if (!workspace || !tickets) return (int)hipErrorInvalidValue;
     if (B * H * W <= 0) return 0;
-    if ((double)H * W * 3.0 * 4.0 >= 4294967296.0 || H >= (1 << 22) || W >= (1 << 22))
-        return (int)hipErrorInvalidValue;                        // 32-bit byte offsets inside an image
+    if ((double)H * W * 4.0 >= 268435456.0 || H >= (1 << 22) || W >= (1 << 22))
+        return (int)hipErrorInvalidValue;     // byte offsets inside a plane fit 28 bits (4 flag bits ride above them)
     if ((((uintptr_t)workspace) & 7) != 0) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const int N = H * W;
