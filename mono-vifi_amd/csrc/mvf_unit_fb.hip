@@ -1004,8 +1004,9 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         const float *dc = dispP + e;
         const float *t0 = tgtP + e;
         auto wgt = [&](int o) {
-            float gi = div3((fabsf(t0[0] - t0[o]) + fabsf(t0[PLANE] - t0[PLANE + o])) +
-                            fabsf(t0[2 * PLANE] - t0[2 * PLANE + o]));
+            // (the smoothness term is tolerance arithmetic -- its exp already is: the channel mean as a multiply)
+            float gi = ((fabsf(t0[0] - t0[o]) + fabsf(t0[PLANE] - t0[PLANE + o])) +
+                        fabsf(t0[2 * PLANE] - t0[2 * PLANE + o])) * (1.0f / 3.0f);
             return __expf(-gi);
         };
         auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
