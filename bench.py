@@ -348,6 +348,30 @@ class HotPathStep:
         return total
 
 
+def cpu_quota():
+    """CPUs the container may use: the cgroup quota (cpu.max / cfs_quota) if there is one, else the affinity
+    mask.  The gpurun boxes show 256 hardware threads and grant 16 CPUs (cpu.max = 1600000 100000): that, not
+    the port, is why every thread-count sweep of the CPU baselines peaked at 16."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            return min(n, max(1, int(round(int(q) / int(per))))), n
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            per = int(f.read())
+        if q > 0:
+            return min(n, max(1, int(round(q / per)))), n
+    except (OSError, ValueError):
+        pass
+    return n, n
+
+
 def cpu_baseline(args):
     """The oracle (CPU port of the reference's algorithm) on a bounded sample: one unit,
     forward + backward, at the benchmark's batch and resolution (the same per-call work as the GPU's:
@@ -360,7 +384,7 @@ def cpu_baseline(args):
     inp = synthetic.unit_inputs(4321, Bs, args.height, args.width, with_mask=True)
     T = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
                   for k in range(2)], 0)
-    host_cores = os.cpu_count() or 1
+    quota, host_cores = cpu_quota()
 
     def one():
         O.unit(inp["disp"], inp["tgt"], inp["src"], T, inp["K"], inp["inv_K"], inp["noise"],
@@ -369,7 +393,8 @@ def cpu_baseline(args):
     # parallel regions cover (image x row band) / (plane x row band) tasks since round 3 (its adjoint was
     # 36-way parallel and the smoothness adjoint serial: 16 of 256 cores was the optimum)
     best = (float("inf"), 1)
-    for nt in sorted({c for c in (8, 16, 32, 64) if c <= host_cores}):      # beyond 64 threads every run got slower (measured)
+    # candidates around the CPUs the container is granted (more threads than that only contend)
+    for nt in sorted({c for c in (quota // 2, quota, 2 * quota) if 1 <= c <= host_cores}):
         O.set_threads(nt)
         one()
         t0 = time.perf_counter()
@@ -391,7 +416,9 @@ def cpu_baseline(args):
             "cores": cores, "kind": "port",
             "sample": f"{n} x (1 unit fwd+bwd, batch {Bs}, {args.width}x{args.height}) in "
                       f"{dt:.1f} s; value = hot-path part of a step ({UNITS_PER_STEP} units); oracle/mvf_oracle.c, OpenMP with "
-                      f"{cores} of {host_cores} host cores (fastest of a thread-count sweep)"}
+                      f"{cores} threads (fastest of a sweep around the container's CPU quota: {quota} CPUs granted of "
+                      f"{host_cores} hardware threads)",
+            "host": {"hardware_threads": host_cores, "cpus_granted": quota}}
 
 
 def cpu_baseline_unfused(args):
@@ -407,7 +434,7 @@ def cpu_baseline_unfused(args):
     inp = synthetic.unit_inputs(4321, Bs, args.height, args.width, with_mask=True)
     T = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1))
                   for k in range(2)], 0)
-    host_cores = os.cpu_count() or 1
+    quota, host_cores = cpu_quota()
     tens = [torch.from_numpy(np.ascontiguousarray(a)) for a in
             (inp["disp"], inp["tgt"], T, inp["K"], inp["inv_K"], inp["noise"], inp["mask_rec"])]
     srcs = [torch.from_numpy(np.ascontiguousarray(a)) for a in inp["src"]]
@@ -417,7 +444,7 @@ def cpu_baseline_unfused(args):
     old = torch.get_num_threads()
     best = (float("inf"), 1)
     try:
-        for nt in sorted({c for c in (16, 32, 64) if c <= host_cores} or {host_cores}):
+        for nt in sorted({c for c in (quota // 2, quota, 2 * quota) if 1 <= c <= host_cores}):
             torch.set_num_threads(nt)
             one()
             t0 = time.perf_counter()
@@ -440,7 +467,8 @@ def cpu_baseline_unfused(args):
                       f"value = hot-path part of a step ({UNITS_PER_STEP} units); "
                       f"oracle/torch_unfused.py: the unit as ~130 separate ATen ops under autograd "
                       f"(the operator stream of the reference's CPU path), torch intra-op threads "
-                      f"{best[1]} of {host_cores} host cores (fastest of a sweep)"}
+                      f"{best[1]} (fastest of a sweep around the container's CPU quota: {quota} CPUs granted of "
+                      f"{host_cores} hardware threads)"}
 
 
 def _profiles_json():
