@@ -73,3 +73,41 @@ def test_product_never_imports_the_oracle():
             elif f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text, "the product build links the oracle"
+
+
+def test_units_entry_points_reject_bad_arguments(built):
+    """mvf_units_fwdbwd / mvf_units_fwdbwd_scale validate their arguments BEFORE the first HIP call and
+    return hipErrorInvalidValue (1) -- checked here without a GPU: unit counts outside 1..MVF_MAX_UNITS, more
+    than one source pair, missing workspace / tickets / descriptors / required pointers, a plane whose byte
+    offsets do not fit 28 bits (the tap stash of the unit kernel carries four flag bits above them);
+    an empty batch is a no-op (0)."""
+    import ctypes as C
+    from mono_vifi_amd import _native as nat
+    lib = nat.lib()
+    INVALID = 1
+    n = nat.MAX_UNITS
+    descs = (nat.UnitDesc * n)()
+    ws = (C.c_float * 64)()
+    tk = (C.c_int32 * 16)()
+    P = C.cast(descs, C.c_void_p)
+    W, T = C.cast(ws, C.c_void_p), C.cast(tk, C.c_void_p)
+
+    def call(units=P, n_units=1, S=2, flags=0, ws=W, tickets=T, B=1, H=32, Wd=64):
+        return lib.mvf_units_fwdbwd(units, n_units, S, flags, 1e-3, 0.01, 9.99, 1e-7, ws, tickets, B, H, Wd, None)
+
+    assert call(n_units=0) == INVALID and call(n_units=n + 1) == INVALID
+    assert call(units=None) == INVALID
+    assert call(S=0) == INVALID and call(S=3) == INVALID
+    assert call(ws=None) == INVALID and call(tickets=None) == INVALID
+    assert call(B=0) == 0 and call(H=0) == 0                         # nothing to do
+    assert call(H=8192, Wd=8192) == INVALID                          # 2^28 bytes per plane
+    assert call(H=1 << 22, Wd=8) == INVALID
+    assert call() == INVALID                                          # descriptor without its required pointers
+    sd = (nat.UnitScaleDesc * n)()
+    SP = C.cast(sd, C.c_void_p)
+    assert lib.mvf_units_fwdbwd_scale(None, 1, 1e-3, 1, 2, 32, 64, None) == INVALID
+    assert lib.mvf_units_fwdbwd_scale(SP, 0, 1e-3, 1, 2, 32, 64, None) == INVALID
+    assert lib.mvf_units_fwdbwd_scale(SP, n + 1, 1e-3, 1, 2, 32, 64, None) == INVALID
+    assert lib.mvf_units_fwdbwd_scale(SP, 1, 1e-3, 0, 2, 32, 64, None) == 0
+    assert lib.mvf_units_fwdbwd_scale(SP, 1, 1e-3, 1, 2, 32, 64, None) == INVALID     # missing pointers
+    assert lib.mvf_units_workspace_floats(3, 12, 192, 640) > 0 and lib.mvf_units_ticket_ints(3, 12) >= 3

@@ -136,3 +136,27 @@ def test_distributed_sampler_partitions_and_resumes():
     s1 = datasets.CustomDistributedSampler(D(), seed=5, num_replicas=world, rank=1)
     s1.set_epoch(3)
     assert list(s1) == torch.randperm(103, generator=g.manual_seed(8)).tolist()[:100][1::world]
+
+
+def test_tail_bucket_holds_the_last_arriving_gradients():
+    """The bucket that fills last (the first-registered parameters: backward reaches them last) cannot hide its
+    exchange behind anything, so it is kept small: `tail_mb` splits it off the last full-size bucket."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mono_vifi_amd import parallel
+    mb = 1 << 18                                   # floats per MiB
+    sizes = [mb // 2, mb // 2, mb, 3 * mb, 2 * mb, 4 * mb, 6 * mb]      # registration order
+    params = [nn.Parameter(torch.zeros(n)) for n in sizes]
+    red = parallel.BucketedGradReducer(params, world_size=1, bucket_mb=8.0, tail_mb=1.0)
+    got = [[p.numel() for p in b.params] for b in red.buckets]
+    # backward order = reversed registration order; 8 MiB buckets: [6], [4, 2], [3, 1, .5, .5] -> the last one
+    # gives its last-arriving <= 1 MiB to a bucket of their own
+    assert got == [[6 * mb], [4 * mb, 2 * mb], [3 * mb, mb], [mb // 2, mb // 2]]
+    assert red.buckets[-1].params[-1] is params[0]
+    for p in params:                               # every gradient is a view of its bucket
+        assert any(p.grad.data_ptr() >= b.buf.data_ptr() and
+                   p.grad.data_ptr() < b.buf.data_ptr() + 4 * b.buf.numel() for b in red.buckets)
+    # no split when the last bucket is small anyway, or when switched off
+    red2 = parallel.BucketedGradReducer([nn.Parameter(torch.zeros(n)) for n in sizes], world_size=1,
+                                        bucket_mb=8.0, tail_mb=0.0)
+    assert [[p.numel() for p in b.params] for b in red2.buckets][-1] == [3 * mb, mb, mb // 2, mb // 2]
