@@ -251,7 +251,7 @@ def test_two_ranks_on_one_gpu_gloo(tmp_path):
     assert finite and same
 
 
-def _rccl_worker(port, log_dir, q):
+def _rccl_worker(port, log_dir, q, exchange="all_reduce"):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
@@ -265,9 +265,10 @@ def _rccl_worker(port, log_dir, q):
                             device_id=torch.device("cuda", 0))
     opts = default_options(batch_size=2, height=64, width=96, use_affine=True, num_workers=0,
                            synthetic_len=16, log_dir=log_dir, exp_name="rccl", log_frequency=10 ** 9,
-                           save_frequency=10 ** 9, force_collectives=True)
+                           save_frequency=10 ** 9, force_collectives=True, grad_exchange=exchange)
     t = Trainer(opts)
     t.set_train()
+    assert t.reducer.exchange == exchange
     batch = device_batch(2, 64, 96, t.device)
     g = torch.Generator(device=t.device).manual_seed(3)
     t.tie_break_noise = torch.randn((2, 2, 64, 96), device=t.device, generator=g)
@@ -333,15 +334,18 @@ def _rccl_worker(port, log_dir, q):
     dist.destroy_process_group()
 
 
-def test_rccl_collectives_on_one_gpu(tmp_path):
-    """backend="nccl" (= RCCL) with a group of one: the bucketed gradient all-reduce issued
+@pytest.mark.parametrize("exchange", ["all_reduce", "reduce_scatter"])
+def test_rccl_collectives_on_one_gpu(tmp_path, exchange):
+    """backend="nccl" (= RCCL) with a group of one: the bucketed gradient exchange (one all-reduce per
+    bucket, or reduce_scatter_tensor in place + all_gather_into_tensor on the flat buffer) issued
     from the post-accumulate-grad hooks during backward, finish(), and the grouped
     SyncBatchNorm branch all run on RCCL streams; losses, gradients and running statistics
     equal the step without collectives.  (No scaling number is claimed from this.)"""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    p = ctx.Process(target=_rccl_worker, args=(29700 + (os.getpid() % 1000), str(tmp_path), q))
+    p = ctx.Process(target=_rccl_worker, args=(29700 + (os.getpid() % 1000) + (7 if exchange != "all_reduce" else 0),
+                                               str(tmp_path), q, exchange))
     p.start()
     p.join(900)
     assert p.exitcode == 0
@@ -351,10 +355,15 @@ def test_rccl_collectives_on_one_gpu(tmp_path):
     # EXACT collective counts of one step ("~40 instead of 280 per direction"):
     # forward: one all-gather per BatchNorm layer per GROUPED call; backward: one all-reduce per such
     # invocation + one per gradient bucket; nothing else
-    assert n_ag == bn_invocations == counted["bn_all_gather"]
-    assert n_ar == bn_invocations + n_buckets
-    assert counted["bn_all_reduce"] == bn_invocations and counted["grad_all_reduce"] == n_buckets
-    assert set(counted) == {"bn_all_gather", "bn_all_reduce", "grad_all_reduce"}
+    assert bn_invocations == counted["bn_all_gather"] == counted["bn_all_reduce"]
+    if exchange == "all_reduce":
+        assert n_ag == bn_invocations and n_ar == bn_invocations + n_buckets
+        assert counted["grad_all_reduce"] == n_buckets
+        assert set(counted) == {"bn_all_gather", "bn_all_reduce", "grad_all_reduce"}
+    else:       # the bucket's all-reduce as its two halves: the all-gathers of the buckets join the BatchNorm ones
+        assert n_ar == bn_invocations and n_ag == bn_invocations + n_buckets
+        assert counted["grad_reduce_scatter"] == n_buckets and counted["grad_all_gather"] == n_buckets
+        assert set(counted) == {"bn_all_gather", "bn_all_reduce", "grad_reduce_scatter", "grad_all_gather"}
     # the ResNet18 depth encoder (shared_encoder: 8 calls per step in the reference, train.py:745-868) and
     # the pose encoder (6 calls, train.py:724-731) each run as ONE grouped call: 20 + 20 = 40 collectives
     # per direction where the per-call form issues 20 x 8 + 20 x 6 = 280
