@@ -137,6 +137,22 @@ def get_smooth_loss(disp, img):
     return ops.Smooth.apply(disp, img, False)
 
 
+def get_smooth_loss_dyn(disp, img, mask_dyn):
+    """reference: layers.py:244-258 -- the smoothness term with dynamic-object regions blanked in the image
+    and their vertical disparity gradients weighted 100 x.  Part of the reference's `layers` namespace but
+    called nowhere in it (not on the hot path): a few tensor expressions on the caller's device, kept so that
+    `from layers import *` resolves every name the reference's does."""
+    heavy = 100.0 * mask_dyn + 1.0 - mask_dyn
+    still = (1.0 - mask_dyn) * img
+    d_dx = (disp[..., :, :-1] - disp[..., :, 1:]).abs()
+    d_dy = (disp[..., :-1, :] - disp[..., 1:, :]).abs()
+    i_dx = (still[..., :, :-1] - still[..., :, 1:]).abs().mean(1, keepdim=True)
+    i_dy = (still[..., :-1, :] - still[..., 1:, :]).abs().mean(1, keepdim=True)
+    sx = d_dx * torch.exp(-i_dx)
+    sy = d_dy * torch.exp(-i_dy) * heavy[:, :, :-1, :]
+    return sx.mean() + sy.mean()
+
+
 # ----------------------------------------------------------------------------- conv blocks
 def upsample(x, scale_factor=2, mode="nearest"):
     """reference: layers.py:225-228.  On the HIP device (fp32) bilinear (Lite-Mono decoder) and

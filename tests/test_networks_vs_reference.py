@@ -452,3 +452,21 @@ def test_options_equal_the_reference_parser_on_its_own_config_files():
                 continue
             assert k in mine, (os.path.basename(f), k)
             assert mine[k] == v, (os.path.basename(f), k, mine[k], v)
+
+
+def test_layers_namespace_covers_the_reference(ref):
+    """`from layers import *` must resolve every function / class name the reference's layers.py defines;
+    the one function the reference itself never calls (get_smooth_loss_dyn, layers.py:244-258) equals the
+    reference's on random inputs."""
+    import ast
+    from mono_vifi_amd import layers as mine
+    tree = ast.parse(open(os.path.join(REF, "layers.py")).read())
+    names = {n.name for n in tree.body if isinstance(n, (ast.FunctionDef, ast.ClassDef))}
+    missing = sorted(n for n in names if not hasattr(mine, n))
+    assert not missing, missing
+    ref_layers = importlib.import_module("layers")
+    g = torch.Generator().manual_seed(0)
+    disp, img = torch.rand((2, 1, 12, 20), generator=g), torch.rand((2, 3, 12, 20), generator=g)
+    mask = (torch.rand((2, 1, 12, 20), generator=g) > 0.7).float()
+    a, b = mine.get_smooth_loss_dyn(disp, img, mask), ref_layers.get_smooth_loss_dyn(disp.clone(), img, mask)
+    assert abs(float(a) - float(b)) <= 1e-6 * abs(float(b))
