@@ -268,18 +268,17 @@ class MockStep:
 
 # ----------------------------------------------------------------------------- hot path
 def unit_bytes_per_px(noise_tensor, share_identity, use_affine=True):
-    """Mean algorithmic HBM bytes per pixel and unit over the units of a step:
-    every unit reads disp 4 + target 12 + 2 sources 24 and writes argmin 1 + grad_disp 4 = 45;
-    + 8 tie-break noise when it is supplied as a tensor; + 4 mask_rec on the affine units;
-    + 8 for the identity maps a single-frame unit writes and its multi-frame partner reads."""
+    """(algorithmic, hand-over) HBM bytes per pixel and unit, mean over the units of a step.
+    Algorithmic = what the reference's algorithm must move: every unit reads disp 4 + target 12 + 2 sources 24
+    and writes argmin 1 + grad_disp 4 = 45; + 8 tie-break noise when it is supplied as a tensor; + 4 mask_rec on
+    the affine units.  Hand-over = this build's own extra traffic: the identity maps a single-frame unit writes
+    and its multi-frame partner reads (8 B/px each) -- priced separately, NOT part of `roofline.achieved`."""
     groups = 3 if use_affine else 2
     per = [FB_BYTES_PER_PX + (NOISE_BYTES_PER_PX if noise_tensor else 0)] * groups
-    if share_identity:
-        per[0] += 8
-        per[1] += 8
     if use_affine:
         per[2] += MASK_BYTES_PER_PX
-    return sum(per) / groups
+    hand = [8.0 if share_identity else 0.0, 8.0 if share_identity else 0.0] + [0.0] * (groups - 2)
+    return sum(per) / groups, sum(hand) / groups
 
 
 class HotPathStep:
@@ -324,7 +323,8 @@ class HotPathStep:
                          K=t(inp["K"]), inv_K=t(inp["inv_K"]), mask=t(inp["mask_rec"]) if affine else None)
             self.units.append(d)
         self.images_per_step = B
-        self.bytes_per_px = unit_bytes_per_px(args.noise != "kernel", self.share and self.batched)
+        self.bytes_per_px, self.handover_bytes_per_px = unit_bytes_per_px(args.noise != "kernel",
+                                                                          self.share and self.batched)
 
     def describe(self):
         return None
@@ -529,30 +529,39 @@ def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n, fb_pixels=
     r_bwd = roof(bwd_ms, bwd_n, BWD_BYTES_PER_PX, "k_photo_bwd<fused>")
     # forward+backward of units in one tile kernel (the training path): priced on ITS OWN minimum
     # traffic (inputs read once), plus the optional planes the launches were given
+    hand_px = 0.0
     if fb_bytes_px is None:
         st = getattr(launches_hint, "trainer", launches_hint)
         o = getattr(st, "opt", None)
         if hasattr(launches_hint, "bytes_per_px"):
-            fb_bytes_px = launches_hint.bytes_per_px
+            fb_bytes_px, hand_px = launches_hint.bytes_per_px, getattr(launches_hint, "handover_bytes_per_px", 0.0)
         elif o is not None:
-            fb_bytes_px = unit_bytes_per_px(not getattr(o, "inkernel_noise", True),
-                                            getattr(o, "share_identity", True) and getattr(o, "batch_units", True)
-                                            and getattr(o, "fused_units", True),
-                                            getattr(o, "use_affine", True))
+            fb_bytes_px, hand_px = unit_bytes_per_px(
+                not getattr(o, "inkernel_noise", True),
+                getattr(o, "share_identity", True) and getattr(o, "batch_units", True)
+                and getattr(o, "fused_units", True), getattr(o, "use_affine", True))
         else:
-            fb_bytes_px = unit_bytes_per_px(args.noise != "kernel", True)
+            fb_bytes_px, hand_px = unit_bytes_per_px(args.noise != "kernel", True)
     r_fb = roof(fb_ms, fb_n, fb_bytes_px, "k_unit_fb<2>", fb_pixels)
     if r_fb:
         px_launch = (fb_pixels / fb_n) if fb_pixels else px
-        survey = (FWD_BYTES_PER_PX + BWD_BYTES_PER_PX) * px_launch / (fb_ms / fb_n / 1e3) / 1e9
+        avg_s = fb_ms / fb_n / 1e3
+        survey = (FWD_BYTES_PER_PX + BWD_BYTES_PER_PX) * px_launch / avg_s / 1e9
         r_fb["frac_survey_8d"] = round(survey / HBM_PEAK_GBS, 4)
+        # this build's own extra traffic, NOT in `achieved`: the identity maps handed from the single-frame to
+        # the multi-frame units (what the PMC traffic holds beyond the algorithmic bytes)
+        r_fb["handover_bytes_per_px"] = round(hand_px, 2)
+        r_fb["handover_bytes_per_launch"] = round(hand_px * px_launch)
+        r_fb["frac_incl_handover_bytes"] = round((fb_bytes_px + hand_px) * px_launch / avg_s / 1e9 / HBM_PEAK_GBS, 4)
         r_fb["bytes_note"] = (
             f"algorithmic bytes per pixel and unit, mean over the units of a step: {FB_BYTES_PER_PX} B (disp 4 + "
             f"target 12 + 2 sources 24 read once; argmin 1 + grad_disp 4 written), + {NOISE_BYTES_PER_PX} B when the "
-            f"tie-break noise is a tensor, + {MASK_BYTES_PER_PX} B mask_rec on the affine units, + 8 B identity maps "
-            "written by a single-frame unit and read by its multi-frame partner; a launch carries "
-            "images_per_launch images (several units); frac_survey_8d prices the same launch at SURVEY 8d's "
-            "forward 44 + backward 45 B/px (the two kernels it replaces) for comparison with round 1")
+            f"tie-break noise is a tensor, + {MASK_BYTES_PER_PX} B mask_rec on the affine units; a launch carries "
+            "images_per_launch images (several units).  The 8 B/px identity maps a single-frame unit writes and "
+            "its multi-frame partner reads are this build's own traffic (handover_bytes_*): in the PMC traffic, "
+            "not in `achieved` / `frac` (frac_incl_handover_bytes prices them too); frac_survey_8d prices the "
+            "same launch at SURVEY 8d's forward 44 + backward 45 B/px (the two kernels it replaces) for "
+            "comparison with round 1")
     cands = [(ms, r) for ms, r in ((fwd_ms, r_fwd), (bwd_ms, r_bwd), (fb_ms, r_fb)) if r]
     dominant = max(cands, key=lambda t: t[0])[1] if cands else None
     return {"unit_fwd": r_fwd, "unit_bwd": r_bwd, "unit_fwdbwd": r_fb}, dominant
