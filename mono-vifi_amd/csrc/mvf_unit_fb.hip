@@ -269,6 +269,9 @@ MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restric
 // warp of the source pair into the pair planes: plane positions tid + k*NT, k < NSTAGE.  Full
 // iterations take U positions at a time (their divide chains interleave, all taps in flight);
 // the last position runs alone, and waves whose positions all lie beyond the plane skip it.
+#ifndef MVF_FB_LDS_REDUCE
+#define MVF_FB_LDS_REDUCE 1   // final reduction of the 27 tile partials through an LDS transpose (0: DPP row sums)
+#endif
 #ifndef MVF_FB_KEEPTAPS
 #define MVF_FB_KEEPTAPS 1     // the adjoint takes the forward's taps from registers (0: re-runs the projection chain)
 #endif
@@ -1040,7 +1043,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
         for (int q = 0; q < 12; ++q) { flat[q] = accP[q].x; flat[12 + q] = accP[q].y; }
         flat[24] = fb_photo; flat[25] = fb_sx; flat[26] = fb_sy;
+#if MVF_FB_LDS_REDUCE
+        // every plane is dead by now: the transpose uses the workgroup's LDS from its start (the pose block
+        // behind the planes stays untouched)
+        static_assert(NRED * (NT + 8) + NRED * 8 <= FB_POSE, "the reduction's transpose fits in front of the pose block");
+        const float tot = block_sum_many_lds<NT, NRED>(flat, smem);
+#else
         const float tot = block_sum_many<NT, NRED>(flat, scratch);
+#endif
         const int t = threadIdx.x;
         // gp_ws [S][U*B][ntiles][12], part [U*B][ntiles][NPART]; folded by k_units_finish
         if (t < 12) a.gp_ws[(((size_t)ub) * ntiles + tile) * 12 + t] = tot;
