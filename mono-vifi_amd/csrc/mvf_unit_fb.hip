@@ -148,7 +148,7 @@ MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val,
                         (raw.y >= 0.0f && raw.y <= 1.0f) ? 1.0f : 0.0f);
     const f2 kn = -0.5f * r1 * live;        // d raw / d n
     const f2 kd = -kn * q;                  // d raw / d d = 0.5 n / d^2
-    dmux = kn * (2.0f * my * (A2 - A1)) + kd * (2.0f * mx * (B2 - B1));
+    dmux = pk_fma(kd, 2.0f * mx * (B2 - B1), kn * (2.0f * my * (A2 - A1)));      // partial derivatives: tolerance arithmetic
     dexy = kn * 2.0f * A1;
     dexx2 = kd * B1 * 2.0f;
 }
@@ -777,7 +777,8 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 cf[PX + 1] = from_right(cf[1]);
                 if (col_border) {
 #pragma unroll
-                    for (int j = 0; j < PX; ++j) hs[pl][j] = mlx[j] * cf[j] + cf[j + 1] + mrx[j] * cf[j + 2];
+                    for (int j = 0; j < PX; ++j)
+                        hs[pl][j] = pk_fma(f2s(mrx[j]), cf[j + 2], pk_fma(f2s(mlx[j]), cf[j], cf[j + 1]));
                 } else {
 #pragma unroll
                     for (int j = 0; j < PX; ++j) hs[pl][j] = (cf[j] + cf[j + 1]) + cf[j + 2];
@@ -824,10 +825,10 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 }
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    const f2 t = myu * uu[j] + hs[pl][j] + myd * dd[j];
+                    const f2 t = pk_fma(f2s(myd), dd[j], pk_fma(f2s(myu), uu[j], hs[pl][j]));     // adjoint: tolerance arithmetic
                     if (pl == 0) gw[j] += t;
-                    else if (pl == 1) gw[j] += xq[j] * t;
-                    else gw[j] += f2s(yq[j]) * t;
+                    else if (pl == 1) gw[j] = pk_fma(xq[j], t, gw[j]);
+                    else gw[j] = pk_fma(f2s(yq[j]), t, gw[j]);
                 }
             }
         }
@@ -961,22 +962,24 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 const f2 ewb = qb.sh ? mk2(w.tb.wx, 1.0f - w.tb.wx) : mk2(1.0f - w.tb.wx, w.tb.wx);
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-                    dxa[ch] = (ra0[ch].y - ra0[ch].x) * sna + (ra1[ch].y - ra1[ch].x) * na;
-                    dxb[ch] = (rb0[ch].y - rb0[ch].x) * snb + (rb1[ch].y - rb1[ch].x) * nb;
+                    // (the adjoint is tolerance arithmetic: explicit fused multiply-adds from here on; the
+                    // translation unit's -ffp-contract=off only guards the forward's exact-mode expressions)
+                    dxa[ch] = fmaf(ra1[ch].y - ra1[ch].x, na, (ra0[ch].y - ra0[ch].x) * sna);
+                    dxb[ch] = fmaf(rb1[ch].y - rb1[ch].x, nb, (rb0[ch].y - rb0[ch].x) * snb);
 #if MVF_FB_PACKROWS
                     const f2 va = (mk2(ra1[ch].x, ra1[ch].y) - mk2(ra0[ch].x, ra0[ch].y)) * ewa;
                     const f2 vb = (mk2(rb1[ch].x, rb1[ch].y) - mk2(rb0[ch].x, rb0[ch].y)) * ewb;
                     dya[ch] = va.x + va.y;
                     dyb[ch] = vb.x + vb.y;
 #else
-                    dya[ch] = (ra1[ch].x - ra0[ch].x) * ewa.x + (ra1[ch].y - ra0[ch].y) * ewa.y;
-                    dyb[ch] = (rb1[ch].x - rb0[ch].x) * ewb.x + (rb1[ch].y - rb0[ch].y) * ewb.y;
+                    dya[ch] = fmaf(ra1[ch].y - ra0[ch].y, ewa.y, (ra1[ch].x - ra0[ch].x) * ewa.x);
+                    dyb[ch] = fmaf(rb1[ch].y - rb0[ch].y, ewb.y, (rb1[ch].x - rb0[ch].x) * ewb.x);
 #endif
                 }
             }
 #endif
-            const f2 gix = g0 * mk2(dxa[0], dxb[0]) + g1 * mk2(dxa[1], dxb[1]) + g2 * mk2(dxa[2], dxb[2]);
-            const f2 giy = g0 * mk2(dya[0], dyb[0]) + g1 * mk2(dya[1], dyb[1]) + g2 * mk2(dya[2], dyb[2]);
+            const f2 gix = pk_fma(g2, mk2(dxa[2], dxb[2]), pk_fma(g1, mk2(dxa[1], dxb[1]), g0 * mk2(dxa[0], dxb[0])));
+            const f2 giy = pk_fma(g2, mk2(dya[2], dyb[2]), pk_fma(g1, mk2(dya[1], dyb[1]), g0 * mk2(dya[0], dyb[0])));
             // adjoint of unnormalise / normalise ((W-1)/2 * 2/(W-1) = 1) and of the perspective
             // divide; tolerance arithmetic: one reciprocal of z per source (see warp_point_bwd)
             const f2 gu = mk2(w.ta.inx ? gix.x : 0.0f, w.tb.inx ? gix.y : 0.0f);
@@ -985,19 +988,19 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             f2 gc[3];
             gc[0] = gu * rz;
             gc[1] = gv * rz;
-            gc[2] = -(gc[0] * w.u + gc[1] * w.v);
+            gc[2] = -pk_fma(gc[1], w.v, gc[0] * w.u);
             f2 gd = f2s(0.0f);
 #pragma unroll
             for (int jj = 0; jj < 3; ++jj) {
-                f2 gX = gc[0] * P2[0 * 4 + jj] + gc[1] * P2[1 * 4 + jj] + gc[2] * P2[2 * 4 + jj];
-                gd += gX * w.r[jj];
+                const f2 gX = pk_fma(gc[2], P2[2 * 4 + jj], pk_fma(gc[1], P2[1 * 4 + jj], gc[0] * P2[0 * 4 + jj]));
+                gd = pk_fma(gX, f2s(w.r[jj]), gd);
             }
             gdp = -(hasb ? gd.x + gd.y : gd.x) * w.depth * w.depth * a.range;
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
-                accP[q * 4 + 0] += gc[q] * w.X[0];
-                accP[q * 4 + 1] += gc[q] * w.X[1];
-                accP[q * 4 + 2] += gc[q] * w.X[2];
+                accP[q * 4 + 0] = pk_fma(gc[q], f2s(w.X[0]), accP[q * 4 + 0]);
+                accP[q * 4 + 1] = pk_fma(gc[q], f2s(w.X[1]), accP[q * 4 + 1]);
+                accP[q * 4 + 2] = pk_fma(gc[q], f2s(w.X[2]), accP[q * 4 + 2]);
                 accP[q * 4 + 3] += gc[q];
             }
         }
@@ -1020,18 +1023,18 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #ifndef MVF_ABL_NOSMOOTH
         if (xx + 1 < W) {
             const float w1 = wgt(1), df = nd - dc[1];
-            gn += cxs * w1 * sgn(df);
-            fb_sx += fabsf(df) * rden * w1;
+            gn = fmaf(cxs * w1, sgn(df), gn);
+            fb_sx = fmaf(fabsf(df) * rden, w1, fb_sx);
         }
-        if (xx - 1 >= 0) gn -= cxs * wgt(-1) * sgn(dc[-1] - nd);
+        if (xx - 1 >= 0) gn = fmaf(-cxs * wgt(-1), sgn(dc[-1] - nd), gn);
         if (yy + 1 < H) {
             const float wl = wgt(LDW), df = nd - dc[LDW];
-            gn += cys * wl * sgn(df);
-            fb_sy += fabsf(df) * rden * wl;
+            gn = fmaf(cys * wl, sgn(df), gn);
+            fb_sy = fmaf(fabsf(df) * rden, wl, fb_sy);
         }
-        if (yy - 1 >= 0) gn -= cys * wgt(-LDW) * sgn(dc[-LDW] - nd);
+        if (yy - 1 >= 0) gn = fmaf(-cys * wgt(-LDW), sgn(dc[-LDW] - nd), gn);
 #endif
-        stg_at(gd_b, plane_off4(yy, xx, W), gdp + gn * rden);
+        stg_at(gd_b, plane_off4(yy, xx, W), fmaf(gn, rden, gdp));
     }
 
     // ---- one reduction for all tile partials: grad_P of both sources, photo, smoothness sums
