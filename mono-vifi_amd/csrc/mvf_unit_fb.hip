@@ -129,6 +129,15 @@ MVF_DEV f2 normal_pair(uint32_t seed0, uint32_t seed1, uint32_t idx)
     return mk2(r * __builtin_amdgcn_cosf(u2), r * __builtin_amdgcn_sinf(u2));
 }
 
+// clamp(v, 0, 1) as ONE v_med3_f32 per component (the select form is four instructions).  Same value as
+// torch.clamp for every non-NaN input; a NaN comes out as 0 here, and the pixel that produced it still
+// poisons the loss through its own L1 term |t - p| (the SSIM map of the unit kernel is internal; the
+// stand-alone mvf_ssim_fwd keeps the NaN-propagating select).
+MVF_DEV f2 clamp01_med3_pk(f2 v)
+{
+    return mk2(__builtin_amdgcn_fmed3f(v.x, 0.0f, 1.0f), __builtin_amdgcn_fmed3f(v.y, 0.0f, 1.0f));
+}
+
 // SSIM value (exact: reference layers.py:281-290, literal order) AND its x-side partial
 // derivatives (tolerance) from ONE set of window means of a candidate pair.
 MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val, f2 &dmux, f2 &dexx2,
@@ -143,14 +152,15 @@ MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val,
     const f2 r1 = ssim_recip(d);
     const f2 q = ssim_quot(n, d, r1);
     const f2 raw = (f2s(1.0f) - q) / 2.0f;
-    val = clamp01_pk(raw);
-    const f2 live = mk2((raw.x >= 0.0f && raw.x <= 1.0f) ? 1.0f : 0.0f,
-                        (raw.y >= 0.0f && raw.y <= 1.0f) ? 1.0f : 0.0f);
-    const f2 kn = -0.5f * r1 * live;        // d raw / d n
-    const f2 kd = -kn * q;                  // d raw / d d = 0.5 n / d^2
-    dmux = pk_fma(kd, 2.0f * mx * (B2 - B1), kn * (2.0f * my * (A2 - A1)));      // partial derivatives: tolerance arithmetic
-    dexy = kn * 2.0f * A1;
-    dexx2 = kd * B1 * 2.0f;
+    val = clamp01_med3_pk(raw);
+    // the clamp passes the gradient where it changed nothing (NaN compares unequal: no gradient)
+    const f2 live = mk2(val.x == raw.x ? 1.0f : 0.0f, val.y == raw.y ? 1.0f : 0.0f);
+    // partial derivatives (tolerance arithmetic, constants folded): with L = live / d,
+    //   d raw / d n = -L / 2,  d raw / d d = L q / 2  (q = n / d), and every partial below carries a factor 2
+    const f2 L = r1 * live, Lq = L * q;
+    dmux = pk_fma(Lq, mx * (B2 - B1), -(L * (my * (A2 - A1))));
+    dexy = -(L * A1);
+    dexx2 = Lq * B1;
 }
 
 // ---- target statistics computed ONCE per pixel and channel ------------------------------------------
@@ -253,7 +263,7 @@ MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restric
             for (int j = 0; j < PX; ++j) {
                 my[j] = div9(s.sy[j]);     // (mu_y, E[y*y])
                 f2 raw = ssim_raw_pk(div9(s.sx[j]), f2s(my[j].x), div9(s.sxx[j]), f2s(my[j].y), div9(s.sxy[j]));
-                ss[j] = ss[j] + clamp01_pk(raw);
+                ss[j] = ss[j] + clamp01_med3_pk(raw);
                 ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
             }
             stash_tstats(statP + c * RPPLANE + roff, my);
