@@ -110,3 +110,25 @@ def test_train_workload_with_two_ranks_on_the_test_gpu(launcher):
     assert per.get("bn_all_gather", per.get("bn_all_reduce_fwd")) == 40.0 and per["bn_all_reduce"] == 40.0
     assert c["no_overlap"]["ms_per_step"] > 0
     assert "other_configs" not in d and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_two_ranks_over_rccl_when_the_box_has_two_gpus():
+    """On a box with at least two GPUs: `bench.py --gpus 2` starts two ranks on two devices over RCCL (the
+    driver's multi-GPU form of the benchmark at a small shape).  Skipped on the 1-GPU test boxes -- there the
+    same code runs with two gloo ranks on one GPU (above) and with RCCL in a group of one
+    (tests/test_trainer_gpu.py)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    r = _run(["--gpus", "2", "--workload", "train", "--batch", "2", "--height", "64", "--width", "96", "--steps", "3",
+              "--warmup", "2", "--no-cpu-baseline", "--comm-leg-steps", "2"], timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    c = d["comm"]
+    assert d["n_gpus"] == 2 and c["world_size"] == 2 and c["backend"].startswith("rccl")
+    assert sorted(c["devices"]) == [0, 1] and c["distinct_processes"] == 2
+    per = c["collectives_per_step"]
+    assert per["grad_all_reduce"] == float(c["grad_buckets"]) and per["bn_all_gather"] == 40.0 and per["bn_all_reduce"] == 40.0
+    assert c["exchanges_issued_during_backward"] >= c["grad_buckets"] - 1
+    assert r.stdout.strip().splitlines()[-1].startswith("{")        # the JSON line is the last line on stdout
