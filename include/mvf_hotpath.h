@@ -190,7 +190,9 @@ MVF_API int mvf_unit_fwdbwd(const float *disp, const float *tgt, const float *co
  * the units of a group share B, H, W, S and the flags and go out as one launch of
  * n_units * B * tiles workgroups.  Images are addressed as base + b * stride (strides in FLOATS,
  * 0 = contiguous), so the interleaved [B*G,...] output of a grouped decoder call is read in
- * place; inside an image the reference's planar layout is required (3*H*W*4 < 2^32 bytes).
+ * place; inside an image the reference's planar layout is required, and a plane must stay below
+ * 2^28 bytes (H*W < 67,108,864: tap offsets travel with four flag bits above them) -- larger shapes
+ * return hipErrorInvalidValue.
  *
  * ident_out / ident_in ([B,H,W,2], nullable): the two identity-reprojection maps of the unit
  * (compute_reprojection_loss of the raw sources against the target, train.py:1020-1022, BEFORE
