@@ -132,6 +132,10 @@ def parse():
                     help="seconds of wall time after which the OPTIONAL legs that have not started yet (other "
                          "configs, hot-path-only leg, CPU baselines) are skipped and reported as skipped -- the "
                          "line must come out within minutes even on a box whose MIOpen find-db is cold")
+    ap.add_argument("--no-pmc-leg", dest="pmc_leg", action="store_false", default=True,
+                    help="N = 1 headline run: skip the live PMC passes (rocprofv3 --pmc around short hot-path runs of "
+                         "this script as child processes: HBM traffic and VALU instruction counts of the unit "
+                         "kernel per launch); roofline.traffic / valu then quote the committed profiles/ summary")
     ap.add_argument("--also-steps", dest="also_steps", type=int, default=10)
     ap.add_argument("--also-warmup", dest="also_warmup", type=int, default=5)
     return ap.parse_args()
@@ -659,6 +663,67 @@ def graph_step_leg(args, steps=20, timeout_s=150):
         return {"error": f"{type(e).__name__}: {e}"[:300]}
 
 
+def pmc_leg(args, timeout_s=120):
+    """HBM traffic and VALU counters of the unit kernel, measured NOW: `rocprofv3 --pmc` (counters only, one
+    pass per TCC counter as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE do not
+    fit one pass) around a short hot-path run of this script in a child process, mean per launch of
+    k_unit_fb.  FETCH_SIZE is doubled (the guide's gfx950 note; calibrated here on k_disp_mean, whose
+    5,898,240 B read 2,894 KB), WRITE_SIZE taken 1:1.  Returns None when rocprofv3 is not there or a pass fails
+    (the line then quotes the committed summary, tagged `static_source`)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    passes = [["FETCH_SIZE"], ["WRITE_SIZE"],
+              ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY",
+               "GRBM_GUI_ACTIVE"]]
+    got, launches = {}, 0
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    t0 = time.perf_counter()
+    for counters in passes:
+        d = tempfile.mkdtemp(prefix="mvf_pmc_", dir="/tmp")
+        cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--workload", "hotpath", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
+               "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--noise", args.noise]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+            acc = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if "k_unit_fb" in row["Kernel_Name"]:
+                            a = acc.setdefault(row["Counter_Name"], [0.0, 0])
+                            a[0] += float(row["Counter_Value"])
+                            a[1] += 1
+            for c in counters:
+                if c not in acc:
+                    return None
+                got[c] = acc[c][0] / acc[c][1]
+                launches = acc[c][1]
+        except (subprocess.TimeoutExpired, OSError, ValueError, KeyError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    px_launch = 3.0 * args.batch * args.height * args.width        # three units per launch
+    quad = got["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0            # SQ counters tick in quad-cycles over 1,024 SIMDs
+    return {"traffic": int(round(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)),
+            "valu": {"valu_busy": round(got["SQ_ACTIVE_INST_VALU"] / quad, 3),
+                     "valu_instr_per_px": int(round(got["SQ_INSTS_VALU"] * 64.0 / px_launch)),
+                     "wave_active": round(got["SQ_ACTIVE_INST_ANY"] / got["SQ_WAVE_CYCLES"], 3),
+                     "wave_wait_memory_or_barrier": round(got["SQ_WAIT_ANY"] / got["SQ_WAVE_CYCLES"], 3),
+                     "wave_wait_issue": round(got["SQ_WAIT_INST_ANY"] / got["SQ_WAVE_CYCLES"], 3)},
+            "source": {"measured": "in this run", "how": "rocprofv3 --pmc (three counter-only passes) around child runs of "
+                       "`bench.py --workload hotpath` (3 units per launch, same shapes); FETCH_SIZE x 2 (gfx950 note of "
+                       "MI355X_MICROARCH.md) + WRITE_SIZE; mean over " + str(launches) + " launches of k_unit_fb",
+                       "leg_seconds": round(time.perf_counter() - t0, 1)}}
+
+
 OTHER_CONFIGS = {
     # BASELINE.json configs[2..4] at their per-GPU shapes (reference: configs/dhrnet/DHRNet_KITTI_MR.txt,
     # configs/litemono/LiteMono_KITTI_HR.txt, configs/dhrnet/DHRNet_CS.txt)
@@ -846,6 +911,17 @@ def main():
         gc.collect()
         torch.cuda.empty_cache()
         graph_leg = graph_step_leg(args) if not over_budget(args, 40) else {"skipped": "time budget"}
+
+    # ---- live PMC passes of the unit kernel (child processes under rocprofv3; N = 1 headline run only)
+    if default_headline and rank == 0 and args.pmc_leg and dominant and dominant.get("kernel") == "k_unit_fb<2>":
+        live = pmc_leg(args) if not over_budget(args, 60) else None
+        if live:
+            dominant["traffic"], dominant["valu"] = live["traffic"], live["valu"]
+            dominant["static_source"] = None
+            dominant["pmc_source"] = live["source"]
+            dominant["traffic_over_algorithmic"] = round(live["traffic"] / dominant["algorithmic_bytes_per_launch"], 3)
+            dominant["traffic_over_algorithmic_plus_handover"] = round(
+                live["traffic"] / (dominant["algorithmic_bytes_per_launch"] + dominant.get("handover_bytes_per_launch", 0)), 3)
 
     if rank == 0:
         n_gpus = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
