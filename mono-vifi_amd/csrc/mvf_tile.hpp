@@ -321,7 +321,7 @@ struct PoseLds {
     float den;    // per-image mean disparity + 1e-7
     float gpix;   // backward: upstream grad / (B*H*W)
     float gloss;
-    float pad;
+    float rden;   // 1 / den (forward+backward unit kernel: phase 8)
 };
 
 MVF_DEV void load_pose_pair(const PoseLds &sh, int ka, int kb, f2 P2[12])

@@ -515,6 +515,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         float m = 0.0f;
         for (int i = 0; i < NMEAN; ++i) m += u.mean_ws[b * NMEAN + i];
         sh.den = m / (float)N + 1e-7f;
+        sh.rden = 1.0f / sh.den;          // reciprocal of the mean-normalisation constant (phase 8), once per workgroup
         sh.gpix = 1.0f / (float)((double)a.B * (double)N);
     }
     if (threadIdx.x < 12 * S) {
@@ -859,9 +860,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     float *gd_b = uniform_ptr(u.g_disp + (size_t)b * u.g_stride);
     f2 accP[12];
 #pragma unroll
-    for (int q = 0; q < 12; ++q) accP[q] = f2s(0.0f);
+    for (int q = 0; q < 12; ++q) {
+        accP[q] = f2s(0.0f);
+        // one definition, here: without the pin the compiler re-creates these zeros at every level of the
+        // position loop's condition nest (36 register moves per wave in the first pass alone)
+        asm volatile("" : "+v"(accP[q]));
+    }
     float fb_sx = 0.0f, fb_sy = 0.0f;
-    const float rden = 1.0f / sh.den;
+    const float rden = sh.rden;
     const float cxs = a.smoothness / (float)((double)a.B * H * (W - 1));
     const float cys = a.smoothness / (float)((double)a.B * (H - 1) * W);
 #ifndef MVF_FB_UNROLL7
