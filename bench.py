@@ -128,7 +128,7 @@ def parse():
                          "Lite-Mono 1024x320, DHRNet 512x192) for a few steps each and report them as "
                          "`other_configs`; auto = on for the default headline run, 'none' = off, or a "
                          "comma list of C3,C4,C5")
-    ap.add_argument("--time-budget", dest="time_budget", type=float, default=420.0,
+    ap.add_argument("--time-budget", dest="time_budget", type=float, default=300.0,
                     help="seconds of wall time after which the OPTIONAL legs that have not started yet (other "
                          "configs, hot-path-only leg, CPU baselines) are skipped and reported as skipped -- the "
                          "line must come out within minutes even on a box whose MIOpen find-db is cold")
@@ -910,11 +910,11 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        graph_leg = graph_step_leg(args) if not over_budget(args, 40) else {"skipped": "time budget"}
+        graph_leg = graph_step_leg(args) if not over_budget(args, 60) else {"skipped": "time budget"}
 
     # ---- live PMC passes of the unit kernel (child processes under rocprofv3; N = 1 headline run only)
     if default_headline and rank == 0 and args.pmc_leg and dominant and dominant.get("kernel") == "k_unit_fb<2>":
-        live = pmc_leg(args) if not over_budget(args, 60) else None
+        live = pmc_leg(args) if not over_budget(args, 120) else None
         if live:
             dominant["traffic"], dominant["valu"] = live["traffic"], live["valu"]
             dominant["static_source"] = None
