@@ -132,6 +132,8 @@ def parse():
                     help="seconds of wall time after which the OPTIONAL legs that have not started yet (other "
                          "configs, hot-path-only leg, CPU baselines) are skipped and reported as skipped -- the "
                          "line must come out within minutes even on a box whose MIOpen find-db is cold")
+    ap.add_argument("--no-replay-leg", dest="replay_leg", action="store_false", default=True,
+                    help="hotpath workload: skip the HIP-graph replay measurement (the PMC child runs do)")
     ap.add_argument("--no-pmc-leg", dest="pmc_leg", action="store_false", default=True,
                     help="N = 1 headline run: skip the live PMC passes (rocprofv3 --pmc around short hot-path runs of "
                          "this script as child processes: HBM traffic and VALU instruction counts of the unit "
@@ -687,8 +689,8 @@ def pmc_leg(args, timeout_s=120):
     for counters in passes:
         d = tempfile.mkdtemp(prefix="mvf_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
-               os.path.abspath(__file__), "--workload", "hotpath", "--steps", "3", "--warmup", "2", "--no-cpu-baseline",
-               "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--noise", args.noise]
+               os.path.abspath(__file__), "--workload", "hotpath", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+               "--no-replay-leg", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--noise", args.noise]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             if r.returncode != 0:
@@ -953,7 +955,7 @@ def main():
             out["hip_graph_step"] = graph_leg
         if other:
             out["other_configs"] = other
-        if workload == "hotpath" and world == 1:
+        if workload == "hotpath" and world == 1 and args.replay_leg:
             out["hip_graph_replay"] = graph_replay_leg(step)
         if not args.no_cpu_baseline and world == 1 and workload != "mock":
             # the required baseline always runs (bounded: --cpu-seconds + a thread sweep); the second one
