@@ -169,17 +169,39 @@ MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val,
 // until the adjoint: each lane writes and later reads only the entries of its own pixels, so no
 // barrier is involved), and the warped pass reads them back instead of re-accumulating 9 taps of
 // y and y*y per pixel and channel.  Exact mode is untouched: same sums in the same order.
+// (sum y, sum y*y) over the 3x3 target windows of a lane's TWO pixels, packed over the PIXELS: the three
+// column pairs (c0,c1), (c1,c2), (c2,c3) of a row are the (d = 0, 1, 2) taps of (pixel 0, pixel 1), so each
+// half still adds its nine taps in the reference's row-major order -- exact mode untouched -- while a row
+// costs 2 packed multiplies + 2 pair moves + 6 packed adds (the (y, y*y)-per-pixel form: 4 multiplies +
+// 4 moves + 6 adds).  The stash then holds (mu_y px0, mu_y px1, E[yy] px0, E[yy] px1).
+struct TStat2 {
+    f2 sy, syy;
+};
+MVF_DEV void tstat_row(const Row6 &y, bool first, TStat2 &t)
+{
+    static_assert(PX == 2, "pixel-packed target statistics: two pixels per lane");
+    const f2 y01 = mk2(y.v[0], y.v[1]), y12 = mk2(y.v[1], y.v[2]), y23 = mk2(y.v[2], y.v[3]);
+    const f2 q01 = y01 * y01, q23 = y23 * y23, q12 = mk2(q01.y, q23.x);
+    if (first) { t.sy = y01; t.syy = q01; }
+    else { t.sy = t.sy + y01; t.syy = t.syy + q01; }
+    t.sy = t.sy + y12; t.syy = t.syy + q12;
+    t.sy = t.sy + y23; t.syy = t.syy + q23;
+}
+// (mu_y, E[y*y]) of pixel j out of the pixel-packed means
+MVF_DEV f2 tstat_of(const f2 tm[PX], int j) { return j == 0 ? mk2(tm[0].x, tm[1].x) : mk2(tm[0].y, tm[1].y); }
+
 struct Stats4X {
     f2 sx[PX], sxx[PX], sxy[PX];
     f2 xc[PX];
     float yc[PX];
 };
-MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X &o)
+MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X &o, TStat2 *t = nullptr)
 {
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         Row6P x = load_row6p(xs + r * LDW);
         Row6 y = load_row6(ys + r * LDW);
+        if (t) tstat_row(y, r == 0, *t);
         f2 xx[RW], xy[RW];
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
@@ -226,20 +248,11 @@ MVF_DEV void fetch_tstats(const f2 *__restrict__ statP, f2 my[PX])
 // window means of the target alone (no auto-masking: there is no identity pass to ride on)
 MVF_DEV void target_stats(const float *__restrict__ ys, f2 my[PX])
 {
-    f2 sy[PX];
+    TStat2 t;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        Row6 y = load_row6(ys + r * LDW);
-#pragma unroll
-        for (int j = 0; j < PX; ++j)
-#pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const f2 yy = mk2(y.v[j + d], y.v[j + d] * y.v[j + d]);
-                sy[j] = (r == 0 && d == 0) ? yy : sy[j] + yy;
-            }
-    }
-#pragma unroll
-    for (int j = 0; j < PX; ++j) my[j] = div9(sy[j]);
+    for (int r = 0; r < 3; ++r) tstat_row(load_row6(ys + r * LDW), r == 0, t);
+    my[0] = div9(t.sy);        // (mu_y px0, mu_y px1)
+    my[1] = div9(t.syy);       // (E[yy] px0, E[yy] px1)
 }
 // identity candidates (reference: train.py:973-985 on the raw sources), stashing the target means
 MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restrict__ tgt, int off,
@@ -256,13 +269,16 @@ MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restric
 #pragma unroll
             for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(y.v[j + 1]) - x.v[j + 1]);
         } else {
-            Stats4P s;
-            window_xp(pair + c * PPLANE + off, tgt + c * PLANE + off, s);
+            Stats4X s;
+            TStat2 t;
+            window_x(pair + c * PPLANE + off, tgt + c * PLANE + off, s, &t);
             f2 my[PX];
+            my[0] = div9(t.sy);        // (mu_y px0, mu_y px1)
+            my[1] = div9(t.syy);       // (E[yy] px0, E[yy] px1)
 #pragma unroll
             for (int j = 0; j < PX; ++j) {
-                my[j] = div9(s.sy[j]);     // (mu_y, E[y*y])
-                f2 raw = ssim_raw_pk(div9(s.sx[j]), f2s(my[j].x), div9(s.sxx[j]), f2s(my[j].y), div9(s.sxy[j]));
+                const f2 m = tstat_of(my, j);
+                f2 raw = ssim_raw_pk(div9(s.sx[j]), f2s(m.x), div9(s.sxx[j]), f2s(m.y), div9(s.sxy[j]));
                 ss[j] = ss[j] + clamp01_med3_pk(raw);
                 ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
             }
@@ -635,7 +651,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 fetch_tstats(coefP + c * RPPLANE + roff, tm);
 #pragma unroll
                 for (int j = 0; j < PX; ++j) {
-                    const f2 my = tm[j];
+                    const f2 my = tstat_of(tm, j);
                     f2 val;
                     ssim_val_partials_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
                                          div9(s.sxy[j]), val, pm[c][j], px2[c][j], pg[c][j]);
