@@ -46,7 +46,7 @@ def rel_l2(a, b):
     return float(np.linalg.norm(a - b) / (den if den > 0 else 1.0))
 
 
-def assert_grad_close(a, b, tol=1e-4, what="grad"):
+def assert_grad_close(a, b, tol=1e-4, what="grad", max_tol=None):
     """Tolerance for full-size gradient tensors (1e4..1e6 elements).
 
     The 1e-4 relative bar is applied to the tensor (relative L2 error).  Per element the
@@ -54,11 +54,16 @@ def assert_grad_close(a, b, tol=1e-4, what="grad"):
     (d sigma/dx = 2(x - mu)/9 with x ~ mu), so the reference's own fp32 autograd, the fp32
     oracle and this kernel -- three legitimate fp32 evaluation orders -- sit ~1e-4 of the
     tensor max apart at their worst pixel (measured: reference vs oracle 2.2e-4 at C1,
-    DESIGN.md section 6).  The small golden fixtures are still held to 1e-4 per element."""
+    DESIGN.md section 6).  The small golden fixtures are still held to 1e-4 per element.
+    `max_tol` overrides the per-element bound: the training kernel's gradients are held to 1e-4 per element
+    against the REFERENCE's own sampled gradients at the BASELINE shapes (measured worst 5.3e-5) and to 5e-4
+    against the oracle's whole tensors (measured worst 2.7e-4 of 1.5-2.6 M pixels:
+    profiles/r03_grad_error_report.txt)."""
     l2 = rel_l2(a, b)
     mx = rel_err(a, b)
+    max_tol = 10 * tol if max_tol is None else max_tol
     assert l2 <= tol, f"{what}: relative L2 error {l2:.3e} > {tol}"
-    assert mx <= 10 * tol, f"{what}: max error {mx:.3e} of tensor max > {10 * tol}"
+    assert mx <= max_tol, f"{what}: max error {mx:.3e} of tensor max > {max_tol}"
 
 
 def torch_flow_warp(img, flow):

@@ -243,13 +243,18 @@ def test_fullsize_unit(dev, cfg, unit_kernel):
     assert np.array_equal(am[sidx], g["auto_mask_s"])
     assert abs(am.mean() - float(g["auto_mask_mean"])) <= 1e-6
     gd = N(disp.grad)
-    assert_grad_close(gd.reshape(n)[sidx], g["grad_disp_s"], TOL, "grad_disp vs reference (sampled)")
+    # the training kernel against the REFERENCE's own gradients: 1e-4 on the tensor AND per element (north_star's
+    # bar; measured worst 5.3e-5 -- as close to the reference as the fp64-folding oracle is)
+    assert_grad_close(gd.reshape(n)[sidx], g["grad_disp_s"], TOL, "grad_disp vs reference (sampled)",
+                      max_tol=TOL if unit_kernel == "fwdbwd" else None)
     assert abs(np.linalg.norm(gd.astype(np.float64)) - float(g["grad_disp_norm"])) <= TOL * float(g["grad_disp_norm"])
     # whole tensors vs the oracle (fp64 reductions on both sides)
     ref = O.unit(inp["disp"], inp["tgt"], inp["src"], g["T"], inp["K"], inp["inv_K"], inp["noise"],
                  inp["mask_rec"], 0, want_grads=True)
     assert np.array_equal(N(argmin).astype(np.int32), ref["idx"])
-    assert_grad_close(gd, ref["grad_disp"], TOL, "grad_disp vs oracle")
+    # whole tensor vs the oracle: two fp32 evaluation orders of a cancelling adjoint differ by up to 2.7e-4 of the
+    # tensor max at the worst of 1.5-2.6 M pixels (profiles/r03_grad_error_report.txt): per-element bar 5e-4
+    assert_grad_close(gd, ref["grad_disp"], TOL, "grad_disp vs oracle", max_tol=5e-4 if unit_kernel == "fwdbwd" else None)
     assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
     # the reference itself reduces grad_P in fp32; its own value is only good to ~5e-3
     assert rel_err(N(Tt.grad), g["grad_T"]) <= 5e-3
