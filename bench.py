@@ -48,10 +48,10 @@ if ROOT not in sys.path:
 for _d in ("FWD", "BWD", "WRW"):
     os.environ.setdefault("MIOPEN_DEBUG_CONV_DIRECT_NAIVE_CONV_" + _d, "0")
 
-# before torch: importing the package puts the shipped MIOpen find-db and DEBUG_CLR_GRAPH_PACKET_CAPTURE=0
-# (whole-step HIP graphs) into the environment; the HIP runtime reads the latter at its
-# first call
-import mono_vifi_amd  # noqa: E402,F401
+# importing the package sets nothing; main() calls its two entry-point helpers before the first HIP call:
+# DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 only when --hip-graph was asked for, and a per-process
+# copy of the shipped MIOpen find-db (the tracked file is never MIOpen's writable user db)
+import mono_vifi_amd  # noqa: E402
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -223,7 +223,7 @@ def comm_report(args, world, rank, dev, backend, step, counts_per_step):
     red = getattr(getattr(step, "trainer", step), "reducer", None)
     rep = {"backend": "rccl (torch backend 'nccl')" if backend == "nccl" else backend,
            "world_size": dist.get_world_size(), "devices": devices,
-           "distinct_processes": len(set(pids)),
+           "distinct_processes": len(set(pids)), "pids": pids,
            "grad_exchange": red.exchange if red else None,
            "overlap_with_backward": bool(red.overlap) if red else None,
            "grad_buckets": red.num_buckets if red else 0,
@@ -796,7 +796,11 @@ def over_budget(args, need_s):
 
 def main():
     args = parse()
+    if args.hip_graph:
+        mono_vifi_amd.ensure_graph_replay_env()       # before the first HIP call of this process and of its ranks
     launch_ranks_if_needed(args)
+    if args.workload != "mock":
+        mono_vifi_amd.use_shipped_miopen_db()         # per rank: after the launcher re-executed, before any convolution
     world, rank, dev, backend = dist_setup(args)
     from mono_vifi_amd import parallel
 

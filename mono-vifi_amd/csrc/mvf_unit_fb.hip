@@ -549,12 +549,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // tiles whose staged plane lies inside the image need no reflect / clamp mapping of the
     // coordinates they stage and warp (scalar branch; 240 of 308 tiles at 640x192)
     const bool inner = (py0 >= 0) && (px0 >= 0) && (py0 + PH <= H) && (px0 + PW <= W);
+#ifndef MVF_ABL_NOSTAGE   // timing ablation: nothing staged (the planes keep what the previous workgroup left there)
     if (automask && !ident_given) {
         stage_first(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, H, W, py0, px0, inner);
     } else {
         stage_planes3(tgtP, tgt_b, N, H, W, py0, px0, inner);
         stage_plane(dispP, disp_b, H, W, py0, px0, inner);
     }
+#endif
     __syncthreads();
 
     f2 P2[12];
@@ -680,7 +682,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         const unsigned pix4 = plane_off4(min(max(y, 0), H - 1), min(max(x, 0), W - 1), W);
         mraw[j] = in ? (mask_b ? ldg_at(mask_b, pix4) : 1.0f) : 0.0f;
         nz[j] = f2s(0.0f);
+#ifdef MVF_ABL_NONOISE   // timing ablation: no tie-break noise
+        if (false) {
+#else
         if (automask && in) {
+#endif
             if (u.noise) {
                 const float *nb = uniform_ptr(u.noise + (size_t)b * (avg ? 1 : S) * N);
                 if (avg) nz[j] = f2s(ldg_at(nb, pix4));
@@ -699,6 +705,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // ---- 5: min / argmin / mask / outputs (reference: train.py:1010-1043)
     f2 wk[PX];                 // adjoint weight of the two warped candidates
     float fb_photo = 0.0f;
+#ifdef MVF_ABL_NO5       // timing ablation: no min / argmin / mask / outputs (every candidate value stays live)
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        asm volatile("" :: "v"(vw[j]), "v"(vid[j]), "v"(nz[j]));
+        wk[j] = f2s(sh.gpix * mraw[j]);
+    }
+    if (false)
+#endif
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         const int x = x0 + j, col = seg * PX + j;
@@ -790,7 +804,18 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #endif
     for (int c = 0; c < 3; ++c) {
         f2 hs[3][PX];              // row sums of A, B, G at this lane's columns
+#ifdef MVF_ABL_NO6H      // timing ablation: no SSIM adjoint at all (coefficients, DPP row sums, LDS round trip, gather)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                asm volatile("" :: "v"(pm[c][j]), "v"(px2[c][j]), "v"(pg[c][j]));
+                hs[pl][j] = f2s(0.0f);
+            }
+        if (false) {
+#else
         if (!no_ssim) {
+#endif
             if (c > 0) __syncthreads();        // vertical reads of the previous channel done
 #pragma unroll
             for (int pl = 0; pl < 3; ++pl) {
@@ -834,7 +859,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                         (df.y > 0.0f) ? -1.0f : ((df.y < 0.0f) ? 1.0f : 0.0f));
             gw[j] = wk[j] * ((no_ssim ? 1.0f : 0.15f) * (1.0f / 3.0f)) * sg;
         }
-#ifdef MVF_ABL_NOGATHER
+#if defined(MVF_ABL_NOGATHER) || defined(MVF_ABL_NO6H)
         if (false) {
 #else
         if (!no_ssim && row >= 1 && row <= OH) {
@@ -1066,7 +1091,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         }
         if (yy - 1 >= 0) gn = fmaf(-cys * wgt(-LDW), sgn(dc[-LDW] - nd), gn);
 #endif
+#ifdef MVF_ABL_NOSTORE    // timing ablation: grad_disp not stored
+        { const float gout = fmaf(gn, rden, gdp); asm volatile("" :: "v"(gout)); }
+#else
         stg_at(gd_b, plane_off4(yy, xx, W), fmaf(gn, rden, gdp));
+#endif
     }
 
     // ---- one reduction for all tile partials: grad_P of both sources, photo, smoothness sums
@@ -1078,7 +1107,12 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
         for (int q = 0; q < 12; ++q) { flat[q] = accP[q].x; flat[12 + q] = accP[q].y; }
         flat[24] = fb_photo; flat[25] = fb_sx; flat[26] = fb_sy;
-#if MVF_FB_LDS_REDUCE
+#ifdef MVF_ABL_NORED     // timing ablation: no workgroup reduction (the partials stay live)
+        float tot = 0.0f;
+#pragma unroll
+        for (int q = 0; q < NRED; ++q) asm volatile("" :: "v"(flat[q]));
+        tot = (threadIdx.x & 1) ? flat[1] : flat[0];
+#elif MVF_FB_LDS_REDUCE
         // every plane is dead by now: the transpose uses the workgroup's LDS from its start (the pose block
         // behind the planes stays untouched)
         static_assert(NRED * (NT + 8) + NRED * 8 <= FB_POSE, "the reduction's transpose fits in front of the pose block");

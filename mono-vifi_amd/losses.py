@@ -101,8 +101,11 @@ class HotPathLosses:
         ``units``: list of dicts with keys disp_tgt, img_tgt, poses, imgs_src, K, inv_K and
         optionally mask_rec, ident (the identity maps another unit with the same target and
         sources returned).  Returns (losses [n], idents list | None, auto_masks list | None).
-        Falls back to one `compute_unit` per entry when the forward+backward kernel cannot take
-        them (S > 2, no gradient wanted, an injected noise tensor...)."""
+        Falls back to one `compute_unit` per entry -- and then returns `idents = None`: no identity
+        maps are handed over, the partner units re-evaluate them -- when the forward+backward kernel
+        cannot take the group as one launch: `--batch_units False`, more than MAX_UNITS entries, S > 2,
+        no gradient wanted, or entries of different shapes.  An injected `tie_break_noise` tensor does
+        NOT force the fallback: the batched launch takes the noise as a tensor per unit."""
         o = self.opt
         n = len(units)
         prepared = []

@@ -402,15 +402,31 @@ def _img(t):
 _TICKETS = {}
 
 
+def _ticket_key(dev):
+    return (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+
+
 def _tickets(dev, n):
     """Zeroed int32 counters for the in-kernel finishing folds: one persistent buffer per
-    (device, stream) -- launches on a stream are ordered and each leaves the counters zero."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    (device, stream) -- launches on a stream are ordered and each leaves the counters zero.
+    A launch that FAILS may leave them non-zero (the unit kernel ran, the finishing kernel did not, or was
+    aborted): `_drop_tickets` then forgets the buffer, so that the next launch on the stream starts from a
+    freshly zeroed one instead of folding on a stale count."""
+    key = _ticket_key(dev)
     t = _TICKETS.get(key)
     if t is None or t.numel() < n:
         t = torch.zeros(max(n, 1024), dtype=torch.int32, device=dev)
         _TICKETS[key] = t
     return t
+
+
+def _drop_tickets(dev):
+    _TICKETS.pop(_ticket_key(dev), None)
+
+
+def _expect_shape(name, t, shape):
+    if t is not None and tuple(t.shape) != tuple(shape):
+        raise RuntimeError(f"{name} must be {tuple(shape)}, got {tuple(t.shape)}")
 
 
 UNIT_FIELDS = 8      # tensors per unit in Units.apply before its sources
@@ -457,6 +473,16 @@ class Units(torch.autograd.Function):
             if tuple(disp.shape) != (B, 1, H, W):
                 raise RuntimeError("the units of one launch must share the shape [B,1,H,W]")
             nat.require_device(disp, tgt, T, K, inv_K, mask_rec, noise, ident_in, *src)
+            # raw pointers and strides go to the kernel: every plane it will index is checked here (a target or
+            # source of another resolution / batch size would be an out-of-bounds device read, not an error)
+            _expect_shape("tgt", tgt, (B, 3, H, W))
+            for k, im in enumerate(src):
+                _expect_shape(f"src[{k}]", im, (B, 3, H, W))
+            _expect_shape("mask_rec", mask_rec, (B, 1, H, W))
+            _expect_shape("K", K, (B, 4, 4))
+            _expect_shape("inv_K", inv_K, (B, 4, 4))
+            if noise is not None:
+                _expect_shape("noise", noise, (B, 1 if (flags & AVG_REPROJ) else S, H, W))
             disp, ds = _img(disp)
             tgt, ts = _img(tgt)
             mask_rec, ms = _img(mask_rec)
@@ -506,9 +532,13 @@ class Units(torch.autograd.Function):
             needs.append((ctx.needs_input_grad[1 + u * per], ctx.needs_input_grad[1 + u * per + 2]))
         ws = torch.empty(nat.lib().mvf_units_workspace_floats(n, B, H, W), dtype=torch.float32, device=dev)
         tk = _tickets(dev, nat.lib().mvf_units_ticket_ints(n, B))
-        nat.check(nat.lib().mvf_units_fwdbwd(C.cast(descs, C.c_void_p), n, S, flags, smoothness, md, rg,
-                                             cfg["eps"], nat.ptr(ws), nat.ptr(tk), B, H, W, _stream()),
-                  "units_fwdbwd")
+        try:
+            nat.check(nat.lib().mvf_units_fwdbwd(C.cast(descs, C.c_void_p), n, S, flags, smoothness, md, rg,
+                                                 cfg["eps"], nat.ptr(ws), nat.ptr(tk), B, H, W, _stream()),
+                      "units_fwdbwd")
+        except Exception:
+            _drop_tickets(dev)          # the counters may be non-zero now: never reuse them
+            raise
         ctx.save_for_backward(g_disp, g_T, stats)
         ctx.n, ctx.S, ctx.smoothness, ctx.per, ctx.needs = n, S, smoothness, per, needs
         res = (loss3[:, 0], loss3[:, 1:], *outs)

@@ -112,7 +112,9 @@ def build_parser():
     p.add_argument("--share_identity", type=_str2bool, default=True,
                    help="the multi-frame unit of a target takes the identity-reprojection maps the "
                         "single-frame unit of the same target and sources computed (train.py:747-749 vs "
-                        "795-797) instead of re-evaluating them")
+                        "795-797) instead of re-evaluating them.  Only active together with --batch_units and "
+                        "--fused_units, two sources per unit and auto-masking on (the trainer logs once when it "
+                        "is requested but inactive)")
     p.add_argument("--device_augment", type=_str2bool, default=True,
                    help="flip / ColorJitter / affine views of a batch on the device (augment.py) instead "
                         "of per item on the host (reference: datasets/mono_dataset.py:102-184)")
@@ -123,9 +125,10 @@ def build_parser():
                    help="capture the device work of an optimisation step (networks, hot-path units, backward, "
                         "clipping, AdamW) once into a HIP graph and replay it: one launch per step instead of "
                         "thousands (needs static shapes; trainer._StepGraph).  Runs with the HIP runtime's graph "
-                        "packet capture switched off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, set when the package is "
-                        "imported): with it the replay faults at the BASELINE shapes on ROCm 7.2 (DESIGN.md "
-                        "section 7).  A GPU memory fault during a replay cannot be caught")
+                        "packet capture switched off (DEBUG_CLR_GRAPH_PACKET_CAPTURE=0, put into the environment "
+                        "when this option is parsed / by the Trainer, before the first HIP call): with it the "
+                        "replay faults at the BASELINE shapes on ROCm 7.2 (DESIGN.md section 7).  A GPU memory "
+                        "fault during a replay cannot be caught")
     p.add_argument("--hip_graph_scope", type=str, default="step", choices=["step", "backward"],
                    help="--hip_graph: what the captured graph holds.  step (default): everything incl. clipping "
                         "and the capturable AdamW (learning rate resident on the device).  backward: networks, "
@@ -194,7 +197,16 @@ def parse_args(argv=None):
         opts.global_rank = int(os.environ["RANK"])
     if "WORLD_SIZE" in os.environ:
         opts.world_size = int(os.environ["WORLD_SIZE"])
+    _graph_env(opts)
     return opts
+
+
+def _graph_env(opts):
+    """--hip_graph was asked for: the HIP runtime's graph packet capture must be off before the process's first
+    HIP call (mono_vifi_amd.ensure_graph_replay_env) -- option parsing is the earliest point an entry point has."""
+    if getattr(opts, "hip_graph", False):
+        from . import ensure_graph_replay_env
+        ensure_graph_replay_env()
 
 
 def default_options(**overrides):
@@ -204,4 +216,5 @@ def default_options(**overrides):
         if not hasattr(opts, k):
             raise AttributeError(k)
         setattr(opts, k, v)
+    _graph_env(opts)
     return opts

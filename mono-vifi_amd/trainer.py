@@ -59,6 +59,14 @@ class Trainer(HotPathLosses):
     def __init__(self, options):
         self.opt = options
         o = self.opt
+        # Process-level settings of an entry point, before this process touches the GPU (importing the package
+        # sets nothing): whole-step HIP graphs need the runtime's graph packet capture off (read at the first
+        # HIP call -- `strict` raises when torch's GPU context already exists without it), and MIOpen gets a
+        # per-process copy of the shipped find-db (never the tracked file, never one file for eight ranks).
+        from . import ensure_graph_replay_env, use_shipped_miopen_db
+        if bool(getattr(o, "hip_graph", False)):
+            ensure_graph_replay_env(strict=True)      # (no torch.cuda call before this line: any HIP call fixes the flag)
+        use_shipped_miopen_db()
         self.log_path = os.path.join(o.log_dir, o.exp_name)
         if o.global_rank == 0:
             os.makedirs(self.log_path, exist_ok=True)
@@ -202,9 +210,6 @@ class Trainer(HotPathLosses):
         graph_opt = use_graph and getattr(o, "hip_graph_scope", "step") == "step"
         if graph_opt and o.optimizer not in ("adamw", "adam"):
             raise ValueError("--hip_graph_scope step needs a capturable optimizer (adamw / adam)")
-        if use_graph:
-            from . import ensure_graph_replay_env
-            ensure_graph_replay_env(strict=True)      # the runtime's graph packet capture must be off
         if use_graph:
             logging.warning("--hip_graph: the optimisation step is captured into a HIP graph and replayed (with the "
                             "HIP runtime's graph packet capture switched off, DESIGN.md section 7); a GPU memory "
@@ -599,6 +604,12 @@ class Trainer(HotPathLosses):
                                     unit(disp_pt, img_pt, [pose_pt_n1, pose_pt_p1]),
                                     unit(disp_nt, img_nt, [pose_nt_n1, pose_nt_p1])], want_ident=share)
         losses["loss_base"] = losses["loss_base"] + l_sf
+        if share and idents is None and not getattr(self, "_share_warned", False):
+            # --share_identity only works through the batched forward+backward launch
+            self._share_warned = True
+            logging.warning("--share_identity is on but inactive: it needs --fused_units and --batch_units, at most "
+                            "two sources per unit and a wanted gradient; the multi-frame units re-evaluate the "
+                            "identity candidates")
         id_0, id_pt, id_nt = idents if idents is not None else (None, None, None)
 
         # ---- multi-frame depths

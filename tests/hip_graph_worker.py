@@ -15,8 +15,12 @@ import torch  # noqa: E402
 def main():
     backbone, B, H, W, log_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     scope = sys.argv[6] if len(sys.argv) > 6 else "step"
+    import mono_vifi_amd
     from mono_vifi_amd import synthetic
     from mono_vifi_amd.options import default_options
+    # an entry point that will ask for --hip_graph: packet capture off BEFORE this process's first HIP call
+    # (importing the package no longer sets it; the batches below already touch the GPU)
+    mono_vifi_amd.ensure_graph_replay_env()
     from mono_vifi_amd.trainer import Trainer, _StepGraph
     dev = torch.device("cuda", 0)
     steps = 7

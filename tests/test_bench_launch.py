@@ -41,6 +41,19 @@ def test_gpus_2_spawns_two_ranks_and_reports_the_group():
     assert "launching" in r.stderr          # it re-executed itself under torch.distributed.run
 
 
+def test_gpus_8_spawns_eight_ranks():
+    """The driver's largest form: `--gpus 8` starts eight processes, the process group reports eight ranks and
+    eight distinct PIDs (gloo, mock step: the launcher and the report are under test, never a number)."""
+    r = _run(["--gpus", "8", "--workload", "mock", "--steps", "3", "--warmup", "1", "--batch", "2"],
+             {"MVF_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = _line(r.stdout)
+    assert d["n_gpus"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 16
+    c = d["comm"]
+    assert c["world_size"] == 8 and c["distinct_processes"] == 8 and len(set(c["pids"])) == 8
+    assert c["collectives_per_step"] == {"grad_all_reduce": float(c["grad_buckets"])}
+
+
 def test_reduce_scatter_exchange_is_reported():
     r = _run(["--gpus", "2", "--workload", "mock", "--steps", "3", "--warmup", "1", "--grad-exchange",
               "reduce_scatter", "--no-overlap"], {"MVF_DIST_BACKEND": "gloo"})

@@ -227,3 +227,31 @@ def test_trainer_losses_batched_equal_unbatched(dev):
     assert res[True][0] == res[False][0]
     for (a, b), (c, d) in zip(res[True][1], res[False][1]):
         assert np.array_equal(a, c) and np.array_equal(b, d)
+
+
+@pytest.mark.parametrize("which", ["tgt", "src", "mask", "noise", "K"])
+def test_mismatched_planes_raise_instead_of_reading_out_of_bounds(dev, which):
+    """Raw pointers and strides go to the kernel, so every plane is shape-checked on the host: a
+    target / source / mask / noise / intrinsics tensor of another resolution or batch size is a RuntimeError,
+    not an out-of-bounds device read."""
+    from mono_vifi_amd import ops
+    B, H, W = 2, 32, 64
+    inp = _inputs(77, B, H, W, 0, True)
+    _, _, flat = _flat(inp, dev, 0)
+    small = _inputs(78, B, H // 2, W, 0, True)
+    if which == "tgt":
+        flat[1] = T(small["tgt"], dev)
+    elif which == "src":
+        flat[9] = T(small["src"][1], dev)
+    elif which == "mask":
+        flat[5] = T(small["mask_rec"], dev)
+    elif which == "noise":
+        flat[6] = T(inp["noise_used"][:, :1], dev)          # one candidate's noise for two sources
+    else:
+        flat[3] = T(inp["K"][:1], dev)                      # another batch size
+    with pytest.raises(RuntimeError, match="must be"):
+        ops.Units.apply(_cfg(1, 0), *flat)
+    # the launch path is intact afterwards (a failed launch drops the cached ticket buffer)
+    _, _, good = _flat(inp, dev, 0)
+    res = ops.Units.apply(_cfg(1, 0), *good)
+    assert torch.isfinite(res[0]).all()
