@@ -138,6 +138,15 @@ def parse():
                     help="N = 1 headline run: skip the live PMC passes (rocprofv3 --pmc around short hot-path runs of "
                          "this script as child processes: HBM traffic and VALU instruction counts of the unit "
                          "kernel per launch); roofline.traffic / valu then quote the committed profiles/ summary")
+    ap.add_argument("--no-mfma-leg", dest="mfma_leg", action="store_false", default=True,
+                    help="N = 1 headline run: skip the live MFMA / VALU utilisation pass over the training step's kernels "
+                         "(rocprofv3 --pmc around a child run of four steps; `conv_mfma` in the line)")
+    ap.add_argument("--no-kernel-leg", dest="kernel_leg", action="store_false", default=True,
+                    help="skip the roofline leg of this build's own glue kernels (`own_kernels` in the line: event "
+                         "pairs around every launch for three extra steps)")
+    ap.add_argument("--no-host-leg", dest="host_leg", action="store_false", default=True,
+                    help="N = 1 headline run: skip the host-cost measurement (the step in child processes pinned to the CPUs "
+                         "one of eight ranks would have on this box, eager and as a HIP graph; `host.pinned` in the line)")
     ap.add_argument("--also-steps", dest="also_steps", type=int, default=10)
     ap.add_argument("--also-warmup", dest="also_warmup", type=int, default=5)
     return ap.parse_args()
@@ -573,6 +582,165 @@ def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n, fb_pixels=
     return {"unit_fwd": r_fwd, "unit_bwd": r_bwd, "unit_fwdbwd": r_fb}, dominant
 
 
+def unit_launch_types(args, nat, fb_bytes_px_base, noise_tensor):
+    """The three kinds of unit launch of a step are different work (single-frame: identity SSIM + hand-over write;
+    multi-frame: hand-over read instead; affine: + mask plane): per kind the MEDIAN duration of the recorded launches
+    (median of >= 50 runs), its algorithmic bytes and fraction of HBM peak, and the overall median."""
+    recs = nat.profile_read_launches(nat.PROF_UNIT_FWDBWD)
+    if not recs:
+        return None
+    import statistics
+    out = {}
+    for tag, name in nat.TAG_NAMES.items():
+        sel = [(ms, px) for ms, px, t in recs if t == tag]
+        if not sel:
+            continue
+        med_ms = statistics.median(ms for ms, _ in sel)
+        px = statistics.median(p for _, p in sel)
+        bpp = FB_BYTES_PER_PX + (NOISE_BYTES_PER_PX if noise_tensor else 0) + (MASK_BYTES_PER_PX if tag == 2 else 0)
+        ach = bpp * px / (med_ms / 1e3) / 1e9
+        out[name] = {"launches": len(sel), "median_us": round(med_ms * 1e3, 2),
+                     "min_us": round(min(ms for ms, _ in sel) * 1e3, 2), "max_us": round(max(ms for ms, _ in sel) * 1e3, 2),
+                     "bytes": int(round(bpp * px)), "bytes_per_px": bpp,
+                     "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
+    return {"by_launch": out, "median_us": round(statistics.median(ms for ms, _, _ in recs) * 1e3, 2),
+            "launches_recorded": len(recs)}
+
+
+def glue_kernel_leg(step, nat, steps=3):
+    """Roofline of this build's OWN kernels either side of the unit kernel: a few extra steps
+    with the library's event hooks at level 2 (an event pair around every launch of the kernels listed in
+    include/mvf_hotpath.h: MVF_PROF_*), outside the timed region.  Per kernel: launches and ms per step,
+    algorithmic bytes per step (every input element read once, every output element written once -- stated per
+    launcher in csrc/), achieved GB/s over the kernel's own time, fraction of the 8 TB/s HBM peak."""
+    try:
+        nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
+        nat.check(nat.lib().mvf_profile_enable(2), "profile_enable")
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        nat.lib().mvf_profile_enable(0)
+        out = {}
+        for kid in range(nat.PROF_FIRST_GLUE, nat.PROF_COUNT):
+            ms, n = nat.profile_read(kid)
+            if n == 0:
+                continue
+            nbytes = nat.profile_read_work(kid)
+            ach = nbytes / (ms / 1e3) / 1e9 if ms > 0 else 0.0
+            out[nat.profile_name(kid)] = {
+                "launches_per_step": round(n / steps, 1), "ms_per_step": round(ms / steps, 4),
+                "avg_us": round(ms / n * 1e3, 2), "bytes_per_step": int(nbytes // steps),
+                "bytes_per_launch": int(nbytes // n), "bound": "hbm", "achieved": round(ach, 1), "unit": "GB/s",
+                "peak": HBM_PEAK_GBS, "frac": round(ach / HBM_PEAK_GBS, 4)}
+        nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
+        tot = sum(v["ms_per_step"] for v in out.values())
+        return {"kernels": dict(sorted(out.items(), key=lambda kv: -kv[1]["ms_per_step"])),
+                "own_glue_ms_per_step": round(tot, 3), "steps": steps,
+                "note": "HIP events around every launch of the listed kernels (profile level 2) over extra steps after "
+                        "the timed region; bytes = algorithmic (inputs read once + outputs written once)"}
+    except Exception as e:      # noqa: BLE001 -- an optional leg must never take the bench line down
+        nat.lib().mvf_profile_enable(0)
+        return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+CONV_FAMILIES = (
+    ("winograd", ("miopenSp3AsmConv", "Winograd", "winograd")),
+    ("igemm_fwd", ("igemm_fwd",)),
+    ("igemm_bwd", ("igemm_bwd",)),
+    ("igemm_wrw", ("igemm_wrw",)),
+    ("ck_conv", ("kernel_grouped_conv", "ck::")),
+    ("gemm", ("Cijk_", "rocblas_", "gemv")),
+    ("conv_transposes", ("batched_transpose", "transpose_NCHW", "transpose_CNHW", "SubTensorOp")),
+    ("batch_norm", ("MIOpenBatchNorm", "batch_norm")),
+    ("own_kernels", ("(anonymous namespace)::k_", "k_unit_fb", "k_bias_act", "k_up2cat", "k_reflect", "k_maxpool")),
+)
+
+
+def mfma_leg(args, timeout_s=240):
+    """north_star's "MFMA utilisation against the chip's peak" for the conv GEMMs, measured NOW:
+    one counter-only `rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE --kernel-trace`
+    pass around a child run of two training steps of this script; per kernel family the share of the step's GPU
+    cycles, ms per step (kernel-trace durations), MFMA-pipe busy and VALU busy fractions, and the cycle-weighted
+    figures over the whole step.  Measurement only: the convolution kernels are MIOpen's (out of scope).
+    MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (kernel cycles x 1,024 SIMDs); kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs;
+    VALU busy = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) / the same."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TMPDIR"] = "/tmp"
+    t0 = time.perf_counter()
+    warm, timed = 2, 2
+    d = tempfile.mkdtemp(prefix="mvf_mfma_", dir="/tmp")
+    cmd = ["rocprofv3", "--pmc", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE",
+           "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+           "--workload", "train", "--steps", str(timed), "--warmup", str(warm), "--no-cpu-baseline", "--no-hotpath-leg",
+           "--also-configs", "none", "--no-graph-leg", "--no-pmc-leg", "--no-mfma-leg", "--no-kernel-leg", "--no-host-leg",
+           "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--backbone", args.backbone]
+    try:
+        r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        if r.returncode != 0:
+            return {"error": "rocprofv3 child rc %d: %s" % (r.returncode, (r.stderr.strip().splitlines() or [""])[-1][:200])}
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    acc[row["Kernel_Name"]][row["Counter_Name"]] += float(row["Counter_Value"])
+        dur = collections.defaultdict(float)
+        for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+            with open(f) as fh:
+                for row in csv.DictReader(fh):
+                    dur[row["Kernel_Name"]] += (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) * 1e-6
+    except subprocess.TimeoutExpired:
+        return {"error": f"rocprofv3 child did not finish within {timeout_s} s"}
+    except (OSError, ValueError, KeyError) as e:
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    steps_all = float(warm + timed)     # the counters cover every step the child ran (warm-up included)
+
+    def family(name):
+        for fam, pats in CONV_FAMILIES:
+            if any(p_ in name for p_ in pats):
+                return fam
+        return "other"
+    fam = collections.defaultdict(lambda: [0.0, 0.0, 0.0, 0.0])      # cycles, mfma, valu, ms
+    for k, c in acc.items():
+        cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if cyc <= 0:
+            continue
+        a = fam[family(k)]
+        a[0] += cyc
+        a[1] += c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        a[2] += 4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0)
+        a[3] += dur.get(k, 0.0)
+    tot = [sum(v[i] for v in fam.values()) for i in range(4)]
+    if tot[0] <= 0:
+        return {"error": "no counters collected"}
+    per = {k: {"share_of_gpu_cycles": round(v[0] / tot[0], 4), "ms_per_step": round(v[3] / steps_all, 3),
+               "mfma_busy": round(v[1] / (v[0] * 1024.0), 4), "valu_busy": round(v[2] / (v[0] * 1024.0), 4)}
+           for k, v in sorted(fam.items(), key=lambda kv: -kv[1][0])}
+    conv = [v for k, v in fam.items() if k in ("winograd", "igemm_fwd", "igemm_bwd", "igemm_wrw", "ck_conv", "gemm")]
+    cc = [sum(v[i] for v in conv) for i in range(4)]
+    return {"cycle_weighted_mfma_busy": round(tot[1] / (tot[0] * 1024.0), 4),
+            "cycle_weighted_valu_busy": round(tot[2] / (tot[0] * 1024.0), 4),
+            "conv_and_gemm_kernels": {"share_of_gpu_cycles": round(cc[0] / tot[0], 4), "ms_per_step": round(cc[3] / steps_all, 3),
+                                      "mfma_busy": round(cc[1] / (cc[0] * 1024.0), 4) if cc[0] else None,
+                                      "valu_busy": round(cc[2] / (cc[0] * 1024.0), 4) if cc[0] else None},
+            "families": per, "kernel_ms_per_step_under_pmc": round(tot[3] / steps_all, 2),
+            "peak_note": "MFMA busy 1.0 = the fp32-input MFMA peak of 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32 / 16x16x4_f32: the "
+                         "reference's arithmetic is fp32; /opt/skills/guides/MI355X_MICROARCH.md); the Winograd kernels are "
+                         "VALU code and issue no MFMA",
+            "source": {"measured": "in this run", "how": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES "
+                       "GRBM_GUI_ACTIVE --kernel-trace (counters only) around a child run of %d training steps" % int(steps_all),
+                       "leg_seconds": round(time.perf_counter() - t0, 1)}}
+
+
 def graph_replay_leg(step, steps=50):
     """The same hot-path step captured ONCE into a HIP graph (forward and backward of the 9 units:
     ~40 launches) and replayed: what the launch-bound loop costs without the Python / autograd
@@ -641,8 +809,8 @@ def graph_step_leg(args, steps=20, timeout_s=150):
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "train", "--hip-graph",
            "--hip-graph-scope", args.hip_graph_scope, "--steps", str(steps), "--warmup", "6", "--no-cpu-baseline",
-           "--no-hotpath-leg", "--also-configs", "none", "--no-graph-leg", "--batch", str(args.batch), "--height",
-           str(args.height), "--width", str(args.width), "--backbone", args.backbone]
+           "--no-hotpath-leg", "--also-configs", "none", "--no-graph-leg", "--no-host-leg", "--no-mfma-leg", "--batch",
+           str(args.batch), "--height", str(args.height), "--width", str(args.width), "--backbone", args.backbone]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     t0 = time.perf_counter()
     try:
@@ -663,6 +831,46 @@ def graph_step_leg(args, steps=20, timeout_s=150):
         return {"error": f"child did not finish within {timeout_s} s (killed)"}
     except Exception as e:      # noqa: BLE001 -- an optional leg must never take the bench line down
         return {"error": f"{type(e).__name__}: {e}"[:300]}
+
+
+def host_leg(args, steps=10, timeout_s=150):
+    """What the host costs when eight ranks share this box: the SAME training step in child
+    processes pinned (sched_setaffinity) to the CPUs ONE rank would have with eight ranks on the CPUs this container
+    is granted -- eager, and with the step replayed as a HIP graph.  A step that slows down under the pin is
+    host-bound on the 8-GPU node; the graph step is the mitigation."""
+    import subprocess
+    quota, _ = cpu_quota()
+    ncpu = max(1, quota // 8)
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        return None
+    cpus = allowed[:ncpu]
+    out = {"cpus_per_rank": ncpu, "pinned_to": cpus, "steps": steps}
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["OMP_NUM_THREADS"] = str(ncpu)
+    base = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--workload", "train", "--steps", str(steps), "--warmup", "6",
+            "--no-cpu-baseline", "--no-hotpath-leg", "--also-configs", "none", "--no-graph-leg", "--no-pmc-leg", "--no-mfma-leg",
+            "--no-kernel-leg", "--no-host-leg", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
+            "--backbone", args.backbone]
+    for name, extra in (("eager", []), ("hip_graph", ["--hip-graph", "--hip-graph-scope", args.hip_graph_scope])):
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=timeout_s,
+                               preexec_fn=lambda: os.sched_setaffinity(0, cpus))
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not lines:
+                out[name] = {"error": f"child rc {r.returncode}: " + (r.stderr.strip().splitlines() or [""])[-1][:200]}
+                continue
+            d = json.loads(lines[-1])
+            out[name] = {"value": d["value"], "ms_per_step": d["ms_per_step"],
+                         "process_cpu_ms_per_step": (d.get("host") or {}).get("process_cpu_ms_per_step"),
+                         "leg_seconds": round(time.perf_counter() - t0, 1)}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": f"child did not finish within {timeout_s} s (killed)"}
+        except Exception as e:      # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return out
 
 
 def pmc_leg(args, timeout_s=120):
@@ -690,7 +898,7 @@ def pmc_leg(args, timeout_s=120):
         d = tempfile.mkdtemp(prefix="mvf_pmc_", dir="/tmp")
         cmd = ["rocprofv3", "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                os.path.abspath(__file__), "--workload", "hotpath", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-               "--no-replay-leg", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--noise", args.noise]
+               "--no-replay-leg", "--no-kernel-leg", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width), "--noise", args.noise]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             if r.returncode != 0:
@@ -735,13 +943,20 @@ OTHER_CONFIGS = {
 }
 
 
+HOST_CPU = {}      # CPU time of the last timed region (this rank): process (all threads) and enqueueing thread
+
+
 def timed_steps(step, steps, world):
     barrier_sync(world)
     t0 = time.perf_counter()
+    c0, th0 = time.process_time(), time.thread_time()
     for _ in range(steps):
         step()
+    c1, th1 = time.process_time(), time.thread_time()      # before the closing synchronisation: enqueue cost only
     barrier_sync(world)
     elapsed = time.perf_counter() - t0
+    HOST_CPU.update(process_cpu_ms_per_step=round((c1 - c0) / steps * 1e3, 3),
+                    main_thread_cpu_ms_per_step=round((th1 - th0) / steps * 1e3, 3))
     if world > 1:
         dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else "cpu"
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -773,6 +988,8 @@ def other_config_leg(args, name, rank, world, dev, nat):
                                   static=False, launches_hint=step)
         out = {"workload": step.describe(), "value": round(a.batch * world * args.also_steps / elapsed, 2),
                "unit": "images/sec", "ms_per_step": round(elapsed / args.also_steps * 1e3, 3),
+               "host_process_cpu_ms_per_step": HOST_CPU.get("process_cpu_ms_per_step"),
+               "host_main_thread_cpu_ms_per_step": HOST_CPU.get("main_thread_cpu_ms_per_step"),
                "steps": args.also_steps, "warmup": args.also_warmup,
                "unit_launch_avg_us": dom and dom["avg_us"], "us_per_unit": dom and dom["us_per_unit"],
                "frac": dom and dom["frac"], "unit_launches": dom and dom["launches"],
@@ -834,6 +1051,7 @@ def main():
     if red0 is not None and (world > 1 or args.force_collectives):
         red0.timeline = True          # two event records per bucket and step
     elapsed = timed_steps(step, args.steps, world)
+    host_cpu = dict(HOST_CPU)
     counts = {k: round(v / args.steps, 2) for k, v in sorted(parallel.comm_counts().items())}
     if nat:
         nat.lib().mvf_profile_enable(0)
@@ -845,6 +1063,19 @@ def main():
         fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
         kernels, dominant = kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n,
                                              nat.profile_read_work(nat.PROF_UNIT_FWDBWD), launches_hint=step)
+        if dominant and dominant.get("kernel") == "k_unit_fb<2>":
+            st_ = getattr(step, "trainer", step)
+            noise_tensor = not getattr(getattr(st_, "opt", None), "inkernel_noise", args.noise == "kernel") \
+                if hasattr(st_, "opt") else args.noise != "kernel"
+            types = unit_launch_types(args, nat, FB_BYTES_PER_PX, noise_tensor)
+            if types:
+                dominant.update(types)
+
+    # ---- this build's own kernels either side of the unit kernel: event pairs around every launch for a few
+    # extra steps (outside the timed region; one process only: the extra steps would need every rank)
+    own_kernels = None
+    if nat and args.kernel_leg and world == 1 and workload in ("train", "hotpath") and not args.hip_graph:
+        own_kernels = glue_kernel_leg(step, nat)
 
     # ---- communication report (every rank takes part in its collectives)
     comm = comm_report(args, world, rank, dev, backend, step, counts)
@@ -919,6 +1150,14 @@ def main():
         graph_leg = graph_step_leg(args) if not over_budget(args, 60) else {"skipped": "time budget"}
 
     # ---- live PMC passes of the unit kernel (child processes under rocprofv3; N = 1 headline run only)
+    host_pinned = None
+    if default_headline and rank == 0 and args.host_leg:
+        host_pinned = host_leg(args) if not over_budget(args, 60) else {"skipped": "time budget"}
+
+    conv_mfma = None
+    if default_headline and rank == 0 and args.mfma_leg:
+        conv_mfma = mfma_leg(args) if not over_budget(args, 150) else {"skipped": "time budget"}
+
     if default_headline and rank == 0 and args.pmc_leg and dominant and dominant.get("kernel") == "k_unit_fb<2>":
         live = pmc_leg(args) if not over_budget(args, 120) else None
         if live:
@@ -951,6 +1190,27 @@ def main():
             "roofline": dominant,
             "kernels": kernels,
         }
+        if workload != "mock":
+            quota, host_threads = cpu_quota()
+            # what a step costs the HOST: CPU time of this process per eager step (the Python
+            # thread that enqueues the forward + the autograd thread that enqueues the backward), next to the step time
+            # and to the CPUs a rank would have with eight ranks on this box
+            out["host"] = dict(host_cpu, cpus_granted=quota, hardware_threads=host_threads,
+                               host_cpu_over_step=round(host_cpu.get("process_cpu_ms_per_step", 0.0) /
+                                                        (elapsed / args.steps * 1e3), 3),
+                               cpus_per_rank_with_8_ranks=round(quota / 8.0, 2),
+                               note="process_cpu = CPU time of all threads of this rank per timed step (enqueue only, before "
+                                    "the closing synchronisation); a step is host-bound on a node where this exceeds "
+                                    "ms_per_step x the CPUs a rank gets")
+        if host_pinned and "host" in out:
+            out["host"]["pinned"] = host_pinned
+            e_, g_ = host_pinned.get("eager", {}), host_pinned.get("hip_graph", {})
+            if e_.get("ms_per_step") and g_.get("ms_per_step"):
+                out["host"]["host_bound_with_8_ranks"] = bool(e_["ms_per_step"] > 1.05 * out["ms_per_step"])
+        if own_kernels:
+            out["own_kernels"] = own_kernels
+        if conv_mfma:
+            out["conv_mfma"] = conv_mfma
         if comm:
             out["comm"] = comm
         if hotpath_only:

@@ -420,10 +420,14 @@ MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32
                      int frames, int H, int W, void *stream);
 
 /* ---- measurement hooks (bench.py) ------------------------------------------------------
- * When enabled, the library brackets each launch of its dominant kernels with a pair of HIP
- * events recorded on the launch stream.  mvf_profile_read() synchronises the recorded
- * events and returns the summed kernel time and launch count for one kernel id since the
- * last reset.  Off by default; the only process-global state in the library. */
+ * When enabled, the library brackets launches of its kernels with a pair of HIP events recorded on the
+ * launch stream.  mvf_profile_read() synchronises the recorded events and returns the summed kernel time
+ * and launch count for one kernel id since the last reset.  Off by default; the only process-global state
+ * in the library.  Levels: 1 = the hot-path tile kernels (ids 0..6: what the timed region of bench.py runs
+ * with -- six event records per step), 2 = every kernel id below (the glue kernels either side of the path
+ * too: some hundred event pairs per step, used by bench.py's separate kernel-roofline leg).
+ * `work`: ids 0..6 count PIXELS (images x H x W summed over the units of each launch); ids >= 7 count the
+ * ALGORITHMIC BYTES of each launch (every input element read once + every output element written once). */
 #define MVF_PROF_UNIT_FWD 0  /* fused unit forward tile kernel  */
 #define MVF_PROF_UNIT_BWD 1  /* fused unit backward tile kernel */
 #define MVF_PROF_PHOTO_FWD 2 /* staged compute_losses_base forward */
@@ -431,12 +435,46 @@ MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32
 #define MVF_PROF_WARP_FWD 4  /* staged generate_images_pred */
 #define MVF_PROF_WARP_BWD 5
 #define MVF_PROF_UNIT_FWDBWD 6 /* forward+backward of a unit in one tile kernel */
-#define MVF_PROF_COUNT 7
-MVF_API int mvf_profile_enable(int on);
+#define MVF_PROF_UNITS_FINISH 7      /* k_units_finish */
+#define MVF_PROF_FB_SCALE 8          /* k_fb_scale */
+#define MVF_PROF_DISP_MEAN 9         /* k_disp_mean (only when the disparity head did not supply the partials) */
+#define MVF_PROF_BIAS_ACT_FWD 10     /* k_bias_act_fwd */
+#define MVF_PROF_BIAS_ACT_BWD 11     /* k_bias_act_bwd + k_bias_grad_finish */
+#define MVF_PROF_ACT_BWD_FLAT 12     /* k_act_bwd_flat */
+#define MVF_PROF_UP2CAT_FWD 13       /* k_up2cat_pad_fwd */
+#define MVF_PROF_UP2CAT_BWD_X 14     /* k_up2cat_pad_bwd_x */
+#define MVF_PROF_UP2CAT_BWD_SKIP 15  /* k_up2cat_pad_bwd_skip */
+#define MVF_PROF_REFLECT_PAD_FWD 16  /* k_reflect_pad1_fwd */
+#define MVF_PROF_REFLECT_PAD_BWD 17  /* k_reflect_pad1_bwd */
+#define MVF_PROF_MAXPOOL_FWD 18      /* k_maxpool3s2_fwd */
+#define MVF_PROF_MAXPOOL_BWD 19      /* k_maxpool3s2_bwd */
+#define MVF_PROF_FUSION_FWD 20       /* k_fusion_level_fwd */
+#define MVF_PROF_FUSION_BWD_GATHER 21 /* inverse tap lists + k_fusion_level_bwd_gather */
+#define MVF_PROF_FLOW_WARP_FWD 22    /* k_flow_warp_fwd */
+#define MVF_PROF_DISP_HEAD_FWD 23    /* k_disp_head_fwd */
+#define MVF_PROF_DISP_HEAD_BWD 24    /* k_disp_head_bwd */
+#define MVF_PROF_RESIZE_FWD 25       /* k_resize_bilinear_fwd */
+#define MVF_PROF_RESIZE_BWD 26       /* k_resize_bilinear_bwd */
+#define MVF_PROF_NEAREST_FWD 27      /* k_upsample_nearest_fwd */
+#define MVF_PROF_NEAREST_BWD 28      /* k_upsample_nearest_bwd */
+#define MVF_PROF_SILOG_FWD 29        /* k_silog_partial + k_silog_finish */
+#define MVF_PROF_SILOG_BWD 30        /* k_silog_bwd */
+#define MVF_PROF_AFFINE 31           /* affine transform / restore kernels */
+#define MVF_PROF_COUNT 32
+/* launch tags of MVF_PROF_UNIT_FWDBWD (mvf_profile_read_launches): what kind of unit group a launch carried */
+#define MVF_TAG_SINGLE_FRAME 0  /* identity candidates evaluated (and possibly handed over: ident_out) */
+#define MVF_TAG_MULTI_FRAME 1   /* identity maps taken from another unit (ident_in) */
+#define MVF_TAG_AFFINE 2        /* mask_rec supplied */
+MVF_API int mvf_profile_enable(int level);
 MVF_API int mvf_profile_reset(void);
 MVF_API int mvf_profile_read(int kernel_id, double *total_ms, int64_t *launches);
-/* pixels (images x H x W, summed over the units of each launch) the recorded launches processed */
-MVF_API int mvf_profile_read_work(int kernel_id, int64_t *pixels);
+/* work the recorded launches processed: pixels for ids 0..6, algorithmic bytes for ids >= 7 */
+MVF_API int mvf_profile_read_work(int kernel_id, int64_t *work);
+/* per-launch records of one kernel id since the last reset, oldest first: duration (ms), work, tag.  Returns
+ * the number of records copied (<= cap), or a negative HIP error.  (Medians per launch type: SURVEY 8d.) */
+MVF_API int64_t mvf_profile_read_launches(int kernel_id, double *ms, int64_t *work, int32_t *tag, int64_t cap);
+/* kernel name of a profile id (static string) */
+MVF_API const char *mvf_profile_name(int kernel_id);
 
 /* floats of scratch the reducing entry points need for a [B,*,H,W] problem */
 MVF_API size_t mvf_workspace_floats(int B, int H, int W);

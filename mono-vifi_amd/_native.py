@@ -126,10 +126,14 @@ _SIGNATURES = {
     "mvf_profile_reset": [],
     "mvf_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64)],
     "mvf_profile_read_work": [_i, C.POINTER(C.c_int64)],
+    "mvf_profile_read_launches": [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.c_int64],
+    "mvf_profile_name": [_i],
 }
 (PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD,
  PROF_UNIT_FWDBWD) = range(7)
-_RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_workspace_floats": C.c_size_t,
+PROF_FIRST_GLUE, PROF_COUNT = 7, 32         # ids >= 7: glue kernels, profile level 2, work = algorithmic bytes
+TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine"}
+_RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_profile_name": C.c_char_p, "mvf_profile_read_launches": C.c_int64, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,
             "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t,
             "mvf_units_workspace_floats": C.c_size_t, "mvf_units_ticket_ints": C.c_size_t}
@@ -225,3 +229,18 @@ def profile_read_work(kernel_id):
     px = C.c_int64(0)
     check(lib().mvf_profile_read_work(kernel_id, C.byref(px)), "profile_read_work")
     return px.value
+
+
+def profile_read_launches(kernel_id, cap=65536):
+    """Per-launch records of one kernel id since the last reset: list of (ms, work, tag)."""
+    ms = (C.c_double * cap)()
+    work = (C.c_int64 * cap)()
+    tag = (C.c_int32 * cap)()
+    n = lib().mvf_profile_read_launches(kernel_id, ms, work, tag, cap)
+    if n < 0:
+        check(int(-n), "profile_read_launches")
+    return [(ms[i], work[i], tag[i]) for i in range(n)]
+
+
+def profile_name(kernel_id):
+    return lib().mvf_profile_name(kernel_id).decode()

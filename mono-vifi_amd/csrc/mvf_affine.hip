@@ -305,6 +305,7 @@ int mvf_affine_transform_fwd(const float *img, const float *angle_deg, const int
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
     if (!img || !angle_deg || !box || !out || B > 65535) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_AFFINE, stream, 8LL * B * C * H * W);
     hipLaunchKernelGGL(k_affine_transform, tile_grid(B, H, W), dim3(NT), 0, (hipStream_t)stream, img,
                        angle_deg, box, out, C, H, W);
     return hip_check_launch();
@@ -315,6 +316,7 @@ int mvf_affine_restore_fwd(const float *depth, const float *angle_deg, const int
 {
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
     if (!depth || !angle_deg || !box || !ratio || !out || B > 65535) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_AFFINE, stream, 8LL * B * C * H * W);
     hipLaunchKernelGGL(k_affine_restore_fwd, tile_grid(B, H, W), dim3(NT), 0, (hipStream_t)stream, depth,
                        angle_deg, box, ratio, out, C, H, W);
     return hip_check_launch();
@@ -327,6 +329,7 @@ int mvf_affine_restore_bwd(const float *g_out, const float *angle_deg, const int
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
     if (!g_out || !angle_deg || !box || !ratio || !workspace || !g_depth || B > 65535)
         return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_AFFINE, stream, 8LL * B * C * H * W);
     hipLaunchKernelGGL(k_affine_restore_bwd_rot, tile_grid(B, H, W), dim3(NT), 0, (hipStream_t)stream,
                        g_out, angle_deg, box, ratio, workspace, C, H, W);
     hipLaunchKernelGGL(k_affine_restore_bwd_resize, tile_grid(B, H, W), dim3(NT), 0, (hipStream_t)stream,

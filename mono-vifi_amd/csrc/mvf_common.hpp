@@ -641,16 +641,18 @@ inline int hip_check_launch()
     return (int)hipGetLastError();
 }
 
-// measurement hooks (implemented in mvf_geom.hip): event pair around one kernel launch
-// `work` = pixels the launch processes (summed per kernel id: a launch may carry several units)
+// measurement hooks (implemented in mvf_geom.hip): event pair around one kernel launch (or one launcher's
+// group of launches).  `work`: pixels for the hot-path ids (< MVF_PROF_UNITS_FINISH), algorithmic bytes for
+// the others; `tag`: launch kind (MVF_TAG_*)
 void prof_begin(int kernel_id, hipStream_t st);
-void prof_end(int kernel_id, hipStream_t st, int64_t work);
+void prof_end(int kernel_id, hipStream_t st, int64_t work, int tag);
 struct ProfScope {
-    int id;
+    int id, tag;
     hipStream_t st;
     int64_t work;
-    ProfScope(int kernel_id, hipStream_t s, int64_t w = 0) : id(kernel_id), st(s), work(w) { prof_begin(id, st); }
-    ~ProfScope() { prof_end(id, st, work); }
+    ProfScope(int kernel_id, hipStream_t s, int64_t w = 0, int t = 0) : id(kernel_id), tag(t), st(s), work(w) { prof_begin(id, st); }
+    ProfScope(int kernel_id, void *s, int64_t w = 0, int t = 0) : ProfScope(kernel_id, (hipStream_t)s, w, t) {}
+    ~ProfScope() { prof_end(id, st, work, tag); }
 };
 
 }  // namespace mvf

@@ -442,6 +442,8 @@ int mvf_fusion_level_fwd(const float *feat_0, const float *feat_n1, const float 
     if (!feat_0 || !feat_n1 || !feat_p1 || !prep || !xs || !ys || !out || h < 2 || w < 2)
         return (int)hipErrorInvalidValue;
     const int nchunk = (C + CCH - 1) / CCH;
+    // three feature maps and the prep planes read once; feat_0 | emb(0) | merged (C + EMB each) written once
+    ProfScope ps(MVF_PROF_FUSION_FWD, stream, 4LL * B * h * w * (3LL * C + PREP + 2LL * (C + EMB)));
     hipLaunchKernelGGL(k_fusion_level_fwd, dim3((unsigned)((h * w + NT - 1) / NT), (unsigned)(nchunk + 1), (unsigned)B),
                        dim3(NT), 0, (hipStream_t)stream, feat_0, feat_n1, feat_p1, prep, xs, ys, out, C, h, w);
     return hip_check_launch();
@@ -474,6 +476,9 @@ int mvf_fusion_level_bwd_gather(const float *g_out, const float *prep, const flo
     if (!g_feat_n1 && !g_feat_p1) return 0;
     hipStream_t st = (hipStream_t)stream;
     const int n = h * w;
+    // the merged half of g_out read once, two feature gradients written once (the inverse tap lists are this
+    // build's own traffic, not priced)
+    ProfScope ps(MVF_PROF_FUSION_BWD_GATHER, stream, 4LL * B * n * C * (1 + (g_feat_n1 ? 1 : 0) + (g_feat_p1 ? 1 : 0)));
     const int err = build_inverse_lists<false>(prep, xs, ys, workspace, B, h, w, st);
     if (err) return err;
     const int nchunk = (C + CCH - 1) / CCH;

@@ -713,43 +713,60 @@ __global__ void k_pose_bwd(const float *__restrict__ aa, const float *__restrict
 }  // namespace
 
 // ---------------------------------------------------------------- measurement hooks
+#include <algorithm>
 #include <mutex>
 #include <vector>
 namespace mvf {
 namespace {
+struct ProfRec {
+    hipEvent_t e0, e1;
+    int64_t work;
+    int tag;
+};
+struct ProfDone {
+    double ms;
+    int64_t work;
+    int tag;
+};
 struct ProfState {
     std::mutex mu;
-    bool on = false;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[MVF_PROF_COUNT];
+    int level = 0;
+    std::vector<ProfRec> ev[MVF_PROF_COUNT];
+    std::vector<ProfDone> done[MVF_PROF_COUNT];
     hipEvent_t open_start[MVF_PROF_COUNT] = {};
     double acc_ms[MVF_PROF_COUNT] = {};
     int64_t acc_n[MVF_PROF_COUNT] = {};
-    int64_t acc_work[MVF_PROF_COUNT] = {};     // pixels processed (a launch may carry several units)
+    int64_t acc_work[MVF_PROF_COUNT] = {};
 };
 ProfState &prof() { static ProfState p; return p; }
-constexpr size_t kMaxPairs = 1 << 16;
+constexpr size_t kMaxPairs = 1 << 14, kMaxDone = 1 << 16;
 
 void drain(ProfState &p, int id)
 {
-    for (auto &pr : p.ev[id]) {
+    for (auto &r : p.ev[id]) {
         float ms = 0.0f;
-        if (hipEventSynchronize(pr.second) == hipSuccess &&
-            hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+        if (hipEventSynchronize(r.e1) == hipSuccess && hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
             p.acc_ms[id] += ms;
             p.acc_n[id] += 1;
+            if (p.done[id].size() < kMaxDone) p.done[id].push_back({(double)ms, r.work, r.tag});
         }
-        (void)hipEventDestroy(pr.first);
-        (void)hipEventDestroy(pr.second);
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
     }
     p.ev[id].clear();
+}
+inline bool prof_active(const ProfState &p, int id)
+{
+    return p.level >= 2 || (p.level == 1 && id < MVF_PROF_UNITS_FINISH);
 }
 }  // namespace
 
 void prof_begin(int id, hipStream_t st)
 {
     ProfState &p = prof();
-    if (!p.on) return;
+    if (!p.level) return;
     std::lock_guard<std::mutex> g(p.mu);
+    if (!prof_active(p, id)) return;
     if (p.ev[id].size() >= kMaxPairs) drain(p, id);
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
@@ -757,17 +774,17 @@ void prof_begin(int id, hipStream_t st)
     p.open_start[id] = e;
 }
 
-void prof_end(int id, hipStream_t st, int64_t work)
+void prof_end(int id, hipStream_t st, int64_t work, int tag)
 {
     ProfState &p = prof();
-    if (!p.on) return;
+    if (!p.level) return;
     std::lock_guard<std::mutex> g(p.mu);
     if (!p.open_start[id]) return;
     p.acc_work[id] += work;
     hipEvent_t e;
     if (hipEventCreate(&e) != hipSuccess) return;
     (void)hipEventRecord(e, st);
-    p.ev[id].emplace_back(p.open_start[id], e);
+    p.ev[id].push_back({p.open_start[id], e, work, tag});
     p.open_start[id] = nullptr;
 }
 }  // namespace mvf
@@ -781,16 +798,21 @@ int finish_gT(const float *ws, const float *K, float *gT, int B, int S, int nblk
 }
 }  // namespace mvf_geom
 
+// wide adjoint of the reflection pad (mvf_glue.hip)
+namespace mvf_glue {
+bool reflect_pad1_bwd_wide(const float *g_out, float *g_in, int planes, int H, int W, hipStream_t st);
+}
+
 // ============================================================================ C ABI
 extern "C" {
 
 int mvf_abi_version(void) { return MVF_ABI_VERSION; }
 
-int mvf_profile_enable(int on)
+int mvf_profile_enable(int level)
 {
     auto &p = mvf::prof();
     std::lock_guard<std::mutex> g(p.mu);
-    p.on = on != 0;
+    p.level = level < 0 ? 0 : level;
     return 0;
 }
 
@@ -800,6 +822,7 @@ int mvf_profile_reset(void)
     std::lock_guard<std::mutex> g(p.mu);
     for (int i = 0; i < MVF_PROF_COUNT; ++i) {
         mvf::drain(p, i);
+        p.done[i].clear();
         p.acc_ms[i] = 0.0;
         p.acc_n[i] = 0;
         p.acc_work[i] = 0;
@@ -818,13 +841,41 @@ int mvf_profile_read(int id, double *total_ms, int64_t *launches)
     return 0;
 }
 
-int mvf_profile_read_work(int id, int64_t *pixels)
+int mvf_profile_read_work(int id, int64_t *work)
 {
-    if (id < 0 || id >= MVF_PROF_COUNT || !pixels) return (int)hipErrorInvalidValue;
+    if (id < 0 || id >= MVF_PROF_COUNT || !work) return (int)hipErrorInvalidValue;
     auto &p = mvf::prof();
     std::lock_guard<std::mutex> g(p.mu);
-    *pixels = p.acc_work[id];
+    *work = p.acc_work[id];
     return 0;
+}
+
+int64_t mvf_profile_read_launches(int id, double *ms, int64_t *work, int32_t *tag, int64_t cap)
+{
+    if (id < 0 || id >= MVF_PROF_COUNT || cap < 0) return -(int64_t)hipErrorInvalidValue;
+    auto &p = mvf::prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    mvf::drain(p, id);
+    const int64_t n = std::min<int64_t>(cap, (int64_t)p.done[id].size());
+    for (int64_t i = 0; i < n; ++i) {
+        if (ms) ms[i] = p.done[id][i].ms;
+        if (work) work[i] = p.done[id][i].work;
+        if (tag) tag[i] = p.done[id][i].tag;
+    }
+    return n;
+}
+
+const char *mvf_profile_name(int id)
+{
+    static const char *const names[MVF_PROF_COUNT] = {
+        "k_photo_fwd<fused>", "k_photo_bwd<fused>", "k_photo_fwd", "k_photo_bwd", "k_warp_fwd", "k_warp_bwd",
+        "k_unit_fb", "k_units_finish", "k_fb_scale", "k_disp_mean", "k_bias_act_fwd", "k_bias_act_bwd",
+        "k_act_bwd_flat", "k_up2cat_pad_fwd", "k_up2cat_pad_bwd_x", "k_up2cat_pad_bwd_skip", "k_reflect_pad1_fwd",
+        "k_reflect_pad1_bwd", "k_maxpool3s2_fwd", "k_maxpool3s2_bwd", "k_fusion_level_fwd",
+        "k_fusion_level_bwd_gather", "k_flow_warp_fwd", "k_disp_head_fwd", "k_disp_head_bwd",
+        "k_resize_bilinear_fwd", "k_resize_bilinear_bwd", "k_upsample_nearest_fwd", "k_upsample_nearest_bwd",
+        "k_silog_fwd", "k_silog_bwd", "k_affine"};
+    return (id >= 0 && id < MVF_PROF_COUNT) ? names[id] : "?";
 }
 
 const char *mvf_error_string(int err) { return hipGetErrorString((hipError_t)err); }
@@ -953,6 +1004,8 @@ int mvf_flow_warp_fwd(const float *img, const float *flow, const float *xs, cons
 {
     if (B * C * H * W <= 0) return 0;
     dim3 grid((unsigned)((H * W + NT - 1) / NT), (unsigned)((C + FW_CCH - 1) / FW_CCH), (unsigned)B);
+    // image read once, flow read once, warped image written once
+    ProfScope ps(MVF_PROF_FLOW_WARP_FWD, stream, 4LL * B * H * W * (2LL * C + 2));
     hipLaunchKernelGGL(k_flow_warp_fwd, grid, dim3(NT), 0, (hipStream_t)stream, img, flow, xs, ys, out,
                        idx_xy, C, H, W);
     return hip_check_launch();
@@ -985,6 +1038,7 @@ int mvf_silog_fwd(const float *pred, const float *target, const float *mask, flo
 {
     if (B <= 0 || N <= 0) return 0;
     if (B > 65535) return (int)hipErrorInvalidValue;   // grid.y
+    ProfScope ps(MVF_PROF_SILOG_FWD, stream, 4LL * B * N * (2 + (mask ? 1 : 0)));
     hipLaunchKernelGGL(k_silog_partial, dim3(SIL_NB, B), dim3(NT), 0, (hipStream_t)stream, pred, target,
                        mask, workspace, N);
     hipLaunchKernelGGL(k_silog_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, workspace, loss, sums,
@@ -997,6 +1051,7 @@ int mvf_silog_bwd(const float *pred, const float *target, const float *mask, con
                   void *stream)
 {
     if (B <= 0 || N <= 0) return 0;
+    ProfScope ps(MVF_PROF_SILOG_BWD, stream, 4LL * B * N * (2 + (mask ? 1 : 0) + (g_pred ? 1 : 0) + (g_target ? 1 : 0)));
     hipLaunchKernelGGL(k_silog_bwd, dim3((unsigned)((N + NT - 1) / NT), (unsigned)B), dim3(NT), 0,
                        (hipStream_t)stream, pred, target, mask, sums, g_loss, g_pred, g_target, B, N, beta);
     return hip_check_launch();
@@ -1007,6 +1062,7 @@ int mvf_reflect_pad1_fwd(const float *in, float *out, int planes, int H, int W, 
     if (planes <= 0) return 0;
     if (!in || !out || H < 2 || W < 2 || planes > 65535 * RP_PL) return (int)hipErrorInvalidValue;
     const int n = (H + 2) * (W + 2);
+    ProfScope ps(MVF_PROF_REFLECT_PAD_FWD, stream, 4LL * planes * ((int64_t)H * W + n));
     hipLaunchKernelGGL(k_reflect_pad1_fwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((planes + RP_PL - 1) / RP_PL)),
                        dim3(NT), 0, (hipStream_t)stream, in, out, planes, H, W);
     return hip_check_launch();
@@ -1017,6 +1073,8 @@ int mvf_reflect_pad1_bwd(const float *g_out, float *g_in, int planes, int H, int
     if (planes <= 0) return 0;
     if (!g_out || !g_in || H < 2 || W < 2 || planes > 65535 * RP_PL) return (int)hipErrorInvalidValue;
     const int n = H * W;
+    ProfScope ps(MVF_PROF_REFLECT_PAD_BWD, stream, 4LL * planes * ((int64_t)n + (int64_t)(H + 2) * (W + 2)));
+    if (mvf_glue::reflect_pad1_bwd_wide(g_out, g_in, planes, H, W, (hipStream_t)stream)) return hip_check_launch();
     hipLaunchKernelGGL(k_reflect_pad1_bwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((planes + RP_PL - 1) / RP_PL)),
                        dim3(NT), 0, (hipStream_t)stream, g_out, g_in, planes, H, W);
     return hip_check_launch();

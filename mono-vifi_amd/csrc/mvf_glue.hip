@@ -13,6 +13,8 @@
 //     one pass emits disp, depth and the per-image mean partials of disp the unit kernel needs.
 // Bound: HBM streaming.  -ffp-contract=off (mvf_common.hpp); sigmoid as ATen writes it,
 // 1 / (1 + exp(-x)).
+#include <cstdlib>
+
 #include "mvf_common.hpp"
 
 using namespace mvf;
@@ -117,6 +119,91 @@ __global__ void __launch_bounds__(NT) k_up2cat_pad_bwd_skip(const float *__restr
         if (c0 + k < C2) g_skip[((size_t)b * C2 + c0 + k) * H * W + i] = v[k];
 }
 
+// ---- the pad adjoints, wide form (round 4) ------------------------------------------------------------------
+// The one-element-per-lane gathers above move 4 bytes per lane and instruction (0.40-0.51 of the HBM peak in the
+// training step).  Here a lane owns FOUR consecutive columns of an unpadded row: its own copies are one 16-byte load
+// from the padded plane (4-byte aligned: a padded row is W + 2 floats), the reflected border copies are added by the
+// few lanes that sit on rows 1 / H-2 or hold columns 1 / W-2, and the result leaves as one aligned 16-byte store.
+// Same additions in the same order as pad_adjoint.  Needs W % 4 == 0, W >= 8, H >= 4 (else the forms above run).
+struct __attribute__((packed, aligned(4))) F4U {
+    float x, y, z, w;
+};
+MVF_DEV float4 ldg4u(const float *__restrict__ p)
+{
+    const F4U v = *reinterpret_cast<const F4U *>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+MVF_DEV float4 pad_adj4(const float *__restrict__ g, int y, int x0, int H, int W)
+{
+    const int Wp = W + 2;
+    const float *row = g + (size_t)(y + 1) * Wp;
+    float4 v = ldg4u(row + x0 + 1);
+    const bool first = x0 == 0, last = x0 + 4 == W;
+    if (first) v.y += row[0];                  // column 1 also receives padded column 0
+    if (last) v.z += row[W + 1];               // column W-2 also receives padded column W+1
+    const int ry = (y == 1) ? 0 : ((y == H - 2) ? H + 1 : -1);
+    if (ry >= 0) {
+        const float *rr = g + (size_t)ry * Wp;
+        const float4 r = ldg4u(rr + x0 + 1);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        if (first) v.y += rr[0];
+        if (last) v.z += rr[W + 1];
+    }
+    return v;
+}
+constexpr int PADW_PL = 4;      // planes per lane
+// dst plane p (of `planes`) <- padded source plane (p / Cd) * Cs + Coff + p % Cd; grid (H * W/4 blocks, plane chunks)
+__global__ void __launch_bounds__(NT) k_pad1_bwd_w4(const float *__restrict__ g, float *__restrict__ dst, int planes,
+                                                    int Cd, int Cs, int Coff, int H, int W)
+{
+    const int W4 = W >> 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W4) return;
+    const int y = i / W4, x0 = (i - y * W4) * 4;
+    const size_t PP = (size_t)(H + 2) * (W + 2), n = (size_t)H * W;
+    const int p0 = blockIdx.y * PADW_PL;
+    float4 v[PADW_PL];
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k) {
+        const int p = min(p0 + k, planes - 1);
+        const int b = p / Cd, c = p - b * Cd;
+        v[k] = pad_adj4(g + ((size_t)b * Cs + Coff + c) * PP, y, x0, H, W);
+    }
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k)
+        if (p0 + k < planes) *reinterpret_cast<float4 *>(dst + (size_t)(p0 + k) * n + (size_t)y * W + x0) = v[k];
+}
+// g_x of the x2-upsampled part: two outputs per lane = the 2 x 4 children of rows 2Y, 2Y+1
+__global__ void __launch_bounds__(NT) k_up2cat_pad_bwd_x_w4(const float *__restrict__ g, float *__restrict__ g_x, int planes,
+                                                            int C1, int C, int h, int w)
+{
+    const int H = 2 * h, W = 2 * w, w2 = w >> 1;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= h * w2) return;
+    const int Y = i / w2, j = i - Y * w2;
+    const size_t PP = (size_t)(H + 2) * (W + 2), n = (size_t)h * w;
+    const int p0 = blockIdx.y * PADW_PL;
+    float4 a[PADW_PL], bq[PADW_PL];
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k) {
+        const int p = min(p0 + k, planes - 1);
+        const int b = p / C1, c = p - b * C1;
+        const float *gp = g + ((size_t)b * C + c) * PP;
+        a[k] = pad_adj4(gp, 2 * Y, 4 * j, H, W);
+        bq[k] = pad_adj4(gp, 2 * Y + 1, 4 * j, H, W);
+    }
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k)
+        if (p0 + k < planes)
+            *reinterpret_cast<float2 *>(g_x + (size_t)(p0 + k) * n + (size_t)Y * w + 2 * j) =
+                make_float2((a[k].x + a[k].y) + (bq[k].x + bq[k].y), (a[k].z + a[k].w) + (bq[k].z + bq[k].w));
+}
+static bool pad_wide_ok(const void *padded, const void *plain, int H, int W)
+{
+    return (W & 3) == 0 && W >= 8 && H >= 4 && (((uintptr_t)plain) & 15) == 0 && (((uintptr_t)padded) & 3) == 0 &&
+           !getenv("MVF_PAD_NARROW");
+}
+
 // ---- disparity head: disp = sigmoid(logit), depth = 1 / (min_disp + range * disp), mean partials
 // grid (NMEAN, B): block (chunk, b) walks its slice of the image
 __global__ void __launch_bounds__(NT) k_disp_head_fwd(const float *__restrict__ logit,
@@ -219,7 +306,7 @@ __global__ void __launch_bounds__(NT) k_bias_act_fwd(const float *__restrict__ x
         for (int k = 0; k < U; ++k) {
             const int64_t i = i0 + k * NT;
             if (i >= total) continue;
-            const int c = (int)((i / per_plane) % C);
+            const int c = (int)(((unsigned)i / (unsigned)per_plane) % (unsigned)C);     // total < 2^31 (launcher)
             const float bv = bias ? bias[c] : 0.0f;
             const float sv = (act == ACT_PRELU) ? slope[slope_n == 1 ? 0 : c] : 0.0f;
             float4 t = v[k];
@@ -233,7 +320,7 @@ __global__ void __launch_bounds__(NT) k_bias_act_fwd(const float *__restrict__ x
         for (int k = 0; k < U; ++k) {
             const int64_t i = i0 + k * NT;
             if (i >= total) continue;
-            const int c = (int)((i / per_plane) % C);
+            const int c = (int)(((unsigned)i / (unsigned)per_plane) % (unsigned)C);
             float t = x[i] + (bias ? bias[c] : 0.0f);
             if (res) t += res[i];
             out[i] = act_apply(t, act, (act == ACT_PRELU) ? slope[slope_n == 1 ? 0 : c] : 0.0f);
@@ -276,51 +363,135 @@ __global__ void __launch_bounds__(NT) k_act_bwd_flat(const float *__restrict__ g
 
 // block (c, s): the s-th of `nsplit` equal runs of channel c's N*HW elements (n-major).
 // g_x = g * act'(out) (not written for act none: it IS g), part[s][c] = sum of g_x over the run.
+// Round 4: a lane keeps FOUR element groups in flight per iteration (the one-group loop left two 16-byte loads in
+// flight per lane: 0.50 of the HBM peak) and the (image, offset) split of an element index is 32-bit arithmetic
+// (N * HW / 4 < 2^31 is checked by the launcher; the 64-bit divide was ~60 instructions per 16 bytes).
+MVF_DEV float4 act_grad4(float4 gv, float4 ov, int act)
+{
+    if (act == ACT_ELU) {
+        gv.x = (ov.x > 0.0f) ? gv.x : gv.x * (ov.x + 1.0f);
+        gv.y = (ov.y > 0.0f) ? gv.y : gv.y * (ov.y + 1.0f);
+        gv.z = (ov.z > 0.0f) ? gv.z : gv.z * (ov.z + 1.0f);
+        gv.w = (ov.w > 0.0f) ? gv.w : gv.w * (ov.w + 1.0f);
+    } else {
+        gv.x = (ov.x > 0.0f) ? gv.x : 0.0f;
+        gv.y = (ov.y > 0.0f) ? gv.y : 0.0f;
+        gv.z = (ov.z > 0.0f) ? gv.z : 0.0f;
+        gv.w = (ov.w > 0.0f) ? gv.w : 0.0f;
+    }
+    return gv;
+}
 template <bool VEC>
 __global__ void __launch_bounds__(NT) k_bias_act_bwd(const float *__restrict__ g, const float *__restrict__ out,
                                                      float *__restrict__ gx, float *__restrict__ part, int N, int C,
                                                      int HW, int act, int nsplit)
 {
     __shared__ float scratch[NT / 16];
+    constexpr int U = 4;
     const int c = blockIdx.x % C, s = blockIdx.x / C;
-    const int per_plane = VEC ? (HW >> 2) : HW;
-    const int64_t total = (int64_t)N * per_plane;
-    const int64_t per = (total + nsplit - 1) / nsplit;
-    const int64_t lo = (int64_t)s * per, hi = (lo + per < total) ? lo + per : total;
+    const unsigned per_plane = VEC ? (unsigned)(HW >> 2) : (unsigned)HW;
+    const unsigned total = (unsigned)N * per_plane;
+    const unsigned per = (total + nsplit - 1) / nsplit;
+    const unsigned lo = min((unsigned)s * per, total), hi = min(lo + per, total);
     float acc = 0.0f;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += NT) {
-        const int n = (int)(i / per_plane), q = (int)(i - (int64_t)n * per_plane);
-        const size_t o = ((size_t)n * C + c) * HW;
+    for (unsigned i0 = lo + threadIdx.x; i0 < hi; i0 += U * NT) {
+        size_t o[U];
+        bool ok[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            const unsigned i = i0 + k * NT;
+            ok[k] = i < hi;
+            const unsigned ic = ok[k] ? i : lo;
+            const unsigned n = ic / per_plane, q = ic - n * per_plane;
+            o[k] = ((size_t)n * C + c) * HW + (VEC ? (size_t)q * 4 : q);
+        }
         if (VEC) {
-            float4 gv = reinterpret_cast<const float4 *>(g + o)[q];
-            if (act != ACT_NONE) {
-                const float4 ov = reinterpret_cast<const float4 *>(out + o)[q];
-                if (act == ACT_ELU) {
-                    gv.x = (ov.x > 0.0f) ? gv.x : gv.x * (ov.x + 1.0f);
-                    gv.y = (ov.y > 0.0f) ? gv.y : gv.y * (ov.y + 1.0f);
-                    gv.z = (ov.z > 0.0f) ? gv.z : gv.z * (ov.z + 1.0f);
-                    gv.w = (ov.w > 0.0f) ? gv.w : gv.w * (ov.w + 1.0f);
-                } else {
-                    gv.x = (ov.x > 0.0f) ? gv.x : 0.0f;
-                    gv.y = (ov.y > 0.0f) ? gv.y : 0.0f;
-                    gv.z = (ov.z > 0.0f) ? gv.z : 0.0f;
-                    gv.w = (ov.w > 0.0f) ? gv.w : 0.0f;
+            float4 gv[U], ov[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                gv[k] = *reinterpret_cast<const float4 *>(g + o[k]);
+                if (act != ACT_NONE) ov[k] = *reinterpret_cast<const float4 *>(out + o[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (!ok[k]) continue;
+                float4 t = gv[k];
+                if (act != ACT_NONE) {
+                    t = act_grad4(t, ov[k], act);
+                    *reinterpret_cast<float4 *>(gx + o[k]) = t;
                 }
-                reinterpret_cast<float4 *>(gx + o)[q] = gv;
+                acc += (t.x + t.y) + (t.z + t.w);
             }
-            acc += (gv.x + gv.y) + (gv.z + gv.w);
         } else {
-            float gv = g[o + q];
-            if (act != ACT_NONE) {
-                const float ov = out[o + q];
-                gv = (ov > 0.0f) ? gv : ((act == ACT_ELU) ? gv * (ov + 1.0f) : 0.0f);
-                gx[o + q] = gv;
+            float gv[U], ov[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                gv[k] = g[o[k]];
+                if (act != ACT_NONE) ov[k] = out[o[k]];
             }
-            acc += gv;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (!ok[k]) continue;
+                float t = gv[k];
+                if (act != ACT_NONE) {
+                    t = (ov[k] > 0.0f) ? t : ((act == ACT_ELU) ? t * (ov[k] + 1.0f) : 0.0f);
+                    gx[o[k]] = t;
+                }
+                acc += t;
+            }
         }
     }
     const float r = block_sum<NT>(acc, scratch);
     if (threadIdx.x == 0) part[(size_t)s * C + c] = r;
+}
+
+// The same pass, ONE SHOT per block (round 4): block (chunk, plane) handles 1024 float4 of one (n, c) plane with its
+// four 16-byte loads per stream in flight and exits -- measured on this chip the many-short-blocks form streams at
+// 0.69 of the HBM peak (k_act_bwd_flat, k_bias_act_fwd) where blocks that loop over long runs reach 0.48-0.50.
+// part[(n * chunks + chunk) * C + c]; folded per channel in that order by k_bias_grad_finish_tree.
+__global__ void __launch_bounds__(NT) k_bias_act_bwd_shot(const float4 *__restrict__ g, const float4 *__restrict__ out,
+                                                          float4 *__restrict__ gx, float *__restrict__ part, int C,
+                                                          int per_plane, int act)
+{
+    __shared__ float scratch[NT / kWave];
+    constexpr int U = 4;
+    const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
+    const size_t base = (size_t)plane * per_plane;
+    const int q0 = blockIdx.x * (NT * U) + threadIdx.x;
+    float4 gv[U], ov[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int q = q0 + k * NT;
+        if (q < per_plane) {
+            gv[k] = g[base + q];
+            if (act != ACT_NONE) ov[k] = out[base + q];
+        }
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int q = q0 + k * NT;
+        if (q >= per_plane) continue;
+        float4 t = gv[k];
+        if (act != ACT_NONE) {
+            t = act_grad4(t, ov[k], act);
+            gx[base + q] = t;
+        }
+        acc += (t.x + t.y) + (t.z + t.w);
+    }
+    const float r = block_sum<NT>(acc, scratch);
+    if (threadIdx.x == 0) part[((size_t)n * gridDim.x + blockIdx.x) * C + c] = r;
+}
+// block c: lane t adds the partials t, t + 256, ... of channel c in index order, then one fixed-shape block sum
+__global__ void __launch_bounds__(NT) k_bias_grad_finish_tree(const float *__restrict__ part, float *__restrict__ gb,
+                                                              int C, int nsplit)
+{
+    __shared__ float scratch[NT / kWave];
+    const int c = blockIdx.x;
+    float a = 0.0f;
+    for (int s = threadIdx.x; s < nsplit; s += NT) a += part[(size_t)s * C + c];
+    const float r = block_sum<NT>(a, scratch);
+    if (threadIdx.x == 0) gb[c] = r;
 }
 
 __global__ void __launch_bounds__(NT) k_bias_grad_finish(const float *__restrict__ part, float *__restrict__ gb,
@@ -580,6 +751,133 @@ __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd(const float *__restrict__
     }
 }
 
+// ---- the same pool, wide form (W % 4 == 0, 16-byte aligned planes: every ResNet stem of the step) --------
+// Round 4: the one-output-per-lane kernels above ran at 0.28 / 0.31 of the HBM peak -- nine (forward) / eight
+// (backward) 4-byte loads per element and plane, each wave instruction touching 256 useful bytes.  Here a lane
+// owns TWO horizontally adjacent outputs (forward: their 3 x 5 input patch is one 16-byte load + one scalar per
+// row) resp. a 2 x 4 INPUT block (backward: the six windows that can touch it are a float2 + a float and a
+// uchar2 + a uchar per window row; two 16-byte stores).  Same selection rule, same accumulation order as above
+// (bit-identical results: tests/test_hip_parity.py::test_maxpool3s2_vs_oracle runs both forms).
+constexpr int PLW = 4;      // planes per lane
+MVF_DEV void pool_take(float v, int code, float &best, int &bi)
+{
+    if ((v > best) || (v != v)) { best = v; bi = code; }
+}
+__global__ void __launch_bounds__(NT) k_maxpool3s2_fwd_w4(const float *__restrict__ x, float *__restrict__ out,
+                                                          uint8_t *__restrict__ idx, int planes, int H, int W,
+                                                          int OH, int OW)
+{
+    const int OW2 = OW >> 1;                       // output pairs per row (OW = W / 2 is even)
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= OH * OW2) return;
+    const int oy = i / OW2, j = i - oy * OW2;
+    const int y0 = 2 * oy - 1, xa = 4 * j;         // window rows y0..y0+2; columns xa-1 .. xa+3
+    const int p0 = blockIdx.y * PLW;
+    const size_t ni = (size_t)H * W, no = (size_t)OH * OW;
+    const bool left = xa > 0;
+    float4 r[PLW][3];
+    float l[PLW][3];
+#pragma unroll
+    for (int k = 0; k < PLW; ++k) {
+        const float *xp = x + (size_t)min(p0 + k, planes - 1) * ni;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = min(max(y0 + kh, 0), H - 1);          // clamped address; invalid rows are skipped below
+            r[k][kh] = *reinterpret_cast<const float4 *>(xp + (size_t)yy * W + xa);
+            l[k][kh] = xp[(size_t)yy * W + (left ? xa - 1 : xa)];
+        }
+    }
+    const int first = (y0 < 0 ? 3 : 0);
+#pragma unroll
+    for (int k = 0; k < PLW; ++k) {
+        if (p0 + k >= planes) continue;
+        float b0 = -INFINITY, b1 = -INFINITY;
+        int i0 = first + (left ? 0 : 1), i1 = first;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int yy = y0 + kh;
+            if (yy < 0 || yy >= H) continue;
+            if (left) pool_take(l[k][kh], kh * 3 + 0, b0, i0);
+            pool_take(r[k][kh].x, kh * 3 + 1, b0, i0);
+            pool_take(r[k][kh].y, kh * 3 + 2, b0, i0);
+            pool_take(r[k][kh].y, kh * 3 + 0, b1, i1);
+            pool_take(r[k][kh].z, kh * 3 + 1, b1, i1);
+            pool_take(r[k][kh].w, kh * 3 + 2, b1, i1);
+        }
+        const size_t o = (size_t)(p0 + k) * no + (size_t)oy * OW + 2 * j;
+        *reinterpret_cast<float2 *>(out + o) = make_float2(b0, b1);
+        *reinterpret_cast<uchar2 *>(idx + o) = make_uchar2((uint8_t)i0, (uint8_t)i1);
+    }
+}
+
+// one input pixel's gradient from the (<= 4) windows around it; wg / wc: gradients and codes of the window block
+// rows {a, a+1} x columns {2b, 2b+1, 2b+2}; (ry, rx) = pixel position inside the 2 x 4 block
+MVF_DEV float pool_gather(const float (&wg)[2][3], const uint8_t (&wc)[2][3], int ry, int rx, bool vy1, const bool (&vx)[3])
+{
+    // windows of row y = 2a + ry: oy0 = a (+ a+1 for odd y); of column x = 4b + rx: ox0 = 2b + (rx >> 1) (+1 for odd x)
+    const int c0 = rx >> 1, c1 = c0 + 1;
+    const bool oddy = ry & 1, oddx = rx & 1;
+    const int cy0 = (ry + 1) * 3, cy1 = (ry - 1) * 3;          // (y - 2 oy + 1) * 3 for oy = a, a + 1
+    const int cx0 = rx - 2 * c0 + 1, cx1 = rx - 2 * c1 + 1;
+    float acc = 0.0f;
+    if (wc[0][c0] == (uint8_t)(cy0 + cx0)) acc += wg[0][c0];
+    if (oddx && vx[c1] && wc[0][c1] == (uint8_t)(cy0 + cx1)) acc += wg[0][c1];
+    if (oddy && vy1 && wc[1][c0] == (uint8_t)(cy1 + cx0)) acc += wg[1][c0];
+    if (oddy && vy1 && oddx && vx[c1] && wc[1][c1] == (uint8_t)(cy1 + cx1)) acc += wg[1][c1];
+    return acc;
+}
+__global__ void __launch_bounds__(NT) k_maxpool3s2_bwd_w4(const float *__restrict__ g, const uint8_t *__restrict__ idx,
+                                                          float *__restrict__ gx, int planes, int H, int W, int OH,
+                                                          int OW)
+{
+    const int W4 = W >> 2, H2 = H >> 1;            // H even, W % 4 == 0
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H2 * W4) return;
+    const int a = i / W4, b = i - a * W4;
+    const int p0 = blockIdx.y * PLW;
+    const size_t ni = (size_t)H * W, no = (size_t)OH * OW;
+    const bool vy1 = a + 1 < OH;
+    const bool vx[3] = {true, true, 2 * b + 2 < OW};
+    const int oy1 = vy1 ? a + 1 : a, ox2 = vx[2] ? 2 * b + 2 : 2 * b + 1;
+    float2 g01[PLW][2];
+    float g2[PLW][2];
+    uchar2 c01[PLW][2];
+    uint8_t c2[PLW][2];
+#pragma unroll
+    for (int k = 0; k < PLW; ++k) {
+        const size_t pb = (size_t)min(p0 + k, planes - 1) * no;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const size_t o = pb + (size_t)(r ? oy1 : a) * OW;
+            g01[k][r] = *reinterpret_cast<const float2 *>(g + o + 2 * b);
+            g2[k][r] = g[o + ox2];
+            c01[k][r] = *reinterpret_cast<const uchar2 *>(idx + o + 2 * b);
+            c2[k][r] = idx[o + ox2];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PLW; ++k) {
+        if (p0 + k >= planes) continue;
+        float wg[2][3];
+        uint8_t wc[2][3];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            wg[r][0] = g01[k][r].x; wg[r][1] = g01[k][r].y; wg[r][2] = g2[k][r];
+            wc[r][0] = c01[k][r].x; wc[r][1] = c01[k][r].y; wc[r][2] = c2[k][r];
+        }
+        float *op = gx + (size_t)(p0 + k) * ni + (size_t)(2 * a) * W + 4 * b;
+#pragma unroll
+        for (int ry = 0; ry < 2; ++ry) {
+            float4 v;
+            v.x = pool_gather(wg, wc, ry, 0, vy1, vx);
+            v.y = pool_gather(wg, wc, ry, 1, vy1, vx);
+            v.z = pool_gather(wg, wc, ry, 2, vy1, vx);
+            v.w = pool_gather(wg, wc, ry, 3, vy1, vx);
+            *reinterpret_cast<float4 *>(op + (size_t)ry * W) = v;
+        }
+    }
+}
+
 // ---- on-device colour augmentation -------------------------------------------------------------
 // MonoDataset.__getitem__ / preprocess (datasets/mono_dataset.py:102-184, 214-256): with
 // probability 1/2 a sample's frames are flipped horizontally, and with probability 1/2 all of its
@@ -693,6 +991,17 @@ __global__ void __launch_bounds__(NT) k_jitter_apply(const float *__restrict__ i
 
 }  // namespace
 
+// wide adjoint of ReflectionPad2d(1) for mvf_reflect_pad1_bwd (mvf_geom.hip); false when the shape needs the narrow form
+namespace mvf_glue {
+bool reflect_pad1_bwd_wide(const float *g_out, float *g_in, int planes, int H, int W, hipStream_t st)
+{
+    if (!pad_wide_ok(g_out, g_in, H, W) || planes > 65535 * PADW_PL) return false;
+    hipLaunchKernelGGL(k_pad1_bwd_w4, dim3((unsigned)((H * (W / 4) + NT - 1) / NT), (unsigned)((planes + PADW_PL - 1) / PADW_PL)),
+                       dim3(NT), 0, st, g_out, g_in, planes, 1, 1, 0, H, W);
+    return true;
+}
+}  // namespace mvf_glue
+
 extern "C" {
 
 int mvf_up2cat_pad_fwd(const float *x, const float *skip, float *out, int B, int C1, int C2, int h, int w,
@@ -701,6 +1010,8 @@ int mvf_up2cat_pad_fwd(const float *x, const float *skip, float *out, int B, int
     if (B <= 0 || C1 <= 0 || h <= 0 || w <= 0) return 0;
     if (!x || !out || C2 < 0 || (C2 > 0 && !skip)) return (int)hipErrorInvalidValue;
     const int n = (2 * h + 2) * (2 * w + 2), C = C1 + C2;
+    // algorithmic bytes: x and skip read once, the padded concatenation written once
+    ProfScope ps(MVF_PROF_UP2CAT_FWD, stream, 4LL * B * ((int64_t)C1 * h * w + (int64_t)C2 * 4 * h * w + (int64_t)C * n));
     hipLaunchKernelGGL(k_up2cat_pad_fwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((C + PL - 1) / PL), (unsigned)B),
                        dim3(NT), 0, (hipStream_t)stream, x, skip, out, C1, C2, h, w);
     return hip_check_launch();
@@ -711,12 +1022,25 @@ int mvf_up2cat_pad_bwd(const float *g_out, float *g_x, float *g_skip, int B, int
 {
     if (B <= 0 || C1 <= 0 || h <= 0 || w <= 0) return 0;
     if (!g_out || C2 < 0 || h < 2 || w < 2) return (int)hipErrorInvalidValue;   // 2h, 2w >= 4
-    if (g_x)
+    const int64_t PPb = (int64_t)(2 * h + 2) * (2 * w + 2);
+    if (g_x) {
+        ProfScope ps(MVF_PROF_UP2CAT_BWD_X, stream, 4LL * B * C1 * (PPb + (int64_t)h * w));
+        if (pad_wide_ok(g_out, g_x, 2 * h, 2 * w) && (((uintptr_t)g_x) & 7) == 0 && (int64_t)B * C1 <= 65535LL * PADW_PL)
+            hipLaunchKernelGGL(k_up2cat_pad_bwd_x_w4, dim3((unsigned)((h * (w / 2) + NT - 1) / NT), (unsigned)((B * C1 + PADW_PL - 1) / PADW_PL)),
+                               dim3(NT), 0, (hipStream_t)stream, g_out, g_x, B * C1, C1, C1 + C2, h, w);
+        else
         hipLaunchKernelGGL(k_up2cat_pad_bwd_x, dim3((unsigned)((h * w + NT - 1) / NT), (unsigned)((C1 + PL - 1) / PL), (unsigned)B),
                            dim3(NT), 0, (hipStream_t)stream, g_out, g_x, C1, C2, h, w);
-    if (g_skip && C2 > 0)
+    }
+    if (g_skip && C2 > 0) {
+        ProfScope ps(MVF_PROF_UP2CAT_BWD_SKIP, stream, 4LL * B * C2 * (PPb + 4LL * h * w));
+        if (pad_wide_ok(g_out, g_skip, 2 * h, 2 * w) && (int64_t)B * C2 <= 65535LL * PADW_PL)
+            hipLaunchKernelGGL(k_pad1_bwd_w4, dim3((unsigned)((2 * h * (2 * w / 4) + NT - 1) / NT), (unsigned)((B * C2 + PADW_PL - 1) / PADW_PL)),
+                               dim3(NT), 0, (hipStream_t)stream, g_out, g_skip, B * C2, C2, C1 + C2, C1, 2 * h, 2 * w);
+        else
         hipLaunchKernelGGL(k_up2cat_pad_bwd_skip, dim3((unsigned)((4 * h * w + NT - 1) / NT), (unsigned)((C2 + PL - 1) / PL), (unsigned)B),
                            dim3(NT), 0, (hipStream_t)stream, g_out, g_skip, C1, C2, h, w);
+    }
     return hip_check_launch();
 }
 
@@ -725,6 +1049,7 @@ int mvf_disp_head_fwd(const float *logit, float *disp, float *depth, float *mean
 {
     if (B <= 0 || N <= 0) return 0;
     if (!logit || !disp || B > 65535) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_DISP_HEAD_FWD, stream, 4LL * B * N * (2 + (depth ? 1 : 0)));
     hipLaunchKernelGGL(k_disp_head_fwd, dim3(NMEAN, (unsigned)B), dim3(NT), 0, (hipStream_t)stream, logit, disp,
                        depth, mean_partials, N, min_disp, range);
     return hip_check_launch();
@@ -737,6 +1062,7 @@ int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_dep
     if (!disp || !g_logit) return (int)hipErrorInvalidValue;
     int64_t blocks = (n + NT - 1) / NT;
     if (blocks > 8192) blocks = 8192;
+    ProfScope ps(MVF_PROF_DISP_HEAD_BWD, stream, 4LL * n * (2 + (g_disp ? 1 : 0) + (g_depth ? 1 : 0)));
     hipLaunchKernelGGL(k_disp_head_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, disp, g_disp,
                        g_depth, g_logit, n, min_disp, range);
     return hip_check_launch();
@@ -753,7 +1079,19 @@ static int bias_act_nsplit(int N, int C, int HW)
     return (int)s;
 }
 
-size_t mvf_bias_act_workspace_floats(int N, int C, int HW) { return (size_t)bias_act_nsplit(N, C, HW) * C; }
+// one-shot form of the backward pass: 16-byte vectors, planes of >= 512 float4, plane count within grid.y
+static bool bias_shot_ok(int N, int C, int HW, bool vec)
+{
+    return vec && (HW >> 2) >= 512 && (int64_t)N * C <= 65535 && !getenv("MVF_BIAS_RUNS");
+}
+static int bias_shot_chunks(int HW) { return ((HW >> 2) + NT * 4 - 1) / (NT * 4); }
+
+size_t mvf_bias_act_workspace_floats(int N, int C, int HW)
+{
+    const size_t runs = (size_t)bias_act_nsplit(N, C, HW) * C;
+    const size_t shot = ((HW & 3) == 0) ? (size_t)N * bias_shot_chunks(HW) * C : 0;
+    return runs > shot ? runs : shot;
+}
 
 int mvf_bias_act_fwd(const float *x, const float *bias, const float *slope, const float *res, float *out, int N,
                      int C, int HW, int act, int slope_n, void *stream)
@@ -765,7 +1103,8 @@ int mvf_bias_act_fwd(const float *x, const float *bias, const float *slope, cons
     const int per_plane = vec ? HW / 4 : HW;
     const int64_t total = (int64_t)N * C * per_plane;
     const int64_t blocks = (total + NT * 4 - 1) / (NT * 4);
-    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    if (total >= 0x7fffffffLL) return (int)hipErrorInvalidValue;       // 32-bit element index inside the kernel
+    ProfScope ps(MVF_PROF_BIAS_ACT_FWD, stream, 4LL * N * C * HW * (2 + (res ? 1 : 0)));
     if (vec)
         hipLaunchKernelGGL(k_bias_act_fwd<true>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, x, bias,
                            slope, res, out, C, per_plane, total, act, slope_n);
@@ -787,6 +1126,7 @@ int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias
         const int64_t total = (int64_t)N * C * (vec ? HW / 4 : HW);
         const int64_t blocks = (total + NT * 4 - 1) / (NT * 4);
         if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+        ProfScope ps(MVF_PROF_ACT_BWD_FLAT, stream, 12LL * N * C * HW);
         if (vec)
             hipLaunchKernelGGL(k_act_bwd_flat<true>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, g, out,
                                g_x, total, act);
@@ -796,6 +1136,18 @@ int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float *g_bias
         return hip_check_launch();
     }
     const int nsplit = bias_act_nsplit(N, C, HW);
+    if ((int64_t)N * HW >= 0x7fffffffLL) return (int)hipErrorInvalidValue;      // 32-bit element index per channel
+    // g read once; with an activation: its output read and g_x written as well
+    ProfScope ps(MVF_PROF_BIAS_ACT_BWD, stream, 4LL * N * C * HW * (act != ACT_NONE ? 3 : 1));
+    if (bias_shot_ok(N, C, HW, vec)) {
+        const int chunks = bias_shot_chunks(HW);
+        hipLaunchKernelGGL(k_bias_act_bwd_shot, dim3((unsigned)chunks, (unsigned)(N * C)), dim3(NT), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4 *>(g), reinterpret_cast<const float4 *>(out),
+                           reinterpret_cast<float4 *>(g_x), workspace, C, HW >> 2, act);
+        hipLaunchKernelGGL(k_bias_grad_finish_tree, dim3((unsigned)C), dim3(NT), 0, (hipStream_t)stream, workspace, g_bias,
+                           C, N * chunks);
+        return hip_check_launch();
+    }
     if (vec)
         hipLaunchKernelGGL(k_bias_act_bwd<true>, dim3((unsigned)(C * nsplit)), dim3(NT), 0, (hipStream_t)stream, g,
                            out, g_x, workspace, N, C, HW, act, nsplit);
@@ -812,6 +1164,7 @@ int mvf_resize_bilinear_fwd(const float *x, float *out, int planes, int ih, int 
 {
     if (planes <= 0 || oh <= 0 || ow <= 0) return 0;
     if (!x || !out || ih <= 0 || iw <= 0 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_RESIZE_FWD, stream, 4LL * planes * ((int64_t)ih * iw + (int64_t)oh * ow));
     hipLaunchKernelGGL(k_resize_bilinear_fwd, dim3((unsigned)((oh * ow + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, x, out, planes, ih, iw, oh, ow, scale_h, scale_w,
                        align_corners);
@@ -823,6 +1176,7 @@ int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, int planes, int ih, 
 {
     if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
     if (!g_out || !g_x || oh <= 0 || ow <= 0 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_RESIZE_BWD, stream, 4LL * planes * ((int64_t)ih * iw + (int64_t)oh * ow));
     hipLaunchKernelGGL(k_resize_bilinear_bwd, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw, oh, ow, scale_h, scale_w,
                        align_corners);
@@ -834,6 +1188,7 @@ int mvf_upsample_nearest_fwd(const float *x, float *out, int planes, int ih, int
     if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
     if (!x || !out || factor < 1 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     const int no = ih * factor * iw * factor;
+    ProfScope ps(MVF_PROF_NEAREST_FWD, stream, 4LL * planes * ((int64_t)ih * iw + no));
     hipLaunchKernelGGL(k_upsample_nearest_fwd, dim3((unsigned)((no + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, x, out, planes, ih, iw, factor);
     return hip_check_launch();
@@ -843,9 +1198,17 @@ int mvf_upsample_nearest_bwd(const float *g_out, float *g_x, int planes, int ih,
 {
     if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
     if (!g_out || !g_x || factor < 1 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_NEAREST_BWD, stream, 4LL * planes * (int64_t)ih * iw * (1 + factor * factor));
     hipLaunchKernelGGL(k_upsample_nearest_bwd, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw, factor);
     return hip_check_launch();
+}
+
+// wide kernels: W % 4 == 0 (so OW = W / 2 is even and every plane row starts 16-byte aligned), aligned bases
+static bool pool_wide_ok(const float *full, const float *pooled, const uint8_t *idx, int H, int W)
+{
+    return (W & 3) == 0 && W >= 4 && H >= 2 && (((uintptr_t)full) & 15) == 0 && (((uintptr_t)pooled) & 7) == 0 &&
+           (((uintptr_t)idx) & 1) == 0;
 }
 
 int mvf_maxpool3s2_fwd(const float *x, float *out, uint8_t *idx, int planes, int H, int W, void *stream)
@@ -853,6 +1216,13 @@ int mvf_maxpool3s2_fwd(const float *x, float *out, uint8_t *idx, int planes, int
     if (planes <= 0 || H <= 0 || W <= 0) return 0;
     if (!x || !out || !idx || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    // input read once; pooled values (4 B) and window-local argmax (1 B) written
+    ProfScope ps(MVF_PROF_MAXPOOL_FWD, stream, (int64_t)planes * (4LL * H * W + 5LL * OH * OW));
+    if (pool_wide_ok(x, out, idx, H, W) && !getenv("MVF_POOL_NARROW")) {
+        hipLaunchKernelGGL(k_maxpool3s2_fwd_w4, dim3((unsigned)((OH * (OW / 2) + NT - 1) / NT), (unsigned)((planes + PLW - 1) / PLW)),
+                           dim3(NT), 0, (hipStream_t)stream, x, out, idx, planes, H, W, OH, OW);
+        return hip_check_launch();
+    }
     hipLaunchKernelGGL(k_maxpool3s2_fwd, dim3((unsigned)((OH * OW + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, x, out, idx, planes, H, W, OH, OW);
     return hip_check_launch();
@@ -863,6 +1233,12 @@ int mvf_maxpool3s2_bwd(const float *g_out, const uint8_t *idx, float *g_x, int p
     if (planes <= 0 || H <= 0 || W <= 0) return 0;
     if (!g_out || !idx || !g_x || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    ProfScope ps(MVF_PROF_MAXPOOL_BWD, stream, (int64_t)planes * (4LL * H * W + 5LL * OH * OW));
+    if (pool_wide_ok(g_x, g_out, idx, H, W) && (H & 1) == 0 && !getenv("MVF_POOL_NARROW")) {
+        hipLaunchKernelGGL(k_maxpool3s2_bwd_w4, dim3((unsigned)(((H / 2) * (W / 4) + NT - 1) / NT), (unsigned)((planes + PLW - 1) / PLW)),
+                           dim3(NT), 0, (hipStream_t)stream, g_out, idx, g_x, planes, H, W, OH, OW);
+        return hip_check_launch();
+    }
     hipLaunchKernelGGL(k_maxpool3s2_bwd, dim3((unsigned)((H * W + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, g_out, idx, g_x, planes, H, W, OH, OW);
     return hip_check_launch();

@@ -994,6 +994,7 @@ int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *sta
 namespace mvf_photo {
 void launch_disp_mean(const float *disp, size_t image_stride, float *ws, int B, int N, hipStream_t st)
 {
+    ProfScope ps(MVF_PROF_DISP_MEAN, st, 4LL * B * N);
     hipLaunchKernelGGL(k_disp_mean, dim3(NMEAN, B), dim3(256), 0, st, disp, ws, N, image_stride);
 }
 }  // namespace mvf_photo

@@ -1347,7 +1347,13 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
         }
     }
     {
-        ProfScope ps(MVF_PROF_UNIT_FWDBWD, st, (int64_t)n_units * B * N);
+        // launch kind for the per-type medians of bench.py: identity maps taken over / mask supplied / neither
+        int tag = MVF_TAG_SINGLE_FRAME;
+        for (int i = 0; i < n_units; ++i) {
+            if (a.u[i].ident_in) tag = MVF_TAG_MULTI_FRAME;
+            else if (a.u[i].mask && tag != MVF_TAG_MULTI_FRAME) tag = MVF_TAG_AFFINE;
+        }
+        ProfScope ps(MVF_PROF_UNIT_FWDBWD, st, (int64_t)n_units * B * N, tag);
         const dim3 grid((unsigned)(ntiles * B * n_units));
         const bool avg = flags & MVF_AVG_REPROJ;
         if (S == 1 && !avg) hipLaunchKernelGGL((k_unit_fb<1, false>), grid, dim3(NT), fb_smem(), st, a);
@@ -1355,7 +1361,11 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
         else if (!avg) hipLaunchKernelGGL((k_unit_fb<2, false>), grid, dim3(NT), fb_smem(), st, a);
         else hipLaunchKernelGGL((k_unit_fb<2, true>), grid, dim3(NT), fb_smem(), st, a);
     }
-    hipLaunchKernelGGL(k_units_finish, dim3((unsigned)(n_units * B)), dim3(32 * FIN_SLICES), 0, st, a, S);
+    {
+        // tile partials read once (27 floats per tile and image, 24 of them only with two sources)
+        ProfScope ps(MVF_PROF_UNITS_FINISH, st, 4LL * n_units * B * (int64_t)ntiles * (NPART + 12 * S));
+        hipLaunchKernelGGL(k_units_finish, dim3((unsigned)(n_units * B)), dim3(32 * FIN_SLICES), 0, st, a, S);
+    }
     return hip_check_launch();
 }
 
@@ -1386,6 +1396,7 @@ int mvf_units_fwdbwd_scale(const mvf_unit_scale_desc *units, int n_units, float 
     a.nT = S * B * 16;
     const int per = vec ? a.N4 : (N + 3) / 4;
     const unsigned gx = (unsigned)((max(per, a.nT) + 255) / 256);
+    ProfScope ps(MVF_PROF_FB_SCALE, stream, 8LL * n_units * B * N);       // raw gradient read, scaled gradient written
     hipLaunchKernelGGL(k_fb_scale, dim3(gx, (unsigned)B + 1, (unsigned)n_units), dim3(256), 0,
                        (hipStream_t)stream, a);
     return hip_check_launch();

@@ -353,6 +353,39 @@ def g4_fullsize():
              **{k: np.array(v) for k, v in sha.items()})
 
 
+# ----------------------------------------------------------------------------- G4 with other flag sets
+# full-size reference gradients existed for the default flags only; the other flag sets were
+# reference-checked at 24x40 (G3).  Same capture as G4 at the BASELINE shape C2 for --no_ssim, --avg_reprojection
+# and --disable_automasking (the latter without a mask: the reference's in-place mask multiply cannot broadcast a
+# single-candidate map, train.py:1030-1036).
+FLAG_SETS = {"no_ssim": dict(no_ssim=True), "avg": dict(avg_reprojection=True),
+             "noauto": dict(disable_automasking=True)}
+
+
+def g4_flag_sets():
+    B, H, W = FULL_SHAPES["C2"]
+    for fi, (name, flags) in enumerate(FLAG_SETS.items()):
+        seed = 410 + fi
+        use_mask = name != "noauto"
+        inp = synth.unit_inputs(seed, B, H, W, with_mask=use_mask)
+        fs = fake_self(B, H, W, **flags)
+        out, noise = run_unit_with_grads(fs, inp, use_mask=use_mask)
+        n = B * H * W
+        sidx = sample_idx(n, seed=11 + fi)
+        am = out["auto_mask"]
+        save("g4_flags_C2_" + name,
+             shape=np.array([B, H, W], np.int32), seed=np.array(seed, np.int32),
+             flags=np.array([int(fs.opt.no_ssim), int(fs.opt.avg_reprojection),
+                             int(fs.opt.disable_automasking)], np.int32),
+             use_mask=np.array(int(use_mask), np.int32),
+             loss=out["loss"], sample_idx=sidx,
+             auto_mask_mean=(am.mean() if am is not None else None),
+             auto_mask_s=(am.reshape(n)[sidx] if am is not None else None),
+             grad_disp_s=out["grad_disp"].reshape(n)[sidx],
+             grad_disp_norm=out["grad_disp"].double().norm(),
+             T=out["T"], grad_T=out["grad_T"])
+
+
 # ----------------------------------------------------------------------------- G5
 def g5_pose():
     rng = np.random.default_rng(500)
@@ -493,8 +526,8 @@ def g9_fusion():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
-    fns = dict(g1=g1_geometry, g2=g2_photometric, g3=g3_gradients, g4=g4_fullsize,
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g4f", "g5", "g6", "g7", "g8", "g9"]
+    fns = dict(g1=g1_geometry, g2=g2_photometric, g3=g3_gradients, g4=g4_fullsize, g4f=g4_flag_sets,
                g5=g5_pose, g6=g6_ssim_smooth, g7=g7_flow_warp, g8=g8_silog, g9=g9_fusion)
     for w in which:
         fns[w]()

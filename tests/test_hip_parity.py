@@ -260,6 +260,53 @@ def test_fullsize_unit(dev, cfg, unit_kernel):
     assert rel_err(N(Tt.grad), g["grad_T"]) <= 5e-3
 
 
+@BOTH_KERNELS
+@pytest.mark.parametrize("name", ["no_ssim", "avg", "noauto"])
+def test_fullsize_unit_flag_sets(dev, name, unit_kernel):
+    """C2 (12 x 192 x 640) under --no_ssim / --avg_reprojection / --disable_automasking against what the REFERENCE
+    produced on the same seeded inputs (loss, sampled auto-mask, 4,096 sampled gradients: 1e-4 on the tensor and,
+    for the training kernel, per element) and the whole tensors against the oracle."""
+    from mono_vifi_amd import ops, synthetic
+    g = load_golden("g4_flags_C2_" + name)
+    B, H, W = (int(v) for v in g["shape"])
+    flags = int(g["flags"][0]) * 1 + int(g["flags"][1]) * 2 + int(g["flags"][2]) * 4
+    use_mask = bool(int(g["use_mask"]))
+    inp = synthetic.unit_inputs(int(g["seed"]), B, H, W, with_mask=use_mask)
+    noise_np = np.ascontiguousarray(inp["noise"][:, :1] if flags & 2 else inp["noise"])
+    mask_np = inp["mask_rec"] if use_mask else None
+    disp = T(inp["disp"], dev, True)
+    Tt = T(g["T"], dev, True)
+    cfgt = (2, flags, 1e-3, 0.1, 100.0, 1e-7, True, False)
+    loss, auto_mask, argmin, _, _ = ops.Unit.apply(
+        disp, T(inp["tgt"], dev), Tt, T(inp["K"], dev), T(inp["inv_K"], dev),
+        T(mask_np, dev) if use_mask else None, None if flags & 4 else T(noise_np, dev), cfgt,
+        T(inp["src"][0], dev), T(inp["src"][1], dev))
+    loss.backward()
+    n = B * H * W
+    sidx = g["sample_idx"]
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    if "auto_mask_s" in g:
+        am = N(auto_mask).reshape(n)
+        assert np.array_equal(am[sidx], g["auto_mask_s"])
+        assert abs(am.mean() - float(g["auto_mask_mean"])) <= 1e-6
+    gd = N(disp.grad)
+    # 1e-4 on the tensor; per element 2e-4 of the tensor max: under these flag sets the REFERENCE's own fp32
+    # evaluation order sits 1.2-1.3e-4 from the fp64-folding oracle at its worst of the 4,096 samples (measured:
+    # no_ssim 1.30e-4, avg 1.24e-4, noauto 1.25e-4; relative L2 2.0-3.1e-5), the training kernel 1.44e-4 -- as close
+    # to the reference as a second legitimate evaluation order gets
+    assert_grad_close(gd.reshape(n)[sidx], g["grad_disp_s"], TOL, "grad_disp vs reference (sampled)",
+                      max_tol=2e-4 if unit_kernel == "fwdbwd" else None)
+    assert abs(np.linalg.norm(gd.astype(np.float64)) - float(g["grad_disp_norm"])) <= TOL * float(g["grad_disp_norm"])
+    ref = O.unit(inp["disp"], inp["tgt"], inp["src"], g["T"], inp["K"], inp["inv_K"], noise_np, mask_np, flags,
+                 want_grads=True)
+    am = N(argmin).astype(np.int32)
+    am[am == 255] = -1
+    assert np.array_equal(am, ref["idx"])
+    assert_grad_close(gd, ref["grad_disp"], TOL, "grad_disp vs oracle", max_tol=5e-4 if unit_kernel == "fwdbwd" else None)
+    assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
+    assert rel_err(N(Tt.grad), g["grad_T"]) <= 5e-3
+
+
 # ------------------------------------------------------------------ ragged shapes vs oracle
 RAGGED = [(1, 2, 2), (1, 3, 5), (2, 14, 62), (1, 15, 63), (1, 16, 64), (2, 17, 65), (1, 31, 129),
           (3, 33, 70), (1, 64, 200)]
@@ -639,7 +686,8 @@ def test_affine_vs_torch_formulation(dev):
 
 
 # ------------------------------------------------------------------ Conv3x3's reflection pad
-@pytest.mark.parametrize("shape", [(1, 1, 2, 2), (2, 3, 3, 5), (3, 16, 24, 40), (12, 16, 192, 640)])
+@pytest.mark.parametrize("shape", [(1, 1, 2, 2), (2, 3, 3, 5), (3, 16, 24, 40), (12, 16, 192, 640), (2, 3, 4, 8),
+                                   (1, 5, 5, 12)])
 def test_reflect_pad1(dev, shape):
     """layers.Conv3x3 pads by reflection (layers.py:121-138): bit-identical copy forward,
     deterministic gather backward, against ATen on the same device."""
@@ -661,7 +709,8 @@ def test_reflect_pad1(dev, shape):
 
 # ------------------------------------------------------------------ in-kernel tie-break noise
 @pytest.mark.parametrize("shape,flags,S", [((2, 33, 70), 0, 2), ((1, 64, 200), 2, 2), ((2, 17, 65), 0, 1),
-                                           ((4, 192, 640), 0, 2), ((12, 192, 640), 0, 2), ((8, 320, 1024), 0, 2)])
+                                           ((4, 192, 640), 0, 2), ((12, 192, 640), 0, 2), ((8, 320, 1024), 0, 2),
+                                           ((12, 192, 512), 0, 2)])
 def test_inkernel_noise_replayed_through_the_oracle(dev, shape, flags, S):
     """noise=None: the forward+backward kernel draws the tie-break noise of train.py:1023-1024
     itself (counter-based generator keyed by a per-call seed).  The draw is written out and
@@ -831,7 +880,8 @@ def test_fusion_module_fused_equals_op_by_op(dev):
 
 
 # ------------------------------------------------------------------ f4: step glue
-@pytest.mark.parametrize("shape", [(2, 5, 3, 2, 3), (3, 16, 7, 6, 20), (2, 4, 0, 5, 9), (12, 32, 64, 48, 160)])
+@pytest.mark.parametrize("shape", [(2, 5, 3, 2, 3), (3, 16, 7, 6, 20), (2, 4, 0, 5, 9), (12, 32, 64, 48, 160),
+                                   (2, 3, 5, 2, 4), (1, 6, 2, 3, 6)])      # smallest planes of the wide adjoint kernels
 def test_up2cat_pad_vs_torch(dev, shape):
     """Decoder stage glue (monodepth2.py:84-90 + layers.py:121-138, 225-228): one pass ==
     ReflectionPad2d(1)(cat([upsample_nearest(x), skip])), bit-identical forward; the gather
@@ -933,7 +983,8 @@ def test_bias_act_vs_torch(dev, act):
     from mono_vifi_amd import ops
     g = torch.Generator(device="cpu").manual_seed(9)
     for shape, with_res, one_slope in (((3, 5, 12, 20), False, False), ((2, 7, 9, 13), True, True),
-                                       ((4, 16, 96, 160), True, False), ((2, 3, 1, 1), False, False)):
+                                       ((4, 16, 96, 160), True, False), ((2, 3, 1, 1), False, False),
+                                       ((2, 3, 192, 640), True, False)):      # planes of several chunks (plane kernels)
         Nn, C = shape[0], shape[1]
         x = (2 * torch.randn(shape, generator=g)).to(dev)
         b = torch.randn(C, generator=g).to(dev)
@@ -971,6 +1022,12 @@ def test_bias_act_vs_torch(dev, act):
         (ops.bias_act(xa, ba, act, None, ra) * w).sum().backward()
         (stock(xb, bb, rb) * w).sum().backward()
         assert float((xa.grad - xb.grad).abs().max()) <= 1e-6 * max(1.0, float(xb.grad.abs().max())), (act, shape)
+        if act in ("elu", "relu"):
+            # no bias: the activation's adjoint alone (no partial sums) through the same kernels
+            xc_, xd_ = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+            (ops.bias_act(xc_, None, act) * w).sum().backward()
+            ((F.elu(xd_) if act == "elu" else F.relu(xd_)) * w).sum().backward()
+            assert float((xc_.grad - xd_.grad).abs().max()) <= 1e-6 * max(1.0, float(xd_.grad.abs().max())), (act, shape)
         assert float((ba.grad - bb.grad).abs().max()) <= 2e-5 * max(1.0, float(bb.grad.abs().max())), (act, shape)
         if r is not None:
             assert torch.equal(ra.grad, xa.grad) and float((ra.grad - rb.grad).abs().max()) <= 1e-6 * max(1.0, float(rb.grad.abs().max()))

@@ -129,6 +129,32 @@ def test_fullsize_against_reference(cfg):
     assert rel_err(out["grad_T"], g["grad_T"]) <= 5e-3
 
 
+@pytest.mark.parametrize("name", ["no_ssim", "avg", "noauto"])
+def test_fullsize_flag_sets_against_reference(name):
+    """The other flag sets at the BASELINE shape C2 (12 x 192 x 640): loss, sampled auto-mask and sampled
+    gradients the reference produced under --no_ssim / --avg_reprojection / --disable_automasking
+    (tests/golden/make_golden.py::g4_flag_sets; until round 4 these flags were reference-checked at 24x40 only)."""
+    from mono_vifi_amd import synthetic
+    g = load_golden("g4_flags_C2_" + name)
+    B, H, W = (int(v) for v in g["shape"])
+    flags = int(g["flags"][0]) * 1 + int(g["flags"][1]) * 2 + int(g["flags"][2]) * 4
+    use_mask = bool(int(g["use_mask"]))
+    inp = synthetic.unit_inputs(int(g["seed"]), B, H, W, with_mask=use_mask)
+    noise = np.ascontiguousarray(inp["noise"][:, :1] if flags & 2 else inp["noise"])
+    out = O.unit(inp["disp"], inp["tgt"], inp["src"], g["T"], inp["K"], inp["inv_K"], noise,
+                 inp["mask_rec"] if use_mask else None, flags, want_grads=True)
+    n = B * H * W
+    sidx = g["sample_idx"]
+    assert abs(out["loss"] - float(g["loss"])) <= 2e-6 * abs(float(g["loss"]))
+    if "auto_mask_s" in g:
+        assert np.array_equal(out["auto_mask"].reshape(n)[sidx], g["auto_mask_s"])
+        assert abs(out["auto_mask"].mean() - float(g["auto_mask_mean"])) <= 1e-6
+    assert_grad_close(out["grad_disp"].reshape(n)[sidx], g["grad_disp_s"], 1e-4, "grad_disp (sampled)")
+    gnorm = np.linalg.norm(out["grad_disp"].astype(np.float64))
+    assert abs(gnorm - float(g["grad_disp_norm"])) <= 1e-4 * float(g["grad_disp_norm"])
+    assert rel_err(out["grad_T"], g["grad_T"]) <= 5e-3      # the reference reduces grad_P in fp32
+
+
 @pytest.mark.parametrize("case", ["a", "b", "big"])
 def test_flow_warp(case):
     """f1: IFRNet.warp -- indices bit-exact, values 1e-6, grads 1e-5 vs the reference."""
@@ -256,6 +282,15 @@ def _pool_cases(rng):
     s[1, 1, 1] = np.nan
     s[0, 4:, :] = -np.inf
     cases.append(s)
+    # W % 4 == 0 (the device's wide kernels: two outputs / a 2 x 4 input block per lane) with NaN, -inf windows,
+    # ties, an odd height (wide forward, one-pixel-per-lane backward) and the narrowest wide plane
+    for (P, H, W) in [(2, 6, 8), (5, 7, 8), (1, 2, 4), (3, 10, 12)]:
+        w = np.round(rng.standard_normal((P, H, W)) * 2).astype(np.float32) / 2
+        w[0, min(2, H - 1), 3] = np.nan
+        w[0, 0, 0] = np.nan
+        w[P - 1, H - 2:, :] = -np.inf
+        w[P - 1, :, W - 1] = np.nan if W > 4 else w[P - 1, :, W - 1]
+        cases.append(w)
     return cases
 
 
