@@ -800,6 +800,7 @@ int finish_gT(const float *ws, const float *K, float *gT, int B, int S, int nblk
 
 // wide adjoint of the reflection pad (mvf_glue.hip)
 namespace mvf_glue {
+bool reflect_pad1_fwd_wide(const float *in, float *out, int planes, int H, int W, hipStream_t st);
 bool reflect_pad1_bwd_wide(const float *g_out, float *g_in, int planes, int H, int W, hipStream_t st);
 }
 
@@ -1063,6 +1064,7 @@ int mvf_reflect_pad1_fwd(const float *in, float *out, int planes, int H, int W, 
     if (!in || !out || H < 2 || W < 2 || planes > 65535 * RP_PL) return (int)hipErrorInvalidValue;
     const int n = (H + 2) * (W + 2);
     ProfScope ps(MVF_PROF_REFLECT_PAD_FWD, stream, 4LL * planes * ((int64_t)H * W + n));
+    if (mvf_glue::reflect_pad1_fwd_wide(in, out, planes, H, W, (hipStream_t)stream)) return hip_check_launch();
     hipLaunchKernelGGL(k_reflect_pad1_fwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((planes + RP_PL - 1) / RP_PL)),
                        dim3(NT), 0, (hipStream_t)stream, in, out, planes, H, W);
     return hip_check_launch();

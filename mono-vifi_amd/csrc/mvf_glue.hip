@@ -198,6 +198,73 @@ __global__ void __launch_bounds__(NT) k_up2cat_pad_bwd_x_w4(const float *__restr
             *reinterpret_cast<float2 *>(g_x + (size_t)(p0 + k) * n + (size_t)Y * w + 2 * j) =
                 make_float2((a[k].x + a[k].y) + (bq[k].x + bq[k].y), (a[k].z + a[k].w) + (bq[k].z + bq[k].w));
 }
+// forward counterpart: four consecutive columns of an unpadded row go out as one (4-byte aligned) 16-byte store
+// into the padded row; the lanes on the border also write the reflected copies (rows 0 / H+1, columns 0 / W+1)
+MVF_DEV void stg4u(float *__restrict__ p, float4 v)
+{
+    F4U t;
+    t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w;
+    *reinterpret_cast<F4U *>(p) = t;
+}
+MVF_DEV void pad_put4(float *__restrict__ dst, int y, int x0, float4 v, int H, int W)
+{
+    const int Wp = W + 2;
+    float *row = dst + (size_t)(y + 1) * Wp;
+    const bool first = x0 == 0, last = x0 + 4 == W;
+    stg4u(row + x0 + 1, v);
+    if (first) row[0] = v.y;
+    if (last) row[W + 1] = v.z;
+    const int ry = (y == 1) ? 0 : ((y == H - 2) ? H + 1 : -1);
+    if (ry >= 0) {
+        float *rr = dst + (size_t)ry * Wp;
+        stg4u(rr + x0 + 1, v);
+        if (first) rr[0] = v.y;
+        if (last) rr[W + 1] = v.z;
+    }
+}
+__global__ void __launch_bounds__(NT) k_pad1_fwd_w4(const float *__restrict__ in, float *__restrict__ out, int planes, int H,
+                                                    int W)
+{
+    const int W4 = W >> 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W4) return;
+    const int y = i / W4, x0 = (i - y * W4) * 4;
+    const size_t PP = (size_t)(H + 2) * (W + 2), n = (size_t)H * W;
+    const int p0 = blockIdx.y * PADW_PL;
+    float4 v[PADW_PL];
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k)
+        v[k] = *reinterpret_cast<const float4 *>(in + (size_t)min(p0 + k, planes - 1) * n + (size_t)y * W + x0);
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k)
+        if (p0 + k < planes) pad_put4(out + (size_t)(p0 + k) * PP, y, x0, v[k], H, W);
+}
+// grid (H * W/4 blocks, chunks of the C1 + C2 output planes, B)
+__global__ void __launch_bounds__(NT) k_up2cat_pad_fwd_w4(const float *__restrict__ x, const float *__restrict__ skip,
+                                                          float *__restrict__ out, int C1, int C2, int h, int w)
+{
+    const int H = 2 * h, W = 2 * w, W4 = W >> 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W4) return;
+    const int y = i / W4, j = i - y * W4, x0 = 4 * j;
+    const int b = blockIdx.z, C = C1 + C2, c0 = blockIdx.y * PADW_PL;
+    const size_t PP = (size_t)(H + 2) * (W + 2), n1 = (size_t)h * w, n2 = (size_t)H * W;
+    float4 v[PADW_PL];
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k) {
+        const int c = min(c0 + k, C - 1);
+        if (c < C1) {
+            const float2 t = *reinterpret_cast<const float2 *>(x + ((size_t)b * C1 + c) * n1 + (size_t)(y >> 1) * w + 2 * j);
+            v[k] = make_float4(t.x, t.x, t.y, t.y);
+        } else {
+            v[k] = *reinterpret_cast<const float4 *>(skip + ((size_t)b * C2 + (c - C1)) * n2 + (size_t)y * W + x0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k)
+        if (c0 + k < C) pad_put4(out + ((size_t)b * C + c0 + k) * PP, y, x0, v[k], H, W);
+}
+
 static bool pad_wide_ok(const void *padded, const void *plain, int H, int W)
 {
     return (W & 3) == 0 && W >= 8 && H >= 4 && (((uintptr_t)plain) & 15) == 0 && (((uintptr_t)padded) & 3) == 0 &&
@@ -993,6 +1060,13 @@ __global__ void __launch_bounds__(NT) k_jitter_apply(const float *__restrict__ i
 
 // wide adjoint of ReflectionPad2d(1) for mvf_reflect_pad1_bwd (mvf_geom.hip); false when the shape needs the narrow form
 namespace mvf_glue {
+bool reflect_pad1_fwd_wide(const float *in, float *out, int planes, int H, int W, hipStream_t st)
+{
+    if (!pad_wide_ok(out, in, H, W) || planes > 65535 * PADW_PL) return false;
+    hipLaunchKernelGGL(k_pad1_fwd_w4, dim3((unsigned)((H * (W / 4) + NT - 1) / NT), (unsigned)((planes + PADW_PL - 1) / PADW_PL)),
+                       dim3(NT), 0, st, in, out, planes, H, W);
+    return true;
+}
 bool reflect_pad1_bwd_wide(const float *g_out, float *g_in, int planes, int H, int W, hipStream_t st)
 {
     if (!pad_wide_ok(g_out, g_in, H, W) || planes > 65535 * PADW_PL) return false;
@@ -1012,6 +1086,12 @@ int mvf_up2cat_pad_fwd(const float *x, const float *skip, float *out, int B, int
     const int n = (2 * h + 2) * (2 * w + 2), C = C1 + C2;
     // algorithmic bytes: x and skip read once, the padded concatenation written once
     ProfScope ps(MVF_PROF_UP2CAT_FWD, stream, 4LL * B * ((int64_t)C1 * h * w + (int64_t)C2 * 4 * h * w + (int64_t)C * n));
+    if (pad_wide_ok(out, C2 > 0 ? skip : x, 2 * h, 2 * w) && (((uintptr_t)x) & 7) == 0 && (C + PADW_PL - 1) / PADW_PL <= 65535 &&
+        B <= 65535) {
+        hipLaunchKernelGGL(k_up2cat_pad_fwd_w4, dim3((unsigned)((2 * h * (2 * w / 4) + NT - 1) / NT), (unsigned)((C + PADW_PL - 1) / PADW_PL), (unsigned)B),
+                           dim3(NT), 0, (hipStream_t)stream, x, skip, out, C1, C2, h, w);
+        return hip_check_launch();
+    }
     hipLaunchKernelGGL(k_up2cat_pad_fwd, dim3((unsigned)((n + NT - 1) / NT), (unsigned)((C + PL - 1) / PL), (unsigned)B),
                        dim3(NT), 0, (hipStream_t)stream, x, skip, out, C1, C2, h, w);
     return hip_check_launch();
