@@ -98,12 +98,19 @@ MVF_DEV float clip_coord(float v, float hi)
     return __builtin_amdgcn_fmed3f(v, 0.0f, hi);
 }
 
+MVF_DEV Tap tap_of_ixy(float ix, float iy, int H, int W);
 MVF_DEV Tap tap_of(float gx, float gy, int H, int W)
 {
-    Tap t;
     float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     float ix = ((gx + 1.0f) / 2.0f) * wm1;
     float iy = ((gy + 1.0f) / 2.0f) * hm1;
+    return tap_of_ixy(ix, iy, H, W);
+}
+// the same tap from the un-normalised sample position (ix, iy)
+MVF_DEV Tap tap_of_ixy(float ix, float iy, int H, int W)
+{
+    Tap t;
+    float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     t.inx = (ix > 0.0f) && (ix < wm1);
     t.iny = (iy > 0.0f) && (iy < hm1);
     ix = clip_coord(ix, wm1);
@@ -364,6 +371,7 @@ MVF_DEV float div3(float x)
 #endif
 
 // packed pairs: two IEEE fp32 operations per lane per instruction (v_pk_*_f32)
+#ifndef MVF_SCALAR_F2
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 MVF_DEV f2 f2s(float a)
@@ -378,6 +386,28 @@ MVF_DEV f2 mk2(float a, float b)
 }
 MVF_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 MVF_DEV f2 pk_abs(f2 a) { return __builtin_elementwise_abs(a); }
+#else
+// Experiment (round 4): the same pair type as two independent scalars.  On gfx950 a v_pk_*_f32 instruction costs
+// the issue time of two plain ones (tools/valu_ubench.hip: 1.8-2.2 ns vs 1.0), so packing buys nothing by itself
+// and pays register moves wherever a pair has to be assembled from scalars; this form lets the compiler keep
+// the halves wherever they are.  Same IEEE operations per half: exact mode is untouched.
+struct alignas(8) f2 {
+    float x, y;
+};
+MVF_DEV f2 f2s(float a) { return f2{a, a}; }
+MVF_DEV f2 mk2(float a, float b) { return f2{a, b}; }
+MVF_DEV f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+MVF_DEV f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+MVF_DEV f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+MVF_DEV f2 operator/(f2 a, f2 b) { return f2{a.x / b.x, a.y / b.y}; }
+MVF_DEV f2 operator-(f2 a) { return f2{-a.x, -a.y}; }
+MVF_DEV f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
+MVF_DEV f2 operator*(f2 a, float b) { return f2{a.x * b, a.y * b}; }
+MVF_DEV f2 operator/(f2 a, float b) { return f2{a.x / b, a.y / b}; }
+MVF_DEV f2 &operator+=(f2 &a, f2 b) { a.x += b.x; a.y += b.y; return a; }
+MVF_DEV f2 pk_fma(f2 a, f2 b, f2 c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+MVF_DEV f2 pk_abs(f2 a) { return f2{fabsf(a.x), fabsf(a.y)}; }
+#endif
 #ifdef MVF_FAST_SSIM
 MVF_DEV f2 div9(f2 x) { return x * f2s(1.0f / 9.0f); }
 MVF_DEV f2 div3(f2 x) { return x * f2s(1.0f / 3.0f); }

@@ -400,6 +400,91 @@ MVF_DEV void stage_first(float *__restrict__ tgtP, float *__restrict__ dispP, f2
     }
 }
 
+// ---- the same prologues for INNER tiles, two pixels per load (round 4) -------------------------------------
+// A plane that lies inside the image has an even origin column (px0 = bx * (TW - 2) - 2) and an even row stride,
+// so a plane row is PW / 2 aligned 8-byte pairs: half the address arithmetic, half the load and LDS-store
+// instructions of the element-wise form above (staging was 141 VALU instructions per output pixel and 16 % of the
+// unit kernel's time: profiles/r04_unit_kernel_phase_budget.txt), and only the first wave has a second round.
+constexpr int PW2 = PW / 2;
+constexpr int NSTAGE2 = (PH * PW2 + NT - 1) / NT;
+static_assert(PW % 2 == 0 && LDW % 2 == 0 && PLANE % 2 == 0, "8-byte pairs of a plane row");
+struct StagePos2 {
+    unsigned o[NSTAGE2];     // byte offset of the pair inside one [H,W] plane
+    int e[NSTAGE2];          // LDS plane element of its first pixel
+    bool ok[NSTAGE2];
+};
+MVF_DEV StagePos2 stage_pos2(int W, int py0, int px0)
+{
+    StagePos2 p;
+    const unsigned base = plane_off4(py0, px0, W);
+#pragma unroll
+    for (int it = 0; it < NSTAGE2; ++it) {
+        const int idx = (int)threadIdx.x + it * NT;
+        p.ok[it] = idx < PH * PW2;
+        const int ic = min(idx, PH * PW2 - 1);
+        const int r = ic / PW2, c2 = ic - r * PW2;
+        p.o[it] = base + plane_off4(r, 2 * c2, W);
+        p.e[it] = r * LDW + 2 * c2;
+    }
+    return p;
+}
+// rounds after the first only exist for the leading waves (wave-uniform)
+MVF_DEV bool stage2_round_live(int it) { return ((int)(threadIdx.x & ~(kWave - 1)) + it * NT) < PH * PW2; }
+
+MVF_DEV void stage_first_inner(float *__restrict__ tgtP, float *__restrict__ dispP, f2 *__restrict__ pairP,
+                               const float *__restrict__ tgt, const float *__restrict__ disp,
+                               const float *__restrict__ im0, const float *__restrict__ im1, size_t N, int W, int py0,
+                               int px0)
+{
+    const StagePos2 p = stage_pos2(W, py0, px0);
+    float2 vt[NSTAGE2][3], vd[NSTAGE2], va[NSTAGE2][3], vb[NSTAGE2][3];
+#pragma unroll
+    for (int it = 0; it < NSTAGE2; ++it) {
+        if (it > 0 && !stage2_round_live(it)) break;
+        const unsigned o = p.o[it];
+        vt[it][0] = ldg_f2_at(tgt, o); vt[it][1] = ldg_f2_at(tgt + N, o); vt[it][2] = ldg_f2_at(tgt + 2 * N, o);
+        vd[it] = ldg_f2_at(disp, o);
+        va[it][0] = ldg_f2_at(im0, o); va[it][1] = ldg_f2_at(im0 + N, o); va[it][2] = ldg_f2_at(im0 + 2 * N, o);
+        vb[it][0] = ldg_f2_at(im1, o); vb[it][1] = ldg_f2_at(im1 + N, o); vb[it][2] = ldg_f2_at(im1 + 2 * N, o);
+    }
+#pragma unroll
+    for (int it = 0; it < NSTAGE2; ++it) {
+        if (it > 0 && !stage2_round_live(it)) break;
+        if (!p.ok[it]) continue;
+        const int e = p.e[it];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            *reinterpret_cast<float2 *>(tgtP + c * PLANE + e) = vt[it][c];
+            *reinterpret_cast<float4 *>(pairP + c * PPLANE + e) =
+                make_float4(va[it][c].x, vb[it][c].x, va[it][c].y, vb[it][c].y);
+        }
+        *reinterpret_cast<float2 *>(dispP + e) = vd[it];
+    }
+}
+// target + disparity only (units that take their identity maps from another unit, or run without auto-masking)
+MVF_DEV void stage_tgt_disp_inner(float *__restrict__ tgtP, float *__restrict__ dispP, const float *__restrict__ tgt,
+                                  const float *__restrict__ disp, size_t N, int W, int py0, int px0)
+{
+    const StagePos2 p = stage_pos2(W, py0, px0);
+    float2 vt[NSTAGE2][3], vd[NSTAGE2];
+#pragma unroll
+    for (int it = 0; it < NSTAGE2; ++it) {
+        if (it > 0 && !stage2_round_live(it)) break;
+        const unsigned o = p.o[it];
+        vt[it][0] = ldg_f2_at(tgt, o); vt[it][1] = ldg_f2_at(tgt + N, o); vt[it][2] = ldg_f2_at(tgt + 2 * N, o);
+        vd[it] = ldg_f2_at(disp, o);
+    }
+#pragma unroll
+    for (int it = 0; it < NSTAGE2; ++it) {
+        if (it > 0 && !stage2_round_live(it)) break;
+        if (!p.ok[it]) continue;
+        const int e = p.e[it];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) *reinterpret_cast<float2 *>(tgtP + c * PLANE + e) = vt[it][c];
+        *reinterpret_cast<float2 *>(dispP + e) = vd[it];
+    }
+}
+
 // generate_images_pred for TWO sources at one pixel: the ray, depth and camera point are
 // shared, the projection runs packed (lane 0 = source a, lane 1 = source b).
 struct WarpPair {
@@ -455,10 +540,22 @@ MVF_DEV WarpPair warp_point_pair(float disp, const float *__restrict__ iK, const
         un = w.u / f2s(wm1);
         vn = w.v / f2s(hm1);
     }
+#ifndef MVF_NO_FOLD_GRID
+    // grid_sample un-normalises what Project3D normalised: ix = (((un - 0.5) * 2 + 1) / 2) * (W - 1)
+    // (layers.py:219-221, then ATen's grid_sampler_unnormalize).  Scaling by 2 is exact and rounding commutes with
+    // it, so RN(2 t + 1) / 2 == RN(t + 0.5) bit for bit (t = RN(un - 0.5) is at most ~0.5 in magnitude: no overflow;
+    // and where t + 0.5 falls below the normal range it is an exact difference of two nearby floats): two packed
+    // operations less per coordinate pair, same sampling position -- the index SHA-256 tests pin it.
+    const f2 ixp = ((un - f2s(0.5f)) + f2s(0.5f)) * f2s(wm1);
+    const f2 iyp = ((vn - f2s(0.5f)) + f2s(0.5f)) * f2s(hm1);
+    w.ta = tap_of_ixy(ixp.x, iyp.x, H, W);
+    w.tb = tap_of_ixy(ixp.y, iyp.y, H, W);
+#else
     f2 gx = (un - f2s(0.5f)) * 2.0f;
     f2 gy = (vn - f2s(0.5f)) * 2.0f;
     w.ta = tap_of(gx.x, gy.x, H, W);
     w.tb = tap_of(gx.y, gy.y, H, W);
+#endif
     return w;
 }
 

@@ -86,6 +86,7 @@ struct FbArgs {
     double *img_ws;       // [U][B][NIMG] per-image folded loss terms
     int *tickets;         // [U] one per unit (k_units_finish); zero on entry, zero on exit
     int nunits, flags, B, H, W, tiles_x, tiles_y;
+    int flags_int;        // bit 0: every image base / stride of the launch is 8-byte aligned (pair staging allowed)
     float smoothness, min_disp, range, eps;
 };
 
@@ -189,6 +190,23 @@ MVF_DEV void tstat_row(const Row6 &y, bool first, TStat2 &t)
 }
 // (mu_y, E[y*y]) of pixel j out of the pixel-packed means
 MVF_DEV f2 tstat_of(const f2 tm[PX], int j) { return j == 0 ? mk2(tm[0].x, tm[1].x) : mk2(tm[0].y, tm[1].y); }
+
+// sign(v) in {-1, 0, +1} without compares: v * 2^127 * 2^127 is +-inf for every non-zero v (the smallest
+// subnormal times 2^254 is 2^105), 0 for a zero and NaN for a NaN; v_med3_f32(., -1, 1) clamps that to +-1 / 0
+// (a NaN operand yields the minimum of the others: -1 -- the compare form gave 0; a NaN difference only arises from
+// a NaN image, which poisons the loss anyway).  Two full-rate multiplies + one half-rate op instead of two compares
+// and two selects (tools/valu_ubench.hip: 3.7 vs 6.8 ns of issue time per value).
+#ifndef MVF_FB_SIGN_MED3
+#define MVF_FB_SIGN_MED3 1
+#endif
+MVF_DEV float sign_of(float v)
+{
+#if MVF_FB_SIGN_MED3
+    return __builtin_amdgcn_fmed3f((v * 0x1p127f) * 0x1p127f, -1.0f, 1.0f);
+#else
+    return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);
+#endif
+}
 
 struct Stats4X {
     f2 sx[PX], sxx[PX], sxy[PX];
@@ -489,6 +507,21 @@ MVF_DEV void warp_pair_into_lds_fb(const WarpCtx &k, int first)
     }
 }
 
+// ---- static analysis build (tools/isa_cost.py; never shipped) -----------------------------------------------
+// -DMVF_PHASE_MARKERS puts a comment line into the ISA at every phase boundary; -DMVF_ANALYSIS=k freezes the
+// run-time switches to one hot configuration so that the compiler drops the branches that configuration never
+// takes and the static instruction stream IS the executed one (phases are straight-line code, loops unrolled):
+//   1 = single-frame launch (auto-masking, identity candidates evaluated, in-kernel noise, no mask), inner tile
+//   2 = multi-frame launch (identity maps handed over), inner tile      3 = affine launch (as 1 + mask_rec)
+#ifdef MVF_PHASE_MARKERS
+#define MVF_PHASE(name) asm volatile("; MVF_PHASE " name ::: "memory")
+#else
+#define MVF_PHASE(name)
+#endif
+#ifndef MVF_ANALYSIS
+#define MVF_ANALYSIS 0
+#endif
+
 // =============================================================================== the kernel
 template <int S, bool AVG>     // AVG: --avg_reprojection (both sources carry gradient)
 __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
@@ -512,9 +545,13 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     const size_t N = (size_t)H * W;
     const int cy0 = tid.by * OH - 1, cx0 = tid.bx * OW - 1;   // region origin
     const int py0 = cy0 - 1, px0 = cx0 - 1;                   // plane origin
+#if MVF_ANALYSIS
+    constexpr bool no_ssim = false, automask = true;
+#else
     const bool no_ssim = a.flags & MVF_NO_SSIM;
-    constexpr bool avg = AVG;
     const bool automask = !(a.flags & MVF_NO_AUTOMASK);
+#endif
+    constexpr bool avg = AVG;
     const int n_id = automask ? (avg ? 1 : S) : 0;
     constexpr bool hasb = S > 1;
     constexpr int kb = hasb ? 1 : 0;
@@ -525,7 +562,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     const float *sa = uniform_ptr(u.src0 + (size_t)b * u.src0_stride);
     const float *sb = hasb ? uniform_ptr(u.src1 + (size_t)b * u.src1_stride) : sa;
     const float *iK = u.invK + b * 16;
+#if MVF_ANALYSIS
+    constexpr bool ident_given = (MVF_ANALYSIS == 2);
+#else
     const bool ident_given = automask && (u.ident_in != nullptr);
+#endif
 
     if (threadIdx.x == 0) {
         float m = 0.0f;
@@ -548,13 +589,27 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // ---- 1: target, disparity (and the identity pair) -> LDS
     // tiles whose staged plane lies inside the image need no reflect / clamp mapping of the
     // coordinates they stage and warp (scalar branch; 240 of 308 tiles at 640x192)
+#if MVF_ANALYSIS
+    constexpr bool inner = true;
+#else
     const bool inner = (py0 >= 0) && (px0 >= 0) && (py0 + PH <= H) && (px0 + PW <= W);
+#endif
+    MVF_PHASE("1_stage");
 #ifndef MVF_ABL_NOSTAGE   // timing ablation: nothing staged (the planes keep what the previous workgroup left there)
+#ifndef MVF_FB_STAGE2
+#define MVF_FB_STAGE2 1     // inner tiles staged as 8-byte pixel pairs (0: one pixel per load)
+#endif
+    // (the pair form needs 8-byte aligned image bases: checked by the launcher, which clears FB_PAIR_OK otherwise)
+    const bool pairs_ok = MVF_FB_STAGE2 && inner && (a.flags_int & 1);
     if (automask && !ident_given) {
-        stage_first(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, H, W, py0, px0, inner);
+        if (pairs_ok) stage_first_inner(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, W, py0, px0);
+        else stage_first(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, H, W, py0, px0, inner);
     } else {
-        stage_planes3(tgtP, tgt_b, N, H, W, py0, px0, inner);
-        stage_plane(dispP, disp_b, H, W, py0, px0, inner);
+        if (pairs_ok) stage_tgt_disp_inner(tgtP, dispP, tgt_b, disp_b, N, W, py0, px0);
+        else {
+            stage_planes3(tgtP, tgt_b, N, H, W, py0, px0, inner);
+            stage_plane(dispP, disp_b, H, W, py0, px0, inner);
+        }
     }
 #endif
     __syncthreads();
@@ -569,14 +624,15 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         k.iK = iK; k.P2 = P2;
         k.H = H; k.W = W; k.py0 = py0; k.px0 = px0; k.oy0 = cy0 + 1; k.ox0 = cx0 + 1;
         k.min_disp = a.min_disp; k.range = a.range; k.eps = a.eps;
-        k.idx_a = u.idx_xy ? u.idx_xy + ((size_t)b) * N * 2 : nullptr;
-        k.idx_b = u.idx_xy ? u.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
+        k.idx_a = (!MVF_ANALYSIS && u.idx_xy) ? u.idx_xy + ((size_t)b) * N * 2 : nullptr;
+        k.idx_b = (!MVF_ANALYSIS && u.idx_xy) ? u.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
         k.inner = inner;
     }
     TapStash stash[2] = {};
     wk_ctx.stash = stash;
 
     // ---- 2: identity candidates of every region pixel
+    MVF_PHASE("2_identity");
     f2 vid[PX];
 #pragma unroll
     for (int j = 0; j < PX; ++j) vid[j] = f2s(0.0f);
@@ -611,6 +667,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     }
 
     // ---- 3: fused warp of the source pair
+    MVF_PHASE("3_warp");
 #ifdef MVF_ABL_NOWARP    // timing ablation: the raw sources instead of the warped pair
     stage_pair3(pairP, wk_ctx.sa, wk_ctx.sb, N, H, W, py0, px0);
     if (false)
@@ -621,6 +678,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // ---- 4: warped candidates; the SSIM partials of the three channels stay in registers
     // (channel loops unrolled: round 2 rolled them and rotated the partials through three slots,
     // 24 register moves per channel here and again in phase 6)
+    MVF_PHASE("4_ssim_warped");
     f2 pm[3][PX], px2[3][PX], pg[3][PX];      // d/d mu_x, 2 d/d E[xx], d/d E[xy]
     f2 vw[PX];
     {
@@ -672,9 +730,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // mask and tie-break noise of this lane's region pixels.  Fetched / drawn here rather than in
     // the prologue: six registers less across the warp and SSIM phases (128-VGPR budget of 4
     // waves per SIMD); with 4 workgroups per CU the one exposed load latency is covered
+    MVF_PHASE("5a_mask_noise");
     float mraw[PX];            // mask value (1 without a mask), 0 outside the image
     f2 nz[PX];
+#if MVF_ANALYSIS
+    const float *mask_b = (MVF_ANALYSIS == 3) ? uniform_ptr(u.mask + (size_t)b * u.mask_stride) : nullptr;
+#else
     const float *mask_b = u.mask ? uniform_ptr(u.mask + (size_t)b * u.mask_stride) : nullptr;
+#endif
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         const int x = x0 + j;
@@ -687,13 +750,13 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #else
         if (automask && in) {
 #endif
-            if (u.noise) {
+            if (!MVF_ANALYSIS && u.noise) {
                 const float *nb = uniform_ptr(u.noise + (size_t)b * (avg ? 1 : S) * N);
                 if (avg) nz[j] = f2s(ldg_at(nb, pix4));
                 else nz[j] = mk2(ldg_at(nb, pix4), hasb ? ldg_at(nb + N, pix4) : 0.0f);
             } else {
                 nz[j] = normal_pair(u.seed0, u.seed1, (uint32_t)b * (uint32_t)N + (pix4 >> 2));
-                if (u.noise_out) {
+                if (!MVF_ANALYSIS && u.noise_out) {
                     float *nb = uniform_ptr(u.noise_out + (size_t)b * (avg ? 1 : S) * N);
                     stg_at(nb, pix4, nz[j].x);
                     if (!avg && hasb) stg_at(nb + N, pix4, nz[j].y);
@@ -703,6 +766,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     }
 
     // ---- 5: min / argmin / mask / outputs (reference: train.py:1010-1043)
+    MVF_PHASE("5b_argmin_outputs");
     f2 wk[PX];                 // adjoint weight of the two warped candidates
     float fb_photo = 0.0f;
 #ifdef MVF_ABL_NO5       // timing ablation: no min / argmin / mask / outputs (every candidate value stays live)
@@ -755,9 +819,9 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         const bool outp = row_out && (col >= 1) && (col <= OW) && in;
         if (outp) {
             if (u.argmin_out) stg_u8_at(uniform_ptr(u.argmin_out + (size_t)b * N), pix4 >> 2, (uint8_t)sel);
-            if (u.auto_mask_out) stg_at(uniform_ptr(u.auto_mask_out + (size_t)b * N), pix4, (bi > n_id - 1) ? 1.0f : 0.0f);
-            if (u.to_opt_out) stg_at(uniform_ptr(u.to_opt_out + (size_t)b * N), pix4, best);
-            if (u.ident_out && automask)
+            if (!MVF_ANALYSIS && u.auto_mask_out) stg_at(uniform_ptr(u.auto_mask_out + (size_t)b * N), pix4, (bi > n_id - 1) ? 1.0f : 0.0f);
+            if (!MVF_ANALYSIS && u.to_opt_out) stg_at(uniform_ptr(u.to_opt_out + (size_t)b * N), pix4, best);
+            if ((MVF_ANALYSIS ? MVF_ANALYSIS == 1 : (u.ident_out != nullptr)) && automask)
                 stg_f2_at(uniform_ptr(u.ident_out + (size_t)b * N * 2), pix4 * 2u, make_float2(vid[j].x, vid[j].y));
             fb_photo += best;
         }
@@ -778,6 +842,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // and would only reach the region's border columns, which are never outputs).  The planes then
     // hold row sums, and the vertical step reads two rows instead of nine row segments.
     // Reflect-pad multiplicities only exist next to the image border (rows 1, H-2, cols 1, W-2).
+    MVF_PHASE("6_ssim_adjoint");
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
     float mlx[PX], mrx[PX];
 #pragma unroll
@@ -785,7 +850,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         mlx[j] = (x0 + j == 1) ? 2.0f : 1.0f;
         mrx[j] = (x0 + j == W - 2) ? 2.0f : 1.0f;
     }
-    const bool col_border = (cx0 <= 1) || (cx0 + TW >= W - 1);          // workgroup-uniform
+    const bool col_border = !MVF_ANALYSIS && ((cx0 <= 1) || (cx0 + TW >= W - 1));          // workgroup-uniform
     // DPP row shifts inside the 16-lane rows (= the 16 column segments of a region row).  The empty
     // asm pins each 32-bit move: without it hipcc 7.2 folds the two halves of a pair into ONE move
     // and broadcasts it (observed in the ISA: v_mov_b32_dpp + op_sel_hi:[0,1]).
@@ -855,9 +920,8 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         for (int j = 0; j < PX; ++j) {
             // L1 term: d|t-p|/dp = -sign(t-p), channel mean
             f2 df = f2s(yq[j]) - xq[j];
-            f2 sg = mk2((df.x > 0.0f) ? -1.0f : ((df.x < 0.0f) ? 1.0f : 0.0f),
-                        (df.y > 0.0f) ? -1.0f : ((df.y < 0.0f) ? 1.0f : 0.0f));
-            gw[j] = wk[j] * ((no_ssim ? 1.0f : 0.15f) * (1.0f / 3.0f)) * sg;
+            f2 sg = mk2(sign_of(df.x), sign_of(df.y));      // d|t - p| / dp = -sign(t - p): the minus sits in the constant
+            gw[j] = wk[j] * (-(no_ssim ? 1.0f : 0.15f) * (1.0f / 3.0f)) * sg;
         }
 #if defined(MVF_ABL_NOGATHER) || defined(MVF_ABL_NO6H)
         if (false) {
@@ -897,6 +961,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // Lanes now walk the region linearly (position p = tid + k*256, TW per row): neighbouring
     // lanes handle neighbouring pixels, so the bilinear taps of a wave fall into a few cache
     // lines (with the owner mapping a wave's taps were PX pixels apart per lane).
+    MVF_PHASE("7_8_adjoint_smooth");
     load_pose_pair(sh, 0, kb, P2);
     float *gd_b = uniform_ptr(u.g_disp + (size_t)b * u.g_stride);
     f2 accP[12];
@@ -1072,7 +1137,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                         fabsf(t0[2 * PLANE] - t0[2 * PLANE + o])) * (1.0f / 3.0f);
             return __expf(-gi);
         };
-        auto sgn = [](float v) { return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f); };
+        auto sgn = [](float v) { return sign_of(v); };
         // only the SIGN of differences of normalised disparities is needed for the gradient:
         // dividing by the positive per-image constant cannot change it
         const float nd = dc[0];
@@ -1099,6 +1164,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     }
 
     // ---- one reduction for all tile partials: grad_P of both sources, photo, smoothness sums
+    MVF_PHASE("9_reduce");
     const size_t ntiles = (size_t)a.tiles_x * a.tiles_y;
     const size_t tile = (size_t)tid.by * a.tiles_x + tid.bx;
     const size_t UB = (size_t)a.nunits * a.B;
@@ -1320,6 +1386,7 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
     a.gp_ws = workspace + l.gp;
     a.img_ws = reinterpret_cast<double *>(workspace + l.img);
     a.tickets = tickets;
+    bool pair_ok = (W % 2) == 0;
     for (int i = 0; i < n_units; ++i) {
         const mvf_unit_desc &d = units[i];
         if (!d.disp || !d.tgt || !d.src[0] || (S > 1 && !d.src[1]) || !d.T || !d.K || !d.inv_K ||
@@ -1335,6 +1402,8 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
         u.src1_stride = S > 1 ? (d.src_stride[1] ? (size_t)d.src_stride[1] : (size_t)3 * N) : u.src0_stride;
         u.mask_stride = d.mask_stride ? (size_t)d.mask_stride : (size_t)N;
         u.g_stride = d.g_stride ? (size_t)d.g_stride : (size_t)N;
+        pair_ok = pair_ok && ((((uintptr_t)u.disp | (uintptr_t)u.tgt | (uintptr_t)u.src0 | (uintptr_t)u.src1) & 7) == 0) &&
+                  (((u.disp_stride | u.tgt_stride | u.src0_stride | u.src1_stride) & 1) == 0) && ((N & 1) == 0);
         u.g_disp = d.g_disp_raw; u.g_T = d.g_T_raw; u.loss = d.loss; u.stats = d.stats;
         u.argmin_out = d.argmin; u.auto_mask_out = d.auto_mask; u.to_opt_out = d.to_opt;
         u.noise_out = d.noise_out; u.idx_xy = d.idx_xy;
@@ -1346,6 +1415,7 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
             mvf_photo::launch_disp_mean(d.disp, u.disp_stride, mw, B, N, st);
         }
     }
+    a.flags_int = pair_ok ? 1 : 0;
     {
         // launch kind for the per-type medians of bench.py: identity maps taken over / mask supplied / neither
         int tag = MVF_TAG_SINGLE_FRAME;
