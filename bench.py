@@ -355,10 +355,10 @@ class HotPathStep:
                             K=u["K"], inv_K=u["inv_K"], mask_rec=u["mask"],
                             ident=(idents[i] if (g == 1 and idents is not None) else None))
                        for i, u in enumerate(us)]
-            losses, ids, _ = self.l.compute_units(entries, want_ident=(g == 0 and self.share))
+            group_sum, ids, _ = self.l.compute_units(entries, want_ident=(g == 0 and self.share), want_sum=True)
             if g == 0:
                 idents = ids
-            total = losses.sum() if total is None else total + losses.sum()
+            total = group_sum if total is None else total + group_sum
         total.backward()
         return total
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 11
+#define MVF_ABI_VERSION 12
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -226,6 +226,10 @@ typedef struct mvf_unit_desc {
     float *auto_mask, *to_opt;                        /* nullable [B,1,H,W] contiguous */
     int32_t *idx_xy;                                  /* nullable [S,B,H,W,2] */
     float *noise_out;                                 /* nullable, layout of noise */
+    float *loss_sum;                                  /* nullable [1]; read from units[0] only: the SUM of loss[0] over
+                                                         the units of the launch (unit order), written by the last
+                                                         finishing block -- the `losses.sum()` of a group of
+                                                         process_batch (train.py:760, 812, 882) without a launch */
 } mvf_unit_desc;
 MVF_API size_t mvf_units_workspace_floats(int n_units, int B, int H, int W);
 MVF_API size_t mvf_units_ticket_ints(int n_units, int B);
@@ -233,12 +237,14 @@ MVF_API int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int
                      float min_disp, float range, float eps, float *workspace, int32_t *tickets, int B,
                      int H, int W, void *stream);
 /* backward() of mvf_units_fwdbwd, one launch for the units' grad_disp and grad_T (formula below);
- * g_loss: one device scalar per unit. */
+ * upstream gradient of a unit = *g_loss (device scalar, nullable) + *g_sum (device scalar, nullable: the gradient
+ * of the launch's loss_sum); at least one of the two. */
 typedef struct mvf_unit_scale_desc {
     const float *g_disp_raw; int64_t in_stride;
     const float *g_T_raw, *stats, *g_loss;
     float *g_disp;           int64_t out_stride;
     float *g_T;
+    const float *g_sum;
 } mvf_unit_scale_desc;
 MVF_API int mvf_units_fwdbwd_scale(const mvf_unit_scale_desc *units, int n_units, float smoothness, int B,
                            int S, int H, int W, void *stream);

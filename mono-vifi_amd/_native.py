@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -35,7 +35,7 @@ class UnitDesc(C.Structure):
         ("ident_out", _vp), ("loss", _vp), ("stats", _vp),
         ("g_disp_raw", _vp), ("g_stride", _i64),
         ("g_T_raw", _vp), ("argmin", _vp), ("auto_mask", _vp), ("to_opt", _vp), ("idx_xy", _vp),
-        ("noise_out", _vp),
+        ("noise_out", _vp), ("loss_sum", _vp),
     ]
 
 
@@ -45,7 +45,7 @@ class UnitScaleDesc(C.Structure):
         ("g_disp_raw", _vp), ("in_stride", _i64),
         ("g_T_raw", _vp), ("stats", _vp), ("g_loss", _vp),
         ("g_disp", _vp), ("out_stride", _i64),
-        ("g_T", _vp),
+        ("g_T", _vp), ("g_sum", _vp),
     ]
 
 

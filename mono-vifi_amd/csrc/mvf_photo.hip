@@ -270,6 +270,33 @@ __global__ void __launch_bounds__(256) k_disp_mean(const float *__restrict__ dis
     if (threadIdx.x == 0) ws[b * NMEAN + chunk] = r;
 }
 
+// the same partials for up to MVF_MAX_UNITS disparity tensors in ONE launch (grid.z = tensor): the units of a
+// batched launch each needed a k_disp_mean launch of their own when no disparity head supplied the partials
+struct DispMeanMany {
+    const float *disp[MVF_MAX_UNITS];
+    size_t stride[MVF_MAX_UNITS];
+    float *ws[MVF_MAX_UNITS];
+};
+__global__ void __launch_bounds__(256) k_disp_mean_many(DispMeanMany j, int N)
+{
+    __shared__ float scratch[4];
+    const int b = blockIdx.y, chunk = blockIdx.x, u = blockIdx.z;
+    const int per = (N + NMEAN - 1) / NMEAN;
+    const int lo = chunk * per, hi = min(lo + per, N);
+    const float *d = j.disp[u] + (size_t)b * j.stride[u];
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int i = lo + threadIdx.x;
+    for (; i + 3 * 256 < hi; i += 4 * 256) {
+        s0 += d[i];
+        s1 += d[i + 256];
+        s2 += d[i + 512];
+        s3 += d[i + 768];
+    }
+    for (; i < hi; i += 256) s0 += d[i];
+    const float r = block_sum<256>((s0 + s1) + (s2 + s3), scratch);
+    if (threadIdx.x == 0) j.ws[u][b * NMEAN + chunk] = r;
+}
+
 // fold tile partials: loss[0..2], stats[B][4] = {mean, den, sx_b/Nx, sy_b/Ny}.
 // One wave per image (fixed order inside the wave), images of a batch folded in order.
 __global__ void __launch_bounds__(1024) k_finish_fwd(const float *__restrict__ ws,
@@ -992,6 +1019,19 @@ int launch_fwd(bool fused, FwdArgs &a, float smoothness, float *loss, float *sta
 
 // shared with mvf_unit_fb.hip
 namespace mvf_photo {
+struct DispMeanJobs {
+    const float *disp[MVF_MAX_UNITS];
+    size_t stride[MVF_MAX_UNITS];
+    float *ws[MVF_MAX_UNITS];
+    int n;
+};
+void launch_disp_mean_many(const DispMeanJobs &jobs, int B, int N, hipStream_t st)
+{
+    DispMeanMany j = {};
+    for (int i = 0; i < jobs.n; ++i) { j.disp[i] = jobs.disp[i]; j.stride[i] = jobs.stride[i]; j.ws[i] = jobs.ws[i]; }
+    ProfScope ps(MVF_PROF_DISP_MEAN, st, 4LL * jobs.n * B * N);
+    hipLaunchKernelGGL(k_disp_mean_many, dim3(NMEAN, B, jobs.n), dim3(256), 0, st, j, N);
+}
 void launch_disp_mean(const float *disp, size_t image_stride, float *ws, int B, int N, hipStream_t st)
 {
     ProfScope ps(MVF_PROF_DISP_MEAN, st, 4LL * B * N);

@@ -84,7 +84,8 @@ struct FbArgs {
     float *gp_ws;         // [U][S][B][ntiles][12] grad_P partials
     float *part;          // [U][B][ntiles][NPART] loss partials
     double *img_ws;       // [U][B][NIMG] per-image folded loss terms
-    int *tickets;         // [U] one per unit (k_units_finish); zero on entry, zero on exit
+    int *tickets;         // [U + 1] one per unit + one per launch (k_units_finish); zero on entry, zero on exit
+    float *loss_sum;      // nullable: sum of the units' loss[0]
     int nunits, flags, B, H, W, tiles_x, tiles_y;
     int flags_int;        // bit 0: every image base / stride of the launch is 8-byte aligned (pair staging allowed)
     float smoothness, min_disp, range, eps;
@@ -1279,10 +1280,25 @@ __global__ void __launch_bounds__(32 * FIN_SLICES) k_units_finish(FbArgs a, int 
                 smooth += __builtin_nontemporal_load(jw + 1);
             }
             const double pmn = photo / ((double)a.B * (double)N);
-            u.loss[0] = (float)(pmn + (double)a.smoothness * smooth);
+            const float l0 = (float)(pmn + (double)a.smoothness * smooth);
+            u.loss[0] = l0;
             u.loss[1] = (float)pmn;
             u.loss[2] = (float)smooth;
             a.tickets[unit] = 0;               // leave the counter as it was found
+            if (a.loss_sum) {
+                // the launch's last unit to finish adds the units' losses in UNIT order (whoever it is: the
+                // result does not depend on the arrival order); each finisher publishes its loss[0] first
+                __hip_atomic_store(u.loss, l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                if (atomicAdd(a.tickets + a.nunits, 1) == a.nunits - 1) {
+                    __threadfence();
+                    float tot = 0.0f;
+                    for (int i = 0; i < a.nunits; ++i)
+                        tot += __hip_atomic_load(a.u[i].loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a.loss_sum[0] = tot;
+                    a.tickets[a.nunits] = 0;
+                }
+            }
         }
     }
 }
@@ -1291,7 +1307,7 @@ __global__ void __launch_bounds__(32 * FIN_SLICES) k_units_finish(FbArgs a, int 
 // shift_b = (smoothness * smooth_b / N) / den_b is the mean-normalisation term of the smoothness
 // gradient; (x - s) * g in this order reproduces the bits of the two-kernel path for g = 1.
 struct ScaleUnit {
-    const float *g_raw, *gT_raw, *stats, *g_loss;
+    const float *g_raw, *gT_raw, *stats, *g_loss, *g_sum;
     float *g_disp, *gT;
     size_t in_stride, out_stride;
 };
@@ -1303,7 +1319,7 @@ struct ScaleArgs {
 __global__ void __launch_bounds__(256) k_fb_scale(ScaleArgs a)
 {
     const ScaleUnit &u = a.u[blockIdx.z];
-    const float g = u.g_loss[0];
+    const float g = (u.g_loss ? u.g_loss[0] : 0.0f) + (u.g_sum ? u.g_sum[0] : 0.0f);
     if (blockIdx.y == gridDim.y - 1) {            // the extra row of blocks scales grad_T
         const int i = blockIdx.x * 256 + threadIdx.x;
         if (i < a.nT) u.gT[i] = u.gT_raw[i] * g;
@@ -1331,7 +1347,14 @@ __global__ void __launch_bounds__(256) k_fb_scale(ScaleArgs a)
 
 // per-image mean partials of the disparity (mvf_photo.hip)
 namespace mvf_photo {
+struct DispMeanJobs {
+    const float *disp[MVF_MAX_UNITS];
+    size_t stride[MVF_MAX_UNITS];
+    float *ws[MVF_MAX_UNITS];
+    int n;
+};
 void launch_disp_mean(const float *disp, size_t image_stride, float *ws, int B, int N, hipStream_t st);
+void launch_disp_mean_many(const DispMeanJobs &jobs, int B, int N, hipStream_t st);
 }
 
 namespace {
@@ -1360,7 +1383,7 @@ size_t mvf_units_workspace_floats(int n_units, int B, int H, int W)
     return ws_layout(n_units, B, H, W).total + 2;
 }
 
-size_t mvf_units_ticket_ints(int n_units, int B) { (void)B; return (size_t)n_units; }
+size_t mvf_units_ticket_ints(int n_units, int B) { (void)B; return (size_t)n_units + 1; }
 
 int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, float smoothness,
                      float min_disp, float range, float eps, float *workspace, int32_t *tickets, int B,
@@ -1386,6 +1409,9 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
     a.gp_ws = workspace + l.gp;
     a.img_ws = reinterpret_cast<double *>(workspace + l.img);
     a.tickets = tickets;
+    a.loss_sum = units[0].loss_sum;
+    // units without disparity-mean partials of their own: ONE launch computes them for all of them
+    mvf_photo::DispMeanJobs mean_jobs = {};
     bool pair_ok = (W % 2) == 0;
     for (int i = 0; i < n_units; ++i) {
         const mvf_unit_desc &d = units[i];
@@ -1412,9 +1438,11 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
         else {
             float *mw = workspace + l.mean + (size_t)i * B * NMEAN;
             u.mean_ws = mw;
-            mvf_photo::launch_disp_mean(d.disp, u.disp_stride, mw, B, N, st);
+            mean_jobs.disp[mean_jobs.n] = d.disp; mean_jobs.stride[mean_jobs.n] = u.disp_stride; mean_jobs.ws[mean_jobs.n] = mw;
+            ++mean_jobs.n;
         }
     }
+    if (mean_jobs.n) mvf_photo::launch_disp_mean_many(mean_jobs, B, N, st);
     a.flags_int = pair_ok ? 1 : 0;
     {
         // launch kind for the per-type medians of bench.py: identity maps taken over / mask supplied / neither
@@ -1449,10 +1477,10 @@ int mvf_units_fwdbwd_scale(const mvf_unit_scale_desc *units, int n_units, float 
     bool vec = (N % 4 == 0);
     for (int i = 0; i < n_units; ++i) {
         const mvf_unit_scale_desc &d = units[i];
-        if (!d.g_disp_raw || !d.g_T_raw || !d.stats || !d.g_loss || !d.g_disp || !d.g_T)
+        if (!d.g_disp_raw || !d.g_T_raw || !d.stats || (!d.g_loss && !d.g_sum) || !d.g_disp || !d.g_T)
             return (int)hipErrorInvalidValue;
         ScaleUnit &u = a.u[i];
-        u.g_raw = d.g_disp_raw; u.gT_raw = d.g_T_raw; u.stats = d.stats; u.g_loss = d.g_loss;
+        u.g_raw = d.g_disp_raw; u.gT_raw = d.g_T_raw; u.stats = d.stats; u.g_loss = d.g_loss; u.g_sum = d.g_sum;
         u.g_disp = d.g_disp; u.gT = d.g_T;
         u.in_stride = d.in_stride ? (size_t)d.in_stride : (size_t)N;
         u.out_stride = d.out_stride ? (size_t)d.out_stride : (size_t)N;

@@ -94,13 +94,16 @@ class HotPathLosses:
                                                   *imgs_src)
         return loss, (auto_mask if want_auto_mask and not o.disable_automasking else None)
 
-    def compute_units(self, units, want_ident=False, want_auto_mask=False):
+    def compute_units(self, units, want_ident=False, want_auto_mask=False, want_sum=False):
         """Several mutually independent units of one shape as ONE launch (reference: the three
         calls of each group in process_batch, train.py:747-760 / 795-810 / 837-882).
 
         ``units``: list of dicts with keys disp_tgt, img_tgt, poses, imgs_src, K, inv_K and
         optionally mask_rec, ident (the identity maps another unit with the same target and
-        sources returned).  Returns (losses [n], idents list | None, auto_masks list | None).
+        sources returned).  Returns (losses [n], idents list | None, auto_masks list | None); with
+        ``want_sum`` the first element is the 0-dim SUM of the n losses instead (what process_batch adds to
+        loss_base per group, train.py:760 / 812 / 882), written by the launch itself -- no reduction launch
+        forward, no expand + copy of its gradient backward.
         Falls back to one `compute_unit` per entry -- and then returns `idents = None`: no identity
         maps are handed over, the partner units re-evaluate them -- when the forward+backward kernel
         cannot take the group as one launch: `--batch_units False`, more than MAX_UNITS entries, S > 2,
@@ -121,7 +124,8 @@ class HotPathLosses:
         if not batched:
             out = [self.compute_unit(un["disp_tgt"], un["img_tgt"], un["poses"], un["imgs_src"], un["K"],
                                      un["inv_K"], un.get("mask_rec"), want_auto_mask) for un in units]
-            return torch.stack([l for l, _ in out]), None, ([m for _, m in out] if want_auto_mask else None)
+            per_unit = torch.stack([l for l, _ in out])
+            return (per_unit.sum() if want_sum else per_unit), None, ([m for _, m in out] if want_auto_mask else None)
         in_kernel = getattr(o, "inkernel_noise", True) and getattr(self, "tie_break_noise", None) is None
         flat, mean_parts = [], []
         for un, (disp, T) in zip(units, prepared):
@@ -131,10 +135,10 @@ class HotPathLosses:
             mean_parts.append(un["disp_tgt"].get(("disp_mean_partials", 0)))
         cfg = dict(n=n, S=S, flags=self._loss_flags(), smoothness=float(o.disparity_smoothness),
                    min_depth=o.min_depth, max_depth=o.max_depth, eps=1e-7,
-                   want_mask=bool(want_auto_mask), want_idx=False, want_ident=bool(want_ident),
+                   want_mask=bool(want_auto_mask), want_idx=False, want_ident=bool(want_ident), want_sum=bool(want_sum),
                    mean_parts=mean_parts if any(m is not None for m in mean_parts) else None)
         res = ops.Units.apply(cfg, *flat)
-        losses, per = res[0], res[2:]
+        losses, per = (res[-1] if want_sum else res[0]), res[2:]
         idents = [per[4 * u + 3] for u in range(n)] if want_ident and not o.disable_automasking else None
         masks = [per[4 * u + 0] for u in range(n)] if want_auto_mask and not o.disable_automasking else None
         return losses, idents, masks

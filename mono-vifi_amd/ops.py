@@ -440,9 +440,11 @@ class Units(torch.autograd.Function):
 
     apply(cfg, disp_0, tgt_0, T_0, K_0, inv_K_0, mask_0, noise_0, ident_in_0, *src_0 (S), disp_1, ...)
     cfg = dict(n, S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx,
-               want_ident, noise_out (list|None), mean_parts (list|None))
+               want_ident, want_sum, noise_out (list|None), mean_parts (list|None))
     returns (losses [n], terms [n,2] (photo, smooth), then per unit: auto_mask, argmin, idx,
-             ident) -- absent outputs are empty tensors."""
+             ident) -- absent outputs are empty tensors -- and, LAST, with want_sum the 0-dim sum of the n
+    losses (differentiable like `losses`; the finishing kernel writes it, the backward pass takes its upstream
+    gradient as one more device scalar: no reduce / expand / copy launches around a group of units)."""
 
     @staticmethod
     def forward(ctx, cfg, *flat):
@@ -453,6 +455,7 @@ class Units(torch.autograd.Function):
         md, rg = depth_consts(cfg["min_depth"], cfg["max_depth"])
         want_mask, want_idx, want_ident = cfg.get("want_mask", False), cfg.get("want_idx", False), \
             cfg.get("want_ident", False)
+        want_sum = bool(cfg.get("want_sum", False))
         noise_outs = cfg.get("noise_out") or [None] * n
         mean_parts = cfg.get("mean_parts") or [None] * n
         automask = not (flags & NO_AUTOMASK)
@@ -462,6 +465,7 @@ class Units(torch.autograd.Function):
         descs = (nat.UnitDesc * n)()
         keep = []
         loss3 = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        loss_sum = torch.empty((), dtype=torch.float32, device=dev) if want_sum else None
         stats = torch.empty((n, B, 4), dtype=torch.float32, device=dev)
         g_disp = torch.empty((n, B, 1, H, W), dtype=torch.float32, device=dev)
         g_T = torch.empty((n, S, B, 4, 4), dtype=torch.float32, device=dev)
@@ -530,6 +534,8 @@ class Units(torch.autograd.Function):
             outs += [auto_mask if auto_mask is not None else empty, argmin,
                      idx if idx is not None else empty, ident if ident is not None else empty]
             needs.append((ctx.needs_input_grad[1 + u * per], ctx.needs_input_grad[1 + u * per + 2]))
+        if want_sum:
+            descs[0].loss_sum = loss_sum.data_ptr()
         ws = torch.empty(nat.lib().mvf_units_workspace_floats(n, B, H, W), dtype=torch.float32, device=dev)
         tk = _tickets(dev, nat.lib().mvf_units_ticket_ints(n, B))
         try:
@@ -540,9 +546,11 @@ class Units(torch.autograd.Function):
             _drop_tickets(dev)          # the counters may be non-zero now: never reuse them
             raise
         ctx.save_for_backward(g_disp, g_T, stats)
-        ctx.n, ctx.S, ctx.smoothness, ctx.per, ctx.needs = n, S, smoothness, per, needs
+        ctx.n, ctx.S, ctx.smoothness, ctx.per, ctx.needs, ctx.want_sum = n, S, smoothness, per, needs, want_sum
         res = (loss3[:, 0], loss3[:, 1:], *outs)
         ctx.mark_non_differentiable(*res[1:])
+        if want_sum:
+            res = res + (loss_sum,)
         # the engine would otherwise hand backward() a ZERO tensor for every output that received no
         # gradient -- argmin (uint8 [B,H,W]), the identity maps, ... : 16 fill launches per step
         # (profiles/r03_hotpath_kernel_stats_before_nomaterialize.csv: 747 + 581 fills in 83 steps)
@@ -550,22 +558,27 @@ class Units(torch.autograd.Function):
         return res
 
     @staticmethod
-    def backward(ctx, g_losses, *_unused):
+    def backward(ctx, g_losses, *rest):
         # raw gradients for an upstream gradient of 1; one pass applies the per-image constant of
-        # the mean-normalised smoothness term and each unit's upstream gradient
-        if g_losses is None:
+        # the mean-normalised smoothness term and each unit's upstream gradient (its own + the sum's)
+        g_sum = rest[-1] if ctx.want_sum else None
+        if g_losses is None and g_sum is None:
             return (None,) * (1 + ctx.n * ctx.per)
         g_raw, gT_raw, stats = ctx.saved_tensors
         n, S = ctx.n, ctx.S
         _, B, _, H, W = g_raw.shape
-        g_losses = _c(g_losses).reshape(n)
+        if g_losses is not None:
+            g_losses = _c(g_losses).reshape(n)
+        if g_sum is not None:
+            g_sum = _c(g_sum.float()).reshape(1)
         g_disp, g_T = torch.empty_like(g_raw), torch.empty_like(gT_raw)
         descs = (nat.UnitScaleDesc * n)()
         for u in range(n):
             d = descs[u]
             d.g_disp_raw, d.in_stride = g_raw[u].data_ptr(), H * W
             d.g_T_raw, d.stats = gT_raw[u].data_ptr(), stats[u].data_ptr()
-            d.g_loss = g_losses.data_ptr() + 4 * u
+            d.g_loss = (g_losses.data_ptr() + 4 * u) if g_losses is not None else None
+            d.g_sum = g_sum.data_ptr() if g_sum is not None else None
             d.g_disp, d.out_stride = g_disp[u].data_ptr(), H * W
             d.g_T = g_T[u].data_ptr()
         nat.check(nat.lib().mvf_units_fwdbwd_scale(C.cast(descs, C.c_void_p), n, ctx.smoothness, B, S, H, W,

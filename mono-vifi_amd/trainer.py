@@ -448,8 +448,8 @@ class Trainer(HotPathLosses):
         ONE launch of the forward+backward tile kernel for all of them.  units: dicts as for
         `compute_units`.  Returns (sum of their losses, identity maps per unit | None)."""
         if self.opt.fused_units:
-            losses, idents, _ = self.compute_units(units, want_ident=want_ident)
-            return losses.sum(), idents
+            total, idents, _ = self.compute_units(units, want_ident=want_ident, want_sum=True)
+            return total, idents
         total = None
         for un in units:
             l = self._unit(un["disp_tgt"], un["img_tgt"], un["poses"], un["imgs_src"], un["K"], un["inv_K"],

@@ -255,3 +255,45 @@ def test_mismatched_planes_raise_instead_of_reading_out_of_bounds(dev, which):
     _, _, good = _flat(inp, dev, 0)
     res = ops.Units.apply(_cfg(1, 0), *good)
     assert torch.isfinite(res[0]).all()
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 70), (12, 192, 640)])
+@pytest.mark.parametrize("n", [1, 3])
+def test_group_sum_written_by_the_launch(dev, shape, n):
+    """want_sum: the finishing kernel writes the sum of the group's losses (unit order) and the backward pass takes the
+    sum's upstream gradient as one more device scalar (no reduce / expand / copy launches around a
+    group).  The sum equals the sequential fp32 sum of the per-unit losses bit for bit; gradients through the sum
+    equal gradients through `losses.sum()` bit for bit; both paths at once add their upstream gradients; repeated
+    launches on one stream leave the (unit + launch) ticket counters clean."""
+    from mono_vifi_amd import ops
+    B, H, W = shape
+    inps = [_inputs(6100 + 17 * u + H, B, H, W, 0, u == 2) for u in range(n)]
+
+    def run(mode):
+        flat, leaves = [], []
+        for inp in inps:
+            d, Tt, f = _flat(inp, dev, 0)
+            flat += f
+            leaves.append((d, Tt))
+        res = ops.Units.apply(_cfg(n, 0, want_sum=(mode != "losses")), *flat)
+        if mode == "losses":
+            (2.0 * res[0].sum()).backward()
+        elif mode == "sum":
+            (2.0 * res[-1]).backward()
+        else:
+            (0.5 * res[0].sum() + 1.5 * res[-1]).backward()
+        return res, [(N(d.grad), N(Tt.grad)) for d, Tt in leaves]
+
+    r_l, g_l = run("losses")
+    for _ in range(2):                                   # twice: the tickets are left zero
+        r_s, g_s = run("sum")
+        seq = np.float32(0.0)
+        for v in N(r_s[0]):
+            seq = np.float32(seq + v)
+        assert np.float32(float(r_s[-1])) == seq and r_s[-1].dim() == 0
+        assert np.array_equal(N(r_s[0]), N(r_l[0]))
+        for (a, b), (c, d) in zip(g_s, g_l):
+            assert np.array_equal(a, c) and np.array_equal(b, d)
+    _, g_b = run("both")
+    for (a, b), (c, d) in zip(g_b, g_l):                 # 0.5 + 1.5 == 2.0: the two upstream gradients add exactly
+        assert np.array_equal(a, c) and np.array_equal(b, d)
