@@ -805,6 +805,20 @@ class _StepGraph:
             # LU-based like torch.inverse, without its host-side error check (no synchronisation)
             self.static["Rc_inv"].copy_(torch.linalg.inv_ex(self.static["Rc"])[0])
 
+    def _quiesce_collectives(self):
+        """Before the capture: let ProcessGroupNCCL's watchdog retire every collective of the eager warm-up steps.
+        The watchdog polls the end events of the works it still lists with hipEventQuery; on ROCm 7.2 a query that
+        lands while RCCL's stream is part of an ongoing capture fails with hipErrorCapturedEvent ("operation not
+        permitted on an event last recorded in a capturing stream") although the event was recorded before the
+        capture began, and the watchdog takes the process down -- measured with the data-parallel collectives forced
+        through RCCL: 1-3 of 6 runs died at the capture (tools/r04_graph_rccl_probe.py, profiles/r04_graph_rccl.log).
+        Collectives issued DURING the capture are not listed (torch skips them), so an empty list at its start is
+        enough: drain the device, then give the watchdog (100 ms poll) time to see the completed works."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_backend() != "nccl":
+            return
+        torch.cuda.synchronize(self.t.device)
+        time.sleep(float(os.environ.get("MVF_GRAPH_QUIESCE_S", "1.0")))
+
     def __call__(self, inputs):
         t = self.t
         self._load(inputs)
@@ -817,6 +831,7 @@ class _StepGraph:
                     losses = t._device_step(dict(self.static))
                 cur.wait_stream(self.stream)
                 return losses
+            self._quiesce_collectives()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=self.stream):
                 self.losses = (t._device_step if self.scope == "step" else t._forward_backward)(dict(self.static))

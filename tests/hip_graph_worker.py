@@ -15,6 +15,7 @@ import torch  # noqa: E402
 def main():
     backbone, B, H, W, log_dir = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
     scope = sys.argv[6] if len(sys.argv) > 6 else "step"
+    collectives = len(sys.argv) > 7 and sys.argv[7] == "collectives"
     import mono_vifi_amd
     from mono_vifi_amd import synthetic
     from mono_vifi_amd.options import default_options
@@ -23,6 +24,14 @@ def main():
     mono_vifi_amd.ensure_graph_replay_env()
     from mono_vifi_amd.trainer import Trainer, _StepGraph
     dev = torch.device("cuda", 0)
+    if collectives:
+        # the data-parallel exchanges of a step (bucketed gradient all-reduce from the backward hooks, SyncBatchNorm
+        # statistics) through RCCL in a group of one -- captured INTO the graph together with everything else
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29800 + os.getpid() % 1000), RANK="0", WORLD_SIZE="1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(0)
+        dist.init_process_group(backend="nccl", init_method="env://", world_size=1, rank=0, device_id=dev)
     steps = 7
     batches = []
     for i in range(steps):
@@ -35,7 +44,8 @@ def main():
         opts = default_options(batch_size=B, height=H, width=W, backbone=backbone, use_affine=True, num_workers=0,
                                synthetic_len=4 * B, log_dir=os.path.join(log_dir, "graph" if graph else "eager"),
                                exp_name="t", log_frequency=10 ** 9, save_frequency=10 ** 9, hip_graph=graph,
-                               hip_graph_scope=scope, inkernel_noise=False, lr_sche_type="cos", learning_rate=1e-3)
+                               hip_graph_scope=scope, inkernel_noise=False, lr_sche_type="cos", learning_rate=1e-3,
+                               force_collectives=collectives)
         t = Trainer(opts)
         t.set_train()
         t.tie_break_noise = noise
@@ -52,7 +62,8 @@ def main():
         out["graph" if graph else "eager"] = dict(
             losses=losses, delta_norm=float(delta.norm()), lr=float(lr), lr_is_tensor=bool(torch.is_tensor(lr)),
             captured=bool(graph and t._step_graph.graph is not None),
-            calls=int(t._step_graph.calls) if graph else 0)
+            calls=int(t._step_graph.calls) if graph else 0,
+            buckets=int(t.reducer.num_buckets), forced=bool(getattr(t.reducer, "always_reduce", False)))
         if graph:
             # a graph-mode checkpoint resumes in an eager trainer
             t.save_model(batch_idx=1)

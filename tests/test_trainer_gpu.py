@@ -67,7 +67,8 @@ def test_fused_units_equal_staged_path(tmp_path):
 
 @pytest.mark.parametrize("backbone,B,H,W,scope", [("ResNet18", 2, 64, 96, "step"), ("ResNet18", 12, 192, 640, "step"),
                                                   ("ResNet18", 12, 192, 640, "backward"),
-                                                  ("DHRNet", 12, 192, 640, "step")])
+                                                  ("DHRNet", 12, 192, 640, "step"),
+                                                  ("ResNet18", 12, 192, 640, "step+collectives")])
 def test_hip_graph_step_follows_the_eager_step(tmp_path, backbone, B, H, W, scope):
     """--hip_graph at a test shape and at the BASELINE shapes of the ResNet18 and HRNet18 configurations: three
     eager warm-up steps, then the device work of the step is captured once and replayed (scope "step": networks,
@@ -85,8 +86,14 @@ def test_hip_graph_step_follows_the_eager_step(tmp_path, backbone, B, H, W, scop
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ)
     env.setdefault("MIOPEN_FIND_MODE", "FAST")
+    # "step+collectives" (VERDICT r03 item 4d): the same comparison with the data-parallel exchanges forced through
+    # RCCL in a group of one -- bucketed gradient all-reduce from the backward hooks and the SyncBatchNorm
+    # statistics captured INTO the replayed graph: what the eight ranks of a node run when the graph step is on
+    extra = []
+    if scope.endswith("+collectives"):
+        scope, extra = scope.split("+")[0], ["collectives"]
     p = subprocess.run([sys.executable, os.path.join(root, "tests", "hip_graph_worker.py"), backbone, str(B), str(H),
-                        str(W), str(tmp_path), scope], env=env, capture_output=True, text=True, timeout=900)
+                        str(W), str(tmp_path), scope] + extra, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, p.stdout[-2000:]
@@ -94,6 +101,8 @@ def test_hip_graph_step_follows_the_eager_step(tmp_path, backbone, B, H, W, scop
     e, g = r["eager"], r["graph"]
     le, lg = np.array(e["losses"]), np.array(g["losses"])
     assert g["captured"] and g["calls"] == len(lg)
+    if extra:
+        assert g["forced"] and e["forced"] and g["buckets"] >= 2
     assert np.all(np.isfinite(lg))
     np.testing.assert_allclose(lg[:2], le[:2], rtol=1e-4)       # eager warm-up steps of both
     np.testing.assert_allclose(lg, le, rtol=5e-2, atol=1e-6)
