@@ -112,6 +112,9 @@ def parse():
     ap.add_argument("--no-share-identity", dest="no_share_identity", action="store_true",
                     help="multi-frame units re-evaluate the identity candidates instead of taking the maps "
                          "of the single-frame unit of the same target")
+    ap.add_argument("--no-regroup", dest="no_regroup", action="store_true",
+                    help="train workload: per-group views of the grouped encoder's pyramids re-merged with stack "
+                         "(round-3 data flow) instead of one regrouping launch per level")
     ap.add_argument("--grad-exchange", dest="grad_exchange", default="all_reduce",
                     choices=["all_reduce", "reduce_scatter"],
                     help="per gradient bucket: one RCCL all-reduce, or reduce-scatter + all-gather on the "

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 12
+#define MVF_ABI_VERSION 13
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -356,6 +356,21 @@ MVF_API int mvf_affine_restore_bwd(const float *g_out, const float *angle_deg, c
 MVF_API int mvf_reflect_pad1_fwd(const float *in, float *out, int planes, int H, int W, void *stream);
 MVF_API int mvf_reflect_pad1_bwd(const float *g_out, float *g_in, int planes, int H, int W, void *stream);
 
+/* ---- Regrouping of interleaved group batches (section 8f-3; reference: train.py:745-747, 788-797, 830-868 hand
+ * each encoder call's feature pyramid to the decoder / fusion calls that use it) ---------------
+ * src [B*G, chunk] holds G independent invocations interleaved (sample n = b*G + g).  Output k is
+ * the interleaved batch of counts[k] of those groups: dst[k] sample b*counts[k] + j = src sample
+ * b*G + groups[offset_k + j] (groups = the per-output lists concatenated; a group may appear in
+ * several outputs and several times in one).  dst / counts / groups are HOST arrays (n_out <= 8,
+ * at most 32 slots in total, G <= 32); ONE launch for all outputs. */
+MVF_API int mvf_regroup_fwd(const float *src, int G, int B, int64_t chunk, int n_out, float *const *dst,
+                    const int32_t *counts, const int32_t *groups, void *stream);
+/* adjoint: g_src [B*G, chunk] = per source group the sum of the gradients of the slots that read
+ * it, in (output, position) order; groups nobody read (or whose outputs have g_dst[k] == NULL:
+ * not differentiated) get zeros.  Written once, deterministic. */
+MVF_API int mvf_regroup_bwd(const float *const *g_dst, int G, int B, int64_t chunk, int n_out,
+                    const int32_t *counts, const int32_t *groups, float *g_src, void *stream);
+
 /* ---- f4: step glue either side of the hot path ------------------
  * Decoder stage glue (networks/monodepth2.py:84-90 with layers.py:121-138, 225-228): the padded
  * input of upconv_1, out [B, C1+C2, 2h+2, 2w+2] = ReflectionPad2d(1)(cat([upsample_nearest_x2(x),
@@ -466,7 +481,9 @@ MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32
 #define MVF_PROF_SILOG_FWD 29        /* k_silog_partial + k_silog_finish */
 #define MVF_PROF_SILOG_BWD 30        /* k_silog_bwd */
 #define MVF_PROF_AFFINE 31           /* affine transform / restore kernels */
-#define MVF_PROF_COUNT 32
+#define MVF_PROF_REGROUP_FWD 32      /* k_regroup_fwd */
+#define MVF_PROF_REGROUP_BWD 33      /* k_regroup_bwd */
+#define MVF_PROF_COUNT 34
 /* launch tags of MVF_PROF_UNIT_FWDBWD (mvf_profile_read_launches): what kind of unit group a launch carried */
 #define MVF_TAG_SINGLE_FRAME 0  /* identity candidates evaluated (and possibly handed over: ident_out) */
 #define MVF_TAG_MULTI_FRAME 1   /* identity maps taken from another unit (ident_in) */

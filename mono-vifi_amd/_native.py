@@ -12,7 +12,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
@@ -98,6 +98,8 @@ _SIGNATURES = {
     "mvf_upsample_nearest_bwd": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_maxpool3s2_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "mvf_maxpool3s2_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "mvf_regroup_fwd": [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp],
+    "mvf_regroup_bwd": [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp],
     "mvf_color_jitter_workspace_floats": [_i],
     "mvf_color_jitter": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_unit_fwdbwd_scale": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -131,7 +133,7 @@ _SIGNATURES = {
 }
 (PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD,
  PROF_UNIT_FWDBWD) = range(7)
-PROF_FIRST_GLUE, PROF_COUNT = 7, 32         # ids >= 7: glue kernels, profile level 2, work = algorithmic bytes
+PROF_FIRST_GLUE, PROF_COUNT = 7, 34         # ids >= 7: glue kernels, profile level 2, work = algorithmic bytes
 TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine"}
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_profile_name": C.c_char_p, "mvf_profile_read_launches": C.c_int64, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,

@@ -31,6 +31,7 @@ class TrainStep:
             hip_graph_scope=getattr(args, "hip_graph_scope", "step"),
             batch_units=not getattr(args, "no_batch_units", False),
             share_identity=not getattr(args, "no_share_identity", False),
+            regroup=not getattr(args, "no_regroup", False),
             grad_exchange=getattr(args, "grad_exchange", "all_reduce"),
             no_overlap=bool(getattr(args, "no_overlap", False)),
             force_collectives=bool(getattr(args, "force_collectives", False)))

@@ -1056,6 +1056,131 @@ __global__ void __launch_bounds__(NT) k_jitter_apply(const float *__restrict__ i
     out_aug[o] = c.r; out_aug[o + N] = c.g; out_aug[o + 2 * (size_t)N] = c.b;
 }
 
+
+// ---- regrouping of interleaved group batches (networks/grouped.py) ----------------------------------------------
+// One optimisation step of the reference calls the depth encoder once per input and hands each call's feature
+// pyramid to the decoder / fusion module calls that need it (train.py:745-747, 788-797, 830-868).  Here the G
+// encoder inputs are ONE interleaved batch (sample n = b * G + g) and every consumer takes its own interleaved
+// batch of some of the groups: dst_k sample b * Gk + j = src sample b * G + group_k[j].  Forward: every (output,
+// position) slot copies one group, ONE launch for all outputs of a pyramid level (ATen's stack per consumer ran at
+// 0.25 of the HBM peak: strided CatArrayBatchedCopy).  Backward: the gradient of a source group is the sum over the
+// slots that read it, in (output, position) order, written once -- no zero fill for unused groups, no accumulation
+// passes of the autograd engine, no stack of the group gradients.
+constexpr int RG_MAX_OUT = 8, RG_MAX_SLOTS = 32;
+struct RegroupPlan {
+    float *out[RG_MAX_OUT];                 // forward: outputs; backward: their gradients (nullable)
+    int gk[RG_MAX_OUT];                     // groups per output
+    unsigned char slot_k[RG_MAX_SLOTS], slot_j[RG_MAX_SLOTS], slot_g[RG_MAX_SLOTS];
+    unsigned char first[RG_MAX_SLOTS + 1];  // backward: slots [first[g], first[g+1]) of `by_g` read source group g
+    unsigned char by_g[RG_MAX_SLOTS];
+    int nslots;
+};
+
+// grid (chunk blocks, slots, B): one shot per block, four 16-byte (VEC) accesses per lane in flight
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_regroup_fwd(const float *__restrict__ src, RegroupPlan pl, int G, int64_t per)
+{
+    constexpr int U = 4;
+    const int s = blockIdx.y, b = blockIdx.z;
+    const int k = pl.slot_k[s], j = pl.slot_j[s], g = pl.slot_g[s];
+    const int64_t q0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x;
+    const int64_t so = ((int64_t)b * G + g) * per, dof = ((int64_t)b * pl.gk[k] + j) * per;
+    float *__restrict__ dst = pl.out[k];
+    if (VEC) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * NT < per) v[u] = reinterpret_cast<const float4 *>(src)[so + q0 + u * NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * NT < per) reinterpret_cast<float4 *>(dst)[dof + q0 + u * NT] = v[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * NT < per) dst[dof + q0 + u * NT] = src[so + q0 + u * NT];
+    }
+}
+
+// grid (chunk blocks, G, B): the gradient of source group g = sum of its slots' gradients in slot order
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_regroup_bwd(float *__restrict__ g_src, RegroupPlan pl, int G, int64_t per)
+{
+    constexpr int U = 4;
+    const int g = blockIdx.y, b = blockIdx.z;
+    const int64_t q0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x;
+    const int64_t so = ((int64_t)b * G + g) * per;
+    const int lo = pl.first[g], hi = pl.first[g + 1];
+    if (VEC) {
+        float4 acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        for (int e = lo; e < hi; ++e) {
+            const int s = pl.by_g[e], k = pl.slot_k[s];
+            const float4 *__restrict__ gp = reinterpret_cast<const float4 *>(pl.out[k]) + ((int64_t)b * pl.gk[k] + pl.slot_j[s]) * per;
+            float4 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q0 + u * NT < per) v[u] = gp[q0 + u * NT];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (q0 + u * NT < per) {
+                    if (e == lo) acc[u] = v[u];
+                    else { acc[u].x += v[u].x; acc[u].y += v[u].y; acc[u].z += v[u].z; acc[u].w += v[u].w; }
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * NT < per) reinterpret_cast<float4 *>(g_src)[so + q0 + u * NT] = acc[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t q = q0 + u * NT;
+            if (q >= per) continue;
+            float acc = 0.0f;
+            for (int e = lo; e < hi; ++e) {
+                const int s = pl.by_g[e], k = pl.slot_k[s];
+                const float v = pl.out[k][((int64_t)b * pl.gk[k] + pl.slot_j[s]) * per + q];
+                acc = (e == lo) ? v : acc + v;
+            }
+            g_src[so + q] = acc;
+        }
+    }
+}
+
+// host side of both directions: the plan from (counts, groups); slots whose output pointer is null are left out
+// (backward: an output nobody differentiated)
+static int regroup_plan(RegroupPlan &pl, float *const *out, int n_out, const int32_t *counts, const int32_t *groups,
+                        int G, bool skip_null, bool &vec_ok)
+{
+    if (n_out <= 0 || n_out > RG_MAX_OUT || G <= 0 || G > RG_MAX_SLOTS || !counts || !groups || !out)
+        return (int)hipErrorInvalidValue;
+    int ns = 0, at = 0;
+    for (int k = 0; k < n_out; ++k) {
+        if (counts[k] <= 0) return (int)hipErrorInvalidValue;
+        pl.out[k] = out[k];
+        pl.gk[k] = counts[k];
+        if (!out[k] && !skip_null) return (int)hipErrorInvalidValue;
+        if (out[k] && (((uintptr_t)out[k]) & 15)) vec_ok = false;
+        for (int j = 0; j < counts[k]; ++j, ++at) {
+            const int g = groups[at];
+            if (g < 0 || g >= G) return (int)hipErrorInvalidValue;
+            if (!out[k]) continue;
+            if (ns >= RG_MAX_SLOTS) return (int)hipErrorInvalidValue;
+            pl.slot_k[ns] = (unsigned char)k; pl.slot_j[ns] = (unsigned char)j; pl.slot_g[ns] = (unsigned char)g;
+            ++ns;
+        }
+    }
+    for (int k = n_out; k < RG_MAX_OUT; ++k) { pl.out[k] = nullptr; pl.gk[k] = 0; }
+    pl.nslots = ns;
+    int e = 0;
+    for (int g = 0; g < G; ++g) {               // stable: slot order within a group = (output, position) order
+        pl.first[g] = (unsigned char)e;
+        for (int s = 0; s < ns; ++s)
+            if (pl.slot_g[s] == g) pl.by_g[e++] = (unsigned char)s;
+    }
+    for (int g = G; g <= RG_MAX_SLOTS; ++g) pl.first[g] = (unsigned char)e;
+    return 0;
+}
 }  // namespace
 
 // wide adjoint of ReflectionPad2d(1) for mvf_reflect_pad1_bwd (mvf_geom.hip); false when the shape needs the narrow form
@@ -1323,6 +1448,45 @@ int mvf_maxpool3s2_bwd(const float *g_out, const uint8_t *idx, float *g_x, int p
                        dim3(NT), 0, (hipStream_t)stream, g_out, idx, g_x, planes, H, W, OH, OW);
     return hip_check_launch();
 }
+
+int mvf_regroup_fwd(const float *src, int G, int B, int64_t chunk, int n_out, float *const *dst, const int32_t *counts,
+                    const int32_t *groups, void *stream)
+{
+    if (B <= 0 || chunk <= 0) return 0;
+    if (!src || B > 65535 || (int64_t)B * G * chunk > 0x7fffffffffffLL) return (int)hipErrorInvalidValue;
+    RegroupPlan pl;
+    bool vec = (chunk & 3) == 0 && (((uintptr_t)src) & 15) == 0;
+    const int err = regroup_plan(pl, dst, n_out, counts, groups, G, false, vec);
+    if (err) return err;
+    const int64_t per = vec ? chunk / 4 : chunk, blocks = (per + NT * 4 - 1) / (NT * 4);
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    // every slot reads one group and writes one group
+    ProfScope ps(MVF_PROF_REGROUP_FWD, stream, 8LL * pl.nslots * B * chunk);
+    const dim3 grid((unsigned)blocks, (unsigned)pl.nslots, (unsigned)B);
+    if (vec) hipLaunchKernelGGL(k_regroup_fwd<true>, grid, dim3(NT), 0, (hipStream_t)stream, src, pl, G, per);
+    else hipLaunchKernelGGL(k_regroup_fwd<false>, grid, dim3(NT), 0, (hipStream_t)stream, src, pl, G, per);
+    return hip_check_launch();
+}
+
+int mvf_regroup_bwd(const float *const *g_dst, int G, int B, int64_t chunk, int n_out, const int32_t *counts,
+                    const int32_t *groups, float *g_src, void *stream)
+{
+    if (B <= 0 || chunk <= 0) return 0;
+    if (!g_src || B > 65535 || (int64_t)B * G * chunk > 0x7fffffffffffLL) return (int)hipErrorInvalidValue;
+    RegroupPlan pl;
+    bool vec = (chunk & 3) == 0 && (((uintptr_t)g_src) & 15) == 0;
+    const int err = regroup_plan(pl, const_cast<float *const *>(g_dst), n_out, counts, groups, G, true, vec);
+    if (err) return err;
+    const int64_t per = vec ? chunk / 4 : chunk, blocks = (per + NT * 4 - 1) / (NT * 4);
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    // every differentiated slot read once, every source group written once
+    ProfScope ps(MVF_PROF_REGROUP_BWD, stream, 4LL * (pl.nslots + G) * B * chunk);
+    const dim3 grid((unsigned)blocks, (unsigned)G, (unsigned)B);
+    if (vec) hipLaunchKernelGGL(k_regroup_bwd<true>, grid, dim3(NT), 0, (hipStream_t)stream, g_src, pl, G, per);
+    else hipLaunchKernelGGL(k_regroup_bwd<false>, grid, dim3(NT), 0, (hipStream_t)stream, g_src, pl, G, per);
+    return hip_check_launch();
+}
+
 
 size_t mvf_color_jitter_workspace_floats(int images) { return (size_t)images * JIT_NB; }
 

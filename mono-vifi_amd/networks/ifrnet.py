@@ -61,12 +61,20 @@ class ResBlock(nn.Module):
         self.conv5 = nn.Conv2d(ch, ch, 3, 1, 1)
         self.prelu = nn.PReLU(ch)
 
-    def forward(self, x):
+    def _side(self, out, conv):
+        """``cat([out[:, :-s], conv(out[:, -s:])], 1)`` (reference: networks/IFRNet.py ResBlock.forward).  With
+        autograd off (the frozen teacher of a training step) ``out`` -- the fresh output of the previous
+        convolution -- takes the new side channels in place: s of its C channels move instead of all of them
+        twice (IFRNet-L at 36 images: 5.2 GB of cat traffic per step -> 1.2 GB)."""
         s = self.side_channels
-        out = self.conv1(x)
-        out = torch.cat([out[:, :-s], self.conv2(out[:, -s:])], 1)
-        out = self.conv3(out)
-        out = torch.cat([out[:, :-s], self.conv4(out[:, -s:])], 1)
+        if not torch.is_grad_enabled() and not out.requires_grad:
+            out[:, -s:] = conv(out[:, -s:])
+            return out
+        return torch.cat([out[:, :-s], conv(out[:, -s:])], 1)
+
+    def forward(self, x):
+        out = self._side(self.conv1(x), self.conv2)
+        out = self._side(self.conv3(out), self.conv4)
         return conv_bias_act(self.conv5, out, "prelu", self.prelu, res=x)
 
 

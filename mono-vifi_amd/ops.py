@@ -1166,6 +1166,68 @@ def upsample_nearest(x, factor):
     return UpsampleNearest.apply(x, int(factor))
 
 
+class Regroup(torch.autograd.Function):
+    """Interleaved group batch -> the interleaved batches its consumers take (section 8f-3).
+
+    ``src [B*G, ...]`` holds G independent invocations (sample n = b*G + g: networks/grouped.py);
+    ``plans`` is a tuple of group-index tuples, one per consumer.  Output k is the interleaved batch
+    ``[B*len(plans[k]), ...]`` of those groups -- what ``merge_groups([split_groups(src, G)[g] for g in
+    plans[k]])`` builds, for every consumer in ONE launch.  The backward writes the gradient of ``src``
+    once: per group the sum over the slots that read it, zeros where nobody did (reference: the
+    feature pyramids of the encoder calls train.py:745-747, 830-868 feed the decoder / fusion calls
+    train.py:747, 788-797, 837-868)."""
+
+    @staticmethod
+    def forward(ctx, src, G, plans):
+        nat.require_device(src)
+        src = _c(src)
+        if src.dtype != torch.float32:
+            raise RuntimeError("regroup: float32 only")
+        G = int(G)
+        plans = tuple(tuple(int(g) for g in p) for p in plans)
+        if G <= 0 or src.shape[0] % G or not plans or any(not p for p in plans):
+            raise RuntimeError(f"regroup: batch {src.shape[0]} is not {G} interleaved groups, or an empty plan")
+        if any(g < 0 or g >= G for p in plans for g in p):
+            raise RuntimeError(f"regroup: group index outside 0..{G - 1}")
+        B = src.shape[0] // G
+        chunk = src[0].numel()
+        outs = [src.new_empty((B * len(p),) + tuple(src.shape[1:])) for p in plans]
+        counts = (C.c_int32 * len(plans))(*[len(p) for p in plans])
+        flat = [g for p in plans for g in p]
+        groups = (C.c_int32 * len(flat))(*flat)
+        dst, keep = nat.ptr_array(outs)
+        nat.check(nat.lib().mvf_regroup_fwd(nat.ptr(src), G, B, chunk, len(plans), dst, counts, groups, _stream()),
+                  "regroup_fwd")
+        del keep
+        ctx.G, ctx.plans, ctx.shape = G, plans, tuple(src.shape)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        G, plans, shape = ctx.G, ctx.plans, ctx.shape
+        live = [g for g in gouts if g is not None]
+        if not live:
+            return None, None, None
+        nat.require_device(*live)
+        gouts = [None if g is None else _c(g) for g in gouts]
+        g_src = torch.empty(shape, dtype=torch.float32, device=live[0].device)
+        B = shape[0] // G
+        chunk = g_src[0].numel()
+        counts = (C.c_int32 * len(plans))(*[len(p) for p in plans])
+        flat = [g for p in plans for g in p]
+        groups = (C.c_int32 * len(flat))(*flat)
+        arr = (C.c_void_p * len(gouts))(*[None if g is None else g.data_ptr() for g in gouts])
+        nat.check(nat.lib().mvf_regroup_bwd(C.cast(arr, C.c_void_p), G, B, chunk, len(plans), counts, groups,
+                                            nat.ptr(g_src), _stream()), "regroup_bwd")
+        return g_src, None, None
+
+
+def regroup(src, groups, plans):
+    """-> tuple of interleaved batches, one per plan (see `Regroup`)."""
+    return Regroup.apply(src, groups, plans)
+
+
 class MaxPool3s2(torch.autograd.Function):
     """nn.MaxPool2d(3, 2, 1) of the ResNet trunks (reference networks/monodepth2.py:39,
     networks/posenet.py:87): one byte of window-local argmax per output instead of ATen's int64

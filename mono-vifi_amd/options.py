@@ -103,6 +103,10 @@ def build_parser():
                    help="run the mutually independent encoder / decoder / pose / fusion invocations "
                         "of a step as one interleaved batch each, with per-call BatchNorm statistics "
                         "(networks/grouped.py); False = one call at a time like the reference")
+    p.add_argument("--regroup", type=_str2bool, default=True,
+                   help="with --group_calls: the decoder / fusion calls take their interleaved batches of the "
+                        "grouped encoder's feature pyramids from one regrouping launch per level (and one adjoint "
+                        "launch) instead of per-group views re-merged with stack and accumulated by autograd")
     p.add_argument("--fused_units", type=_str2bool, default=True,
                    help="fused unit kernels (warped images in LDS) instead of the staged "
                         "generate_images_pred + compute_losses_base pair")

@@ -55,6 +55,13 @@ def split_g(t, groups):
     return grouped.split_groups(t, groups)
 
 
+class _GroupedPyramids(list):
+    """Per input, the feature pyramid of a grouped encoder call (views), plus what they are views of: `bases`
+    [level] = the interleaved batch of all `G` inputs (`Trainer._regroup` reads those directly)."""
+    bases = None
+    G = 0
+
+
 class Trainer(HotPathLosses):
     def __init__(self, options):
         self.opt = options
@@ -465,6 +472,20 @@ class Trainer(HotPathLosses):
         return out
 
     # ---- the independent invocations of a step, one interleaved batch each (networks/grouped.py)
+    def _regroup(self, enc, plans):
+        """Per plan (a list of positions in the grouped encoder call `enc` came from), the interleaved batches of
+        those inputs' feature pyramids: [plan][level] -- ONE launch per level for all plans (`ops.regroup`)
+        instead of a `stack` per plan and level, and one adjoint launch instead of autograd's accumulation of
+        the per-group gradients + the stack of `split_groups`' backward.  None when it does not apply."""
+        bases = getattr(enc, "bases", None)
+        if bases is None or not getattr(self.opt, "regroup", True):
+            return None
+        if any((not b.is_cuda) or b.dtype != torch.float32 for b in bases):
+            return None
+        from . import ops
+        per_level = [ops.regroup(b, enc.G, plans) for b in bases]
+        return [[lvl[k] for lvl in per_level] for k in range(len(plans))]
+
     def _encode_many(self, name, imgs):
         """Encoder on G independent inputs -> per input, its feature pyramid.  Grouped: one call
         on the interleaved batch with per-call BatchNorm statistics."""
@@ -474,23 +495,28 @@ class Trainer(HotPathLosses):
         with grouped.grouped(self.models[name], G):
             feats = self._encode(name, grouped.merge_groups(imgs))
         per_level = [grouped.split_groups(f, G) for f in feats]
-        return [[lvl[g] for lvl in per_level] for g in range(G)]
+        out = _GroupedPyramids([lvl[g] for lvl in per_level] for g in range(G))
+        out.bases, out.G = list(feats), G
+        return out
 
-    def _depth_many(self, decoder, feats_list):
-        """Depth decoder on G feature pyramids -> per input {("disp", s): fp32 disparity}."""
+    def _depth_many(self, decoder, feats_list, merged=None):
+        """Depth decoder on G feature pyramids -> per input {("disp", s): fp32 disparity}.
+        `merged`: the interleaved batch of the pyramids per level, when the caller already has it."""
         if not self.opt.group_calls or len(feats_list) == 1:
             return [self._depth(decoder, f) for f in feats_list]
         G = len(feats_list)
-        merged = [grouped.merge_groups([f[l] for f in feats_list]) for l in range(len(feats_list[0]))]
+        if merged is None:
+            merged = [grouped.merge_groups([f[l] for f in feats_list]) for l in range(len(feats_list[0]))]
         # a no-op today (no decoder has BatchNorm); keeps per-call statistics if one ever does
         with grouped.grouped(self.models[decoder], G):
             out = self._depth(decoder, merged)
         split = {k: grouped.split_groups(v, G) for k, v in out.items()}
         return [{k: split[k][g] for k in out} for g in range(G)]
 
-    def _fuse_many(self, jobs):
+    def _fuse_many(self, jobs, merged_feats=None):
         """jobs: (three feature pyramids, two flows, merge mask) per fused frame
-        (reference: train.py:788-812) -> per job {("disp", s)} of the multi-frame decoder."""
+        (reference: train.py:788-812) -> per job {("disp", s)} of the multi-frame decoder.
+        `merged_feats`: [position][level] interleaved batches over the jobs, when the caller already has them."""
         def one(feats, fl, mask):
             f = self._nets(lambda: self.models["fusion_module"](
                 [[t.float() for t in lvl] for lvl in feats], fl, mask))
@@ -498,7 +524,8 @@ class Trainer(HotPathLosses):
         if not self.opt.group_calls or len(jobs) == 1:
             return [one(*j) for j in jobs]
         G, L = len(jobs), len(jobs[0][0][0])
-        feats = [[grouped.merge_groups([j[0][pos][l] for j in jobs]) for l in range(L)] for pos in range(3)]
+        feats = merged_feats if merged_feats is not None else \
+            [[grouped.merge_groups([j[0][pos][l] for j in jobs]) for l in range(L)] for pos in range(3)]
         flows = [grouped.merge_groups([j[1][k] for j in jobs]) for k in range(2)]
         mask = grouped.merge_groups([j[2] for j in jobs])
         with grouped.grouped(self.models["fusion_module"], G), grouped.grouped(self.models["depth_mf"], G):
@@ -583,9 +610,22 @@ class Trainer(HotPathLosses):
         enc = self._encode_many("encoder", enc_in)
         feats_0, feats_nt, feats_pt = enc[0], enc[1], enc[2]
         feats_aff = enc[-3:] if o.use_affine else []
+        # which encoder inputs (positions in enc_in) each consumer takes: the single-frame decoder call, and
+        # the three pyramids (previous / centre / next) of the three fusion jobs below
+        n_in = len(enc_in)
+        dec_plan = [0, 2, 1] + ([n_in - 3, n_in - 2, n_in - 1] if o.use_affine else [])
+        fuse_plans = [[3, 3, 0], [0, 1, 2], [4, 0, 4]]       # [feats_n1, feats_n1, feats_0], [feats_0, feats_nt, feats_pt], ...
+        pre = pre_mf = None
+        if o.group_calls:
+            if o.fuse_model_type != "separate_all":
+                pre = self._regroup(enc, [dec_plan] + fuse_plans)
+                pre_mf = pre[1:] if pre is not None else None
+            else:
+                pre = self._regroup(enc, [dec_plan])
 
         # ---- single-frame depths (plain and affine views share the decoder)
-        dec = self._depth_many("depth", [feats_0, feats_pt, feats_nt] + feats_aff)
+        dec = self._depth_many("depth", [feats_0, feats_pt, feats_nt] + feats_aff,
+                               merged=pre[0] if pre is not None else None)
         disp_0, disp_pt, disp_nt = dec[0], dec[1], dec[2]
         def to_depth(d):
             # by-product of the decoder's disparity-head epilogue when it ran fused
@@ -614,14 +654,15 @@ class Trainer(HotPathLosses):
 
         # ---- multi-frame depths
         if o.fuse_model_type == "separate_all":
-            feats_0, feats_nt, feats_pt, feats_n1, feats_p1 = self._encode_many(
-                "encoder_mf", [aug(0), img_nt, img_pt, aug(-1), aug(1)])
+            enc_mf = self._encode_many("encoder_mf", [aug(0), img_nt, img_pt, aug(-1), aug(1)])
+            feats_0, feats_nt, feats_pt, feats_n1, feats_p1 = enc_mf
+            pre_mf = self._regroup(enc_mf, fuse_plans) if o.group_calls else None
         else:
             feats_n1, feats_p1 = enc[3], enc[4]
         fused = self._fuse_many([
             ([feats_n1, feats_0, feats_p1], [flow_0_n1, flow_0_p1], merge_mask_01),
             ([feats_n1, feats_nt, feats_0], [flow_nt_n1, flow_nt_0], merge_mask_nt),
-            ([feats_0, feats_pt, feats_p1], [flow_pt_0, flow_pt_p1], merge_mask_pt)])
+            ([feats_0, feats_pt, feats_p1], [flow_pt_0, flow_pt_p1], merge_mask_pt)], merged_feats=pre_mf)
         disp_0_fuse, disp_nt_fuse, disp_pt_fuse = fused
         depth_0_fuse, depth_nt_fuse, depth_pt_fuse = (to_depth(d) for d in fused)
 
