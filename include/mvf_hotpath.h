@@ -367,9 +367,18 @@ MVF_API int mvf_regroup_fwd(const float *src, int G, int B, int64_t chunk, int n
                     const int32_t *counts, const int32_t *groups, void *stream);
 /* adjoint: g_src [B*G, chunk] = per source group the sum of the gradients of the slots that read
  * it, in (output, position) order; groups nobody read (or whose outputs have g_dst[k] == NULL:
- * not differentiated) get zeros.  Written once, deterministic. */
-MVF_API int mvf_regroup_bwd(const float *const *g_dst, int G, int B, int64_t chunk, int n_out,
-                    const int32_t *counts, const int32_t *groups, float *g_src, void *stream);
+ * not differentiated) get zeros.  Written once, deterministic.  g_strides (HOST, nullable = chunk):
+ * elements between consecutive samples of g_dst[k] (>= chunk: a gradient that is a channel slice
+ * of a wider tensor is read in place). */
+MVF_API int mvf_regroup_bwd(const float *const *g_dst, const int64_t *g_strides, int G, int B, int64_t chunk,
+                    int n_out, const int32_t *counts, const int32_t *groups, float *g_src, void *stream);
+/* Input side of a grouped call: n_slots separate tensors src[s] [B, len[s]] -> dst [B*G, total],
+ * sample b*G + group[s] holding part s at element offset[s] (e.g. the two frames of each of the
+ * six pose pairs of a step, train.py:943-946 / 724-731, as one [B*6, 6*H*W] batch).  HOST arrays,
+ * n_slots <= 32; forward only (the parts are images). */
+MVF_API int mvf_interleave_fwd(const float *const *src, const int64_t *len, const int64_t *offset,
+                       const int32_t *group, int n_slots, float *dst, int G, int B, int64_t total,
+                       void *stream);
 
 /* ---- f4: step glue either side of the hot path ------------------
  * Decoder stage glue (networks/monodepth2.py:84-90 with layers.py:121-138, 225-228): the padded
@@ -483,7 +492,8 @@ MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32
 #define MVF_PROF_AFFINE 31           /* affine transform / restore kernels */
 #define MVF_PROF_REGROUP_FWD 32      /* k_regroup_fwd */
 #define MVF_PROF_REGROUP_BWD 33      /* k_regroup_bwd */
-#define MVF_PROF_COUNT 34
+#define MVF_PROF_INTERLEAVE_FWD 34   /* k_interleave_fwd */
+#define MVF_PROF_COUNT 35
 /* launch tags of MVF_PROF_UNIT_FWDBWD (mvf_profile_read_launches): what kind of unit group a launch carried */
 #define MVF_TAG_SINGLE_FRAME 0  /* identity candidates evaluated (and possibly handed over: ident_out) */
 #define MVF_TAG_MULTI_FRAME 1   /* identity maps taken from another unit (ident_in) */

@@ -1069,6 +1069,7 @@ __global__ void __launch_bounds__(NT) k_jitter_apply(const float *__restrict__ i
 constexpr int RG_MAX_OUT = 8, RG_MAX_SLOTS = 32;
 struct RegroupPlan {
     float *out[RG_MAX_OUT];                 // forward: outputs; backward: their gradients (nullable)
+    int64_t ostride[RG_MAX_OUT];            // distance between consecutive samples of an output, in kernel elements
     int gk[RG_MAX_OUT];                     // groups per output
     unsigned char slot_k[RG_MAX_SLOTS], slot_j[RG_MAX_SLOTS], slot_g[RG_MAX_SLOTS];
     unsigned char first[RG_MAX_SLOTS + 1];  // backward: slots [first[g], first[g+1]) of `by_g` read source group g
@@ -1116,7 +1117,7 @@ __global__ void __launch_bounds__(NT) k_regroup_bwd(float *__restrict__ g_src, R
         for (int u = 0; u < U; ++u) acc[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         for (int e = lo; e < hi; ++e) {
             const int s = pl.by_g[e], k = pl.slot_k[s];
-            const float4 *__restrict__ gp = reinterpret_cast<const float4 *>(pl.out[k]) + ((int64_t)b * pl.gk[k] + pl.slot_j[s]) * per;
+            const float4 *__restrict__ gp = reinterpret_cast<const float4 *>(pl.out[k]) + ((int64_t)b * pl.gk[k] + pl.slot_j[s]) * pl.ostride[k];
             float4 v[U];
 #pragma unroll
             for (int u = 0; u < U; ++u)
@@ -1139,7 +1140,7 @@ __global__ void __launch_bounds__(NT) k_regroup_bwd(float *__restrict__ g_src, R
             float acc = 0.0f;
             for (int e = lo; e < hi; ++e) {
                 const int s = pl.by_g[e], k = pl.slot_k[s];
-                const float v = pl.out[k][((int64_t)b * pl.gk[k] + pl.slot_j[s]) * per + q];
+                const float v = pl.out[k][((int64_t)b * pl.gk[k] + pl.slot_j[s]) * pl.ostride[k] + q];
                 acc = (e == lo) ? v : acc + v;
             }
             g_src[so + q] = acc;
@@ -1147,10 +1148,44 @@ __global__ void __launch_bounds__(NT) k_regroup_bwd(float *__restrict__ g_src, R
     }
 }
 
+// ---- G x P separate [B, len] tensors -> ONE interleaved group batch (input side of a grouped call) -------------
+// dst sample b * G + g = the parts of group g back to back (e.g. the two frames of a pose pair, train.py:943-946,
+// for the six pairs of a step: the reference concatenates per call; here cat per pair + stack of the pairs were
+// seven ATen launches moving every image twice).  Forward only: the inputs are images.
+constexpr int IL_MAX_SLOTS = 32;
+struct InterleavePlan {
+    const float *src[IL_MAX_SLOTS];
+    int64_t len[IL_MAX_SLOTS], off[IL_MAX_SLOTS];     // part length and offset inside the destination sample
+    unsigned char group[IL_MAX_SLOTS];
+};
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_interleave_fwd(InterleavePlan pl, float *__restrict__ dst, int G, int64_t total)
+{
+    constexpr int U = 4;
+    const int s = blockIdx.y, b = blockIdx.z;
+    const int64_t len = pl.len[s], q0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x;
+    if ((int64_t)blockIdx.x * (NT * U) >= len) return;
+    const float *__restrict__ src = pl.src[s];
+    const int64_t so = (int64_t)b * len, dof = ((int64_t)b * G + pl.group[s]) * total + pl.off[s];
+    if (VEC) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * NT < len) v[u] = reinterpret_cast<const float4 *>(src)[so + q0 + u * NT];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * NT < len) reinterpret_cast<float4 *>(dst)[dof + q0 + u * NT] = v[u];
+    } else {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q0 + u * NT < len) dst[dof + q0 + u * NT] = src[so + q0 + u * NT];
+    }
+}
+
 // host side of both directions: the plan from (counts, groups); slots whose output pointer is null are left out
 // (backward: an output nobody differentiated)
 static int regroup_plan(RegroupPlan &pl, float *const *out, int n_out, const int32_t *counts, const int32_t *groups,
-                        int G, bool skip_null, bool &vec_ok)
+                        int G, bool skip_null, bool &vec_ok, int64_t chunk, const int64_t *strides = nullptr)
 {
     if (n_out <= 0 || n_out > RG_MAX_OUT || G <= 0 || G > RG_MAX_SLOTS || !counts || !groups || !out)
         return (int)hipErrorInvalidValue;
@@ -1159,8 +1194,10 @@ static int regroup_plan(RegroupPlan &pl, float *const *out, int n_out, const int
         if (counts[k] <= 0) return (int)hipErrorInvalidValue;
         pl.out[k] = out[k];
         pl.gk[k] = counts[k];
+        pl.ostride[k] = strides ? strides[k] : chunk;
         if (!out[k] && !skip_null) return (int)hipErrorInvalidValue;
-        if (out[k] && (((uintptr_t)out[k]) & 15)) vec_ok = false;
+        if (out[k] && pl.ostride[k] < chunk) return (int)hipErrorInvalidValue;
+        if (out[k] && ((((uintptr_t)out[k]) & 15) || (pl.ostride[k] & 3))) vec_ok = false;
         for (int j = 0; j < counts[k]; ++j, ++at) {
             const int g = groups[at];
             if (g < 0 || g >= G) return (int)hipErrorInvalidValue;
@@ -1170,7 +1207,9 @@ static int regroup_plan(RegroupPlan &pl, float *const *out, int n_out, const int
             ++ns;
         }
     }
-    for (int k = n_out; k < RG_MAX_OUT; ++k) { pl.out[k] = nullptr; pl.gk[k] = 0; }
+    for (int k = n_out; k < RG_MAX_OUT; ++k) { pl.out[k] = nullptr; pl.gk[k] = 0; pl.ostride[k] = 0; }
+    if (vec_ok)
+        for (int k = 0; k < n_out; ++k) pl.ostride[k] /= 4;
     pl.nslots = ns;
     int e = 0;
     for (int g = 0; g < G; ++g) {               // stable: slot order within a group = (output, position) order
@@ -1456,7 +1495,7 @@ int mvf_regroup_fwd(const float *src, int G, int B, int64_t chunk, int n_out, fl
     if (!src || B > 65535 || (int64_t)B * G * chunk > 0x7fffffffffffLL) return (int)hipErrorInvalidValue;
     RegroupPlan pl;
     bool vec = (chunk & 3) == 0 && (((uintptr_t)src) & 15) == 0;
-    const int err = regroup_plan(pl, dst, n_out, counts, groups, G, false, vec);
+    const int err = regroup_plan(pl, dst, n_out, counts, groups, G, false, vec, chunk);
     if (err) return err;
     const int64_t per = vec ? chunk / 4 : chunk, blocks = (per + NT * 4 - 1) / (NT * 4);
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -1468,14 +1507,15 @@ int mvf_regroup_fwd(const float *src, int G, int B, int64_t chunk, int n_out, fl
     return hip_check_launch();
 }
 
-int mvf_regroup_bwd(const float *const *g_dst, int G, int B, int64_t chunk, int n_out, const int32_t *counts,
-                    const int32_t *groups, float *g_src, void *stream)
+int mvf_regroup_bwd(const float *const *g_dst, const int64_t *g_strides, int G, int B, int64_t chunk, int n_out,
+                    const int32_t *counts, const int32_t *groups, float *g_src, void *stream)
 {
     if (B <= 0 || chunk <= 0) return 0;
     if (!g_src || B > 65535 || (int64_t)B * G * chunk > 0x7fffffffffffLL) return (int)hipErrorInvalidValue;
     RegroupPlan pl;
     bool vec = (chunk & 3) == 0 && (((uintptr_t)g_src) & 15) == 0;
-    const int err = regroup_plan(pl, const_cast<float *const *>(g_dst), n_out, counts, groups, G, true, vec);
+    const int err = regroup_plan(pl, const_cast<float *const *>(g_dst), n_out, counts, groups, G, true, vec, chunk,
+                                 g_strides);
     if (err) return err;
     const int64_t per = vec ? chunk / 4 : chunk, blocks = (per + NT * 4 - 1) / (NT * 4);
     if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
@@ -1484,6 +1524,39 @@ int mvf_regroup_bwd(const float *const *g_dst, int G, int B, int64_t chunk, int 
     const dim3 grid((unsigned)blocks, (unsigned)G, (unsigned)B);
     if (vec) hipLaunchKernelGGL(k_regroup_bwd<true>, grid, dim3(NT), 0, (hipStream_t)stream, g_src, pl, G, per);
     else hipLaunchKernelGGL(k_regroup_bwd<false>, grid, dim3(NT), 0, (hipStream_t)stream, g_src, pl, G, per);
+    return hip_check_launch();
+}
+
+
+int mvf_interleave_fwd(const float *const *src, const int64_t *len, const int64_t *offset, const int32_t *group,
+                       int n_slots, float *dst, int G, int B, int64_t total, void *stream)
+{
+    if (B <= 0 || total <= 0 || n_slots <= 0) return 0;
+    if (!src || !len || !offset || !group || !dst || n_slots > IL_MAX_SLOTS || G <= 0 || G > 255 || B > 65535)
+        return (int)hipErrorInvalidValue;
+    InterleavePlan pl;
+    bool vec = (total & 3) == 0 && (((uintptr_t)dst) & 15) == 0;
+    int64_t longest = 0, moved = 0;
+    for (int s = 0; s < n_slots; ++s) {
+        if (!src[s] || len[s] <= 0 || offset[s] < 0 || offset[s] + len[s] > total || group[s] < 0 || group[s] >= G)
+            return (int)hipErrorInvalidValue;
+        if ((len[s] & 3) || (offset[s] & 3) || (((uintptr_t)src[s]) & 15)) vec = false;
+        longest = len[s] > longest ? len[s] : longest;
+        moved += len[s];
+    }
+    for (int s = 0; s < IL_MAX_SLOTS; ++s) {
+        const bool on = s < n_slots;
+        pl.src[s] = on ? src[s] : nullptr;
+        pl.len[s] = on ? (vec ? len[s] / 4 : len[s]) : 0;
+        pl.off[s] = on ? (vec ? offset[s] / 4 : offset[s]) : 0;
+        pl.group[s] = on ? (unsigned char)group[s] : 0;
+    }
+    const int64_t per = vec ? longest / 4 : longest, blocks = (per + NT * 4 - 1) / (NT * 4);
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_INTERLEAVE_FWD, stream, 8LL * B * moved);     // every part read once, written once
+    const dim3 grid((unsigned)blocks, (unsigned)n_slots, (unsigned)B);
+    if (vec) hipLaunchKernelGGL(k_interleave_fwd<true>, grid, dim3(NT), 0, (hipStream_t)stream, pl, dst, G, total / 4);
+    else hipLaunchKernelGGL(k_interleave_fwd<false>, grid, dim3(NT), 0, (hipStream_t)stream, pl, dst, G, total);
     return hip_check_launch();
 }
 

@@ -1210,15 +1210,21 @@ class Regroup(torch.autograd.Function):
         if not live:
             return None, None, None
         nat.require_device(*live)
-        gouts = [None if g is None else _c(g) for g in gouts]
         g_src = torch.empty(shape, dtype=torch.float32, device=live[0].device)
         B = shape[0] // G
         chunk = g_src[0].numel()
+
+        def in_place(g):
+            # a gradient whose samples are contiguous but further apart than their size (a channel slice of a
+            # wider tensor: the fusion level's gradient of its centre features) is read where it is
+            return g.shape[0] <= 1 or (g[0].is_contiguous() and g.stride(0) >= chunk)
+        gouts = [None if g is None else (g if in_place(g) else _c(g)) for g in gouts]
+        strides = (C.c_int64 * len(gouts))(*[chunk if (g is None or g.shape[0] <= 1) else g.stride(0) for g in gouts])
         counts = (C.c_int32 * len(plans))(*[len(p) for p in plans])
         flat = [g for p in plans for g in p]
         groups = (C.c_int32 * len(flat))(*flat)
         arr = (C.c_void_p * len(gouts))(*[None if g is None else g.data_ptr() for g in gouts])
-        nat.check(nat.lib().mvf_regroup_bwd(C.cast(arr, C.c_void_p), G, B, chunk, len(plans), counts, groups,
+        nat.check(nat.lib().mvf_regroup_bwd(C.cast(arr, C.c_void_p), strides, G, B, chunk, len(plans), counts, groups,
                                             nat.ptr(g_src), _stream()), "regroup_bwd")
         return g_src, None, None
 
@@ -1226,6 +1232,46 @@ class Regroup(torch.autograd.Function):
 def regroup(src, groups, plans):
     """-> tuple of interleaved batches, one per plan (see `Regroup`)."""
     return Regroup.apply(src, groups, plans)
+
+
+def interleave_groups(parts):
+    """``merge_groups([torch.cat(p, 1) for p in parts])`` in ONE launch: ``parts[g]`` = the tensors ``[B, C_i, ...]``
+    whose channel concatenation is input g of a grouped call -> ``[B*G, sum C_i, ...]`` interleaved (sample
+    b*G + g).  Forward only (the inputs of the grouped encoder / pose calls are images: reference
+    train.py:724-731, 943-946)."""
+    G = len(parts)
+    flat = [t for p in parts for t in p]
+    nat.require_device(*flat)
+    if any(t.requires_grad for t in flat) and torch.is_grad_enabled():
+        raise RuntimeError("interleave_groups is forward-only; inputs that need a gradient go through merge_groups")
+    if any(t.dtype != torch.float32 for t in flat):
+        raise RuntimeError("interleave_groups: float32 only")
+    B, tail = flat[0].shape[0], tuple(flat[0].shape[2:])
+    widths = [sum(t.shape[1] for t in p) for p in parts]
+    if G == 0 or len(set(widths)) != 1 or any(t.shape[0] != B or tuple(t.shape[2:]) != tail for t in flat):
+        raise RuntimeError("interleave_groups: every group must concatenate to the same [B, C, ...] shape")
+    if len(flat) > 32:
+        raise RuntimeError("interleave_groups: at most 32 parts")
+    flat = [_c(t) for t in flat]
+    inner = 1
+    for d in tail:
+        inner *= int(d)
+    total = widths[0] * inner
+    out = flat[0].new_empty((B * G, widths[0]) + tail)
+    lens, offs, grp = [], [], []
+    for g, p in enumerate(parts):
+        at = 0
+        for t in p:
+            lens.append(t.shape[1] * inner)
+            offs.append(at)
+            grp.append(g)
+            at += t.shape[1] * inner
+    n = len(flat)
+    src, keep = nat.ptr_array(flat)
+    nat.check(nat.lib().mvf_interleave_fwd(src, (C.c_int64 * n)(*lens), (C.c_int64 * n)(*offs), (C.c_int32 * n)(*grp), n,
+                                           nat.ptr(out), G, B, total, _stream()), "interleave_fwd")
+    del keep
+    return out
 
 
 class MaxPool3s2(torch.autograd.Function):

@@ -486,6 +486,16 @@ class Trainer(HotPathLosses):
         per_level = [ops.regroup(b, enc.G, plans) for b in bases]
         return [[lvl[k] for lvl in per_level] for k in range(len(plans))]
 
+    def _merge_inputs(self, parts):
+        """Input of a grouped call: per group, the tensors whose channel concatenation is that call's input ->
+        the interleaved batch.  Images (no gradient) on the device go through one gather launch."""
+        flat = [t for p in parts for t in p]
+        if (getattr(self.opt, "regroup", True) and len(flat) <= 32 and
+                all(t.is_cuda and t.dtype == torch.float32 and not t.requires_grad for t in flat)):
+            from . import ops
+            return ops.interleave_groups(parts)
+        return grouped.merge_groups([p[0] if len(p) == 1 else torch.cat(p, 1) for p in parts])
+
     def _encode_many(self, name, imgs):
         """Encoder on G independent inputs -> per input, its feature pyramid.  Grouped: one call
         on the interleaved batch with per-call BatchNorm statistics."""
@@ -493,7 +503,7 @@ class Trainer(HotPathLosses):
             return [self._encode(name, im) for im in imgs]
         G = len(imgs)
         with grouped.grouped(self.models[name], G):
-            feats = self._encode(name, grouped.merge_groups(imgs))
+            feats = self._encode(name, self._merge_inputs([[im] for im in imgs]))
         per_level = [grouped.split_groups(f, G) for f in feats]
         out = _GroupedPyramids([lvl[g] for lvl in per_level] for g in range(G))
         out.bases, out.G = list(feats), G
@@ -538,7 +548,7 @@ class Trainer(HotPathLosses):
         if not self.opt.group_calls or len(pairs) == 1:
             return [self.predict_poses(a, b) for a, b in pairs]
         G = len(pairs)
-        x = grouped.merge_groups([torch.cat([a, b], 1) for a, b in pairs])
+        x = self._merge_inputs([[a, b] for a, b in pairs])
         with grouped.grouped(self.models["pose_encoder"], G):
             feats = [self._encode("pose_encoder", x)]
         axisangle, translation = self._nets(lambda: self.models["pose"]([[f.float() for f in feats[0]]]))

@@ -1308,3 +1308,40 @@ def test_regroup_rejects_bad_plans():
         ops.regroup(x, 3, ((0,), ()))         # empty plan
     with pytest.raises(RuntimeError):
         ops.regroup(x.cpu(), 3, ((0,),))      # no CPU fallback
+
+
+def test_regroup_adjoint_reads_channel_slices_in_place():
+    """A gradient that is a channel slice of a wider tensor (what the fusion level hands back for its centre
+    features) is read where it lies: same result as from a contiguous copy."""
+    from mono_vifi_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    G, B, C, h, w = 5, 3, 8, 6, 12
+    plans = ((0, 2, 1), (3, 3, 0), (0, 1, 2))
+    x = torch.randn((B * G, C, h, w), device="cuda", generator=g)
+    res = []
+    for sliced in (True, False):
+        xa = x.clone().requires_grad_(True)
+        outs = ops.regroup(xa, G, plans)
+        wide = torch.randn((B * 3, C + 7, h, w), device="cuda", generator=torch.Generator(device="cuda").manual_seed(9))
+        g1 = wide[:, :C] if sliced else wide[:, :C].contiguous()
+        assert g1.is_contiguous() != sliced
+        torch.autograd.backward([outs[0], outs[1], outs[2]], [torch.ones_like(outs[0]), g1, 2 * torch.ones_like(outs[2])])
+        res.append(xa.grad.clone())
+    assert torch.equal(res[0], res[1])
+
+
+@pytest.mark.parametrize("shape,groups,parts", [((12, 3, 16, 20), 6, 2), ((2, 3, 5, 7), 3, 2), ((4, 3, 8, 8), 8, 1)])
+def test_interleave_groups_equals_cat_and_stack(shape, groups, parts):
+    """One gather launch == merge_groups([cat(parts, 1) ...]) (a copy: bit-exact); chunk % 4 != 0 takes the scalar route."""
+    from mono_vifi_amd import ops
+    from mono_vifi_amd.networks import grouped
+    g = torch.Generator(device="cuda").manual_seed(2)
+    ts = [[torch.randn(shape, device="cuda", generator=g) for _ in range(parts)] for _ in range(groups)]
+    ts[0][0] = ts[1][-1]                      # the same image in two groups (a frame shared by two pose pairs)
+    ref = grouped.merge_groups([torch.cat(p, 1) for p in ts])
+    got = ops.interleave_groups(ts)
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    with pytest.raises(RuntimeError):
+        ops.interleave_groups([[ts[0][0]], [ts[1][0][:, :2]]])          # groups of different widths
+    with pytest.raises(RuntimeError):
+        ops.interleave_groups([[ts[0][0].clone().requires_grad_(True)]])    # forward-only

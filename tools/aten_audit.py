@@ -18,6 +18,67 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def trace_copies(step, a):
+    """Forward-pass data movement by call site: bytes written by cat / stack / contiguous / clone / float()."""
+    import traceback
+    import torch
+    log = collections.defaultdict(lambda: [0, 0])
+
+    def site():
+        frames = [f"{os.path.basename(fr.filename)}:{fr.lineno} {fr.name}"
+                  for fr in reversed(traceback.extract_stack()[:-2])
+                  if "mono" in fr.filename and "tools/" not in fr.filename]
+        return " < ".join(frames[:3]) if frames else "?"
+
+    def note(kind, out):
+        if torch.is_tensor(out) and out.is_cuda:
+            k = (kind, site(), tuple(out.shape))
+            log[k][0] += 1
+            log[k][1] += out.numel() * out.element_size()
+
+    o_cat, o_stack, o_contig, o_clone = torch.cat, torch.stack, torch.Tensor.contiguous, torch.Tensor.clone
+
+    def cat(*x, **k):
+        r = o_cat(*x, **k)
+        note("cat", r)
+        return r
+
+    def stack(*x, **k):
+        r = o_stack(*x, **k)
+        note("stack", r)
+        return r
+
+    def contiguous(self, *x, **k):
+        was = self.is_contiguous(*x, **k) if not x else True
+        r = o_contig(self, *x, **k)
+        if not was:
+            note("contiguous", r)
+        return r
+
+    def clone(self, *x, **k):
+        r = o_clone(self, *x, **k)
+        note("clone", r)
+        return r
+
+    torch.cat, torch.stack, torch.Tensor.contiguous, torch.Tensor.clone = cat, stack, contiguous, clone
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        torch.cat, torch.stack, torch.Tensor.contiguous, torch.Tensor.clone = o_cat, o_stack, o_contig, o_clone
+    rows = sorted(log.items(), key=lambda kv: -kv[1][1])
+    out = [f"# {a.backbone} B{a.batch} {a.width}x{a.height}: forward-pass copies of one step by call site (bytes WRITTEN; "
+           f"each is read once too)", f"{'MB':>9} {'calls':>6}  kind | call site | shape"]
+    for (kind, where, shape), (n, by) in rows[:a.top]:
+        out.append(f"{by / 1e6:9.1f} {n:6d}  {kind} | {where} | {list(shape)}")
+    out.append(f"total {sum(v[1] for v in log.values()) / 1e9:.2f} GB written by {sum(v[0] for v in log.values())} calls")
+    text = "\n".join(out)
+    path = os.path.join(ROOT, "gpurun_out", f"aten_copies_{a.backbone}.txt")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    open(path, "w").write(text + "\n")
+    print(text)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--backbone", default="ResNet18")
@@ -26,6 +87,9 @@ def main():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--top", type=int, default=60)
+    ap.add_argument("--copies", action="store_true",
+                    help="instead of the profiler: log every torch.cat / stack / non-trivial .contiguous() / clone of the "
+                         "forward pass with its bytes and Python call site")
     a = ap.parse_args()
     import mono_vifi_amd as pkg
     pkg.use_shipped_miopen_db()
@@ -38,6 +102,9 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    if a.copies:
+        trace_copies(step, a)
+        return
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True,
                  with_stack=True) as prof:
         for _ in range(a.steps):
