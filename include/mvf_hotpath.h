@@ -438,6 +438,12 @@ MVF_API int mvf_upsample_nearest_bwd(const float *g_out, float *g_x, int planes,
 MVF_API int mvf_maxpool3s2_fwd(const float *x, float *out, uint8_t *idx, int planes, int H, int W, void *stream);
 MVF_API int mvf_maxpool3s2_bwd(const float *g_out, const uint8_t *idx, float *g_x, int planes, int H, int W,
                        void *stream);
+/* the same adjoint with the gradient the pooled tensor received from its OTHER consumer added in
+ * the pass: g_x = addend + gather (the stem output of the depth encoder is both pooled and a
+ * feature of the pyramid, monodepth2.py:36-41: autograd's separate accumulation pass read both
+ * full-size tensors again).  addend [planes,H,W], may alias nothing else. */
+MVF_API int mvf_maxpool3s2_bwd_add(const float *g_out, const uint8_t *idx, const float *addend, float *g_x,
+                           int planes, int H, int W, void *stream);
 /* On-device colour augmentation of the data pipeline (datasets/mono_dataset.py:102-184, 214-256:
  * do_flip, do_color_aug with one torchvision ColorJitter draw per sample applied to all of its
  * frames).  img [samples*frames,3,H,W] (frame-minor), factors [samples,4] = {brightness, contrast,

@@ -775,9 +775,10 @@ __global__ void __launch_bounds__(NT) k_maxpool3s2_fwd(const float *__restrict__
         }
 }
 
+template <bool ADD>   // ADD: gx = addend + gathered gradient (the pooled tensor's other consumer, see mvf_maxpool3s2_bwd_add)
 __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd(const float *__restrict__ g, const uint8_t *__restrict__ idx,
-                                                       float *__restrict__ gx, int planes, int H, int W, int OH,
-                                                       int OW)
+                                                       const float *__restrict__ addend, float *__restrict__ gx,
+                                                       int planes, int H, int W, int OH, int OW)
 {
     const int i = blockIdx.x * NT + threadIdx.x;
     if (i >= H * W) return;
@@ -814,7 +815,7 @@ __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd(const float *__restrict__
         if (vx && c[k][1] == (uint8_t)(cy0 + cx1)) acc += v[k][1];
         if (vy && c[k][2] == (uint8_t)(cy1 + cx0)) acc += v[k][2];
         if (vy && vx && c[k][3] == (uint8_t)(cy1 + cx1)) acc += v[k][3];
-        gx[(size_t)(p0 + k) * ni + i] = acc;
+        gx[(size_t)(p0 + k) * ni + i] = ADD ? addend[(size_t)(p0 + k) * ni + i] + acc : acc;
     }
 }
 
@@ -893,9 +894,10 @@ MVF_DEV float pool_gather(const float (&wg)[2][3], const uint8_t (&wc)[2][3], in
     if (oddy && vy1 && oddx && vx[c1] && wc[1][c1] == (uint8_t)(cy1 + cx1)) acc += wg[1][c1];
     return acc;
 }
+template <bool ADD>
 __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd_w4(const float *__restrict__ g, const uint8_t *__restrict__ idx,
-                                                          float *__restrict__ gx, int planes, int H, int W, int OH,
-                                                          int OW)
+                                                          const float *__restrict__ addend, float *__restrict__ gx,
+                                                          int planes, int H, int W, int OH, int OW)
 {
     const int W4 = W >> 2, H2 = H >> 1;            // H even, W % 4 == 0
     const int i = blockIdx.x * NT + threadIdx.x;
@@ -910,6 +912,7 @@ __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd_w4(const float *__restric
     float g2[PLW][2];
     uchar2 c01[PLW][2];
     uint8_t c2[PLW][2];
+    float4 ad[PLW][2];
 #pragma unroll
     for (int k = 0; k < PLW; ++k) {
         const size_t pb = (size_t)min(p0 + k, planes - 1) * no;
@@ -920,6 +923,9 @@ __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd_w4(const float *__restric
             g2[k][r] = g[o + ox2];
             c01[k][r] = *reinterpret_cast<const uchar2 *>(idx + o + 2 * b);
             c2[k][r] = idx[o + ox2];
+            if (ADD)
+                ad[k][r] = *reinterpret_cast<const float4 *>(addend + (size_t)min(p0 + k, planes - 1) * ni +
+                                                             (size_t)(2 * a + r) * W + 4 * b);
         }
     }
 #pragma unroll
@@ -940,6 +946,7 @@ __global__ void __launch_bounds__(NT) k_maxpool3s2_bwd_w4(const float *__restric
             v.y = pool_gather(wg, wc, ry, 1, vy1, vx);
             v.z = pool_gather(wg, wc, ry, 2, vy1, vx);
             v.w = pool_gather(wg, wc, ry, 3, vy1, vx);
+            if (ADD) { v.x = ad[k][ry].x + v.x; v.y = ad[k][ry].y + v.y; v.z = ad[k][ry].z + v.z; v.w = ad[k][ry].w + v.w; }
             *reinterpret_cast<float4 *>(op + (size_t)ry * W) = v;
         }
     }
@@ -1472,20 +1479,35 @@ int mvf_maxpool3s2_fwd(const float *x, float *out, uint8_t *idx, int planes, int
     return hip_check_launch();
 }
 
-int mvf_maxpool3s2_bwd(const float *g_out, const uint8_t *idx, float *g_x, int planes, int H, int W, void *stream)
+static int maxpool3s2_bwd_any(const float *g_out, const uint8_t *idx, const float *addend, float *g_x, int planes, int H,
+                              int W, void *stream)
 {
     if (planes <= 0 || H <= 0 || W <= 0) return 0;
     if (!g_out || !idx || !g_x || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-    ProfScope ps(MVF_PROF_MAXPOOL_BWD, stream, (int64_t)planes * (4LL * H * W + 5LL * OH * OW));
-    if (pool_wide_ok(g_x, g_out, idx, H, W) && (H & 1) == 0 && !getenv("MVF_POOL_NARROW")) {
-        hipLaunchKernelGGL(k_maxpool3s2_bwd_w4, dim3((unsigned)(((H / 2) * (W / 4) + NT - 1) / NT), (unsigned)((planes + PLW - 1) / PLW)),
-                           dim3(NT), 0, (hipStream_t)stream, g_out, idx, g_x, planes, H, W, OH, OW);
-        return hip_check_launch();
-    }
-    hipLaunchKernelGGL(k_maxpool3s2_bwd, dim3((unsigned)((H * W + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
-                       dim3(NT), 0, (hipStream_t)stream, g_out, idx, g_x, planes, H, W, OH, OW);
+    ProfScope ps(MVF_PROF_MAXPOOL_BWD, stream, (int64_t)planes * ((addend ? 8LL : 4LL) * H * W + 5LL * OH * OW));
+    const bool wide = pool_wide_ok(g_x, g_out, idx, H, W) && (H & 1) == 0 && !getenv("MVF_POOL_NARROW") &&
+                      (((uintptr_t)addend) & 15) == 0;
+    const dim3 gw((unsigned)(((H / 2) * (W / 4) + NT - 1) / NT), (unsigned)((planes + PLW - 1) / PLW));
+    const dim3 gn((unsigned)((H * W + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR));
+    hipStream_t st = (hipStream_t)stream;
+    if (wide && addend) hipLaunchKernelGGL(k_maxpool3s2_bwd_w4<true>, gw, dim3(NT), 0, st, g_out, idx, addend, g_x, planes, H, W, OH, OW);
+    else if (wide) hipLaunchKernelGGL(k_maxpool3s2_bwd_w4<false>, gw, dim3(NT), 0, st, g_out, idx, addend, g_x, planes, H, W, OH, OW);
+    else if (addend) hipLaunchKernelGGL(k_maxpool3s2_bwd<true>, gn, dim3(NT), 0, st, g_out, idx, addend, g_x, planes, H, W, OH, OW);
+    else hipLaunchKernelGGL(k_maxpool3s2_bwd<false>, gn, dim3(NT), 0, st, g_out, idx, addend, g_x, planes, H, W, OH, OW);
     return hip_check_launch();
+}
+
+int mvf_maxpool3s2_bwd(const float *g_out, const uint8_t *idx, float *g_x, int planes, int H, int W, void *stream)
+{
+    return maxpool3s2_bwd_any(g_out, idx, nullptr, g_x, planes, H, W, stream);
+}
+
+int mvf_maxpool3s2_bwd_add(const float *g_out, const uint8_t *idx, const float *addend, float *g_x, int planes, int H,
+                           int W, void *stream)
+{
+    if (planes > 0 && H > 0 && W > 0 && !addend) return (int)hipErrorInvalidValue;
+    return maxpool3s2_bwd_any(g_out, idx, addend, g_x, planes, H, W, stream);
 }
 
 int mvf_regroup_fwd(const float *src, int G, int B, int64_t chunk, int n_out, float *const *dst, const int32_t *counts,

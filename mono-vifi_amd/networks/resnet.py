@@ -114,18 +114,22 @@ class ResNetTrunk(nn.Module):
 
 
 STEM_POOL_KERNEL = os.environ.get("MVF_STEM_POOL", "1") != "0"      # developer knob for A/B timing
+STEM_POOL_TAP = os.environ.get("MVF_STEM_POOL_TAP", "1") != "0"     # same: the tap form of the stem pool
 
 
-def _stem_pool(trunk, f0):
-    """The trunk's 3x3 / stride-2 max pool; on the HIP device (fp32) the byte-index gather pair
-    (ops.maxpool3s2) instead of ATen's int64-index kernels."""
+def _stem_pool(trunk, f0, tap=True):
+    """-> (pooled, f0).  The trunk's 3x3 / stride-2 max pool; on the HIP device (fp32) the byte-index gather pair
+    (ops.maxpool3s2) instead of ATen's int64-index kernels.  The returned f0 is what the caller puts into the
+    feature pyramid (`tap`: see ops.MaxPool3s2Tap)."""
     mp = trunk.maxpool
     if (STEM_POOL_KERNEL and f0.is_cuda and f0.dtype == torch.float32 and not torch.is_autocast_enabled()
             and f0.is_contiguous() and isinstance(mp, nn.MaxPool2d) and (mp.kernel_size, mp.stride, mp.padding, mp.dilation, mp.ceil_mode)
             == (3, 2, 1, 1, False)):
         from .. import ops
-        return ops.maxpool3s2(f0)
-    return mp(f0)
+        if tap and STEM_POOL_TAP and torch.is_grad_enabled() and f0.requires_grad:
+            return ops.maxpool3s2_tap(f0)     # (pooled, f0): f0's two gradients meet inside the pooling adjoint
+        return ops.maxpool3s2(f0), f0
+    return mp(f0), f0
 
 
 def pyramid_features(trunk, image):
@@ -133,7 +137,8 @@ def pyramid_features(trunk, image):
     posenet.py:80-93): colour normalisation (x-0.45)/0.225, then stem and 4 stages."""
     x = (image - 0.45) / 0.225
     f0 = trunk.relu(trunk.bn1(trunk.conv1(x)))
-    f1 = trunk.layer1(_stem_pool(trunk, f0))
+    pooled, f0 = _stem_pool(trunk, f0)
+    f1 = trunk.layer1(pooled)
     f2 = trunk.layer2(f1)
     f3 = trunk.layer3(f2)
     f4 = trunk.layer4(f3)

@@ -1310,6 +1310,52 @@ def maxpool3s2(x):
     return MaxPool3s2.apply(x)
 
 
+class MaxPool3s2Tap(torch.autograd.Function):
+    """(maxpool3s2(x), x): the pooled tensor and the input itself as a second output, for an input that is
+    ALSO consumed elsewhere (the stem output of the depth encoder is pooled into layer1 and is level 0 of the
+    feature pyramid: reference networks/monodepth2.py:36-41).  The backward adds the tap's gradient inside the
+    pooling adjoint (`mvf_maxpool3s2_bwd_add`) instead of leaving two full-size tensors to autograd's
+    accumulation pass; same two-term sum, same bits."""
+
+    @staticmethod
+    def forward(ctx, x):
+        nat.require_device(x)
+        x = _c(x)
+        N, C, H, W = x.shape
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        out = torch.empty((N, C, OH, OW), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, C, OH, OW), dtype=torch.uint8, device=x.device)
+        nat.check(nat.lib().mvf_maxpool3s2_fwd(nat.ptr(x), nat.ptr(out), nat.ptr(idx), N * C, H, W, _stream()),
+                  "maxpool3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = (N, C, H, W)
+        ctx.set_materialize_grads(False)
+        return out, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g, g_tap):
+        if g is None:
+            return g_tap
+        idx, = ctx.saved_tensors
+        N, C, H, W = ctx.geom
+        g = _c(g)
+        gx = torch.empty((N, C, H, W), dtype=torch.float32, device=g.device)
+        if g_tap is None:
+            nat.check(nat.lib().mvf_maxpool3s2_bwd(nat.ptr(g), nat.ptr(idx), nat.ptr(gx), N * C, H, W, _stream()),
+                      "maxpool3s2_bwd")
+        else:
+            nat.check(nat.lib().mvf_maxpool3s2_bwd_add(nat.ptr(g), nat.ptr(idx), nat.ptr(_c(g_tap)), nat.ptr(gx), N * C, H, W,
+                                                       _stream()), "maxpool3s2_bwd_add")
+        return gx
+
+
+def maxpool3s2_tap(x):
+    """-> (pooled, x): use the returned x wherever else the input is consumed (see `MaxPool3s2Tap`)."""
+    if x.dim() != 4 or x.dtype != torch.float32:
+        raise RuntimeError("maxpool3s2 expects a float32 [N,C,H,W] tensor")
+    return MaxPool3s2Tap.apply(x)
+
+
 _ACT_CODES = {"none": 0, "elu": 1, "relu": 2, "prelu": 3}
 
 

@@ -689,7 +689,10 @@ class Trainer(HotPathLosses):
         if o.use_affine:
             Rc = inputs["Rc"]
             # (the graph step inverts Rc before the replay: a solver call does not belong in a capture)
-            Rc_inv = inputs["Rc_inv"] if "Rc_inv" in inputs else torch.inverse(Rc)
+            # inv_ex = torch.inverse (same LU, bit-identical result) WITHOUT its host-side singularity check: that check
+            # reads a device flag and so drained the stream in the middle of every step's forward pass (measured:
+            # 92 ms of the host's 120 ms forward enqueue spent waiting there; tools/host_audit.py, tools/inv_probe.py)
+            Rc_inv = inputs["Rc_inv"] if "Rc_inv" in inputs else torch.linalg.inv_ex(Rc).inverse
             srcs_a = [inputs[("color_affine", -1, 0)], inputs[("color_affine", 1, 0)]]
             mask_rec = inputs["valid_mask_rec"]
             todo = ((pose_0_n1, pose_0_p1, depth_0, depth_0_fuse), (pose_nt_n1, pose_nt_p1, depth_nt, depth_nt_fuse),

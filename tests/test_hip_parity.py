@@ -1345,3 +1345,27 @@ def test_interleave_groups_equals_cat_and_stack(shape, groups, parts):
         ops.interleave_groups([[ts[0][0]], [ts[1][0][:, :2]]])          # groups of different widths
     with pytest.raises(RuntimeError):
         ops.interleave_groups([[ts[0][0].clone().requires_grad_(True)]])    # forward-only
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 16, 24), (2, 3, 9, 13), (1, 2, 8, 10)])
+def test_maxpool_tap_adds_the_other_gradient_in_the_pass(shape):
+    """maxpool3s2_tap(x) = (maxpool3s2(x), x); its adjoint = pooling adjoint + the tap's gradient in ONE pass,
+    bit-identical to autograd's separate accumulation (a two-term sum); wide and narrow kernels; tap unused -> the
+    plain adjoint."""
+    from mono_vifi_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(8)
+    x = torch.randn(shape, device="cuda", generator=g)
+    xa, xb, xc = (x.clone().requires_grad_(True) for _ in range(3))
+    pa, ta = ops.maxpool3s2_tap(xa)
+    pb = ops.maxpool3s2(xb)
+    assert torch.equal(pa, pb) and torch.equal(ta, x)
+    w1 = torch.randn(pa.shape, device="cuda", generator=g)
+    w2 = torch.randn(shape, device="cuda", generator=g)
+    ((pa * w1).sum() + (ta * w2).sum()).backward()
+    ((pb * w1).sum() + (xb * w2).sum()).backward()
+    assert torch.equal(xa.grad, xb.grad)
+    pc, _ = ops.maxpool3s2_tap(xc)
+    (pc * w1).sum().backward()
+    xd = x.clone().requires_grad_(True)
+    (ops.maxpool3s2(xd) * w1).sum().backward()
+    assert torch.equal(xc.grad, xd.grad)
