@@ -380,6 +380,24 @@ MVF_API int mvf_interleave_fwd(const float *const *src, const int64_t *len, cons
                        const int32_t *group, int n_slots, float *dst, int G, int B, int64_t total,
                        void *stream);
 
+/* Grouped batch norm (networks/grouped.py; the reference normalises every encoder call on its
+ * own, train.py:745-868 through nn.BatchNorm2d / SyncBatchNorm train.py:207): the C-vectors of a
+ * layer repeated for the G interleaved calls, tiled [4][G*C] = weight | bias | running_mean |
+ * running_var.  One launch instead of stack + repeat. */
+MVF_API int mvf_bn_tile(const float *weight, const float *bias, const float *running_mean,
+                const float *running_var, float *tiled, int C, int G, void *stream);
+/* running <- beta * running + sum_g coef[g] * upd[g*C + c] for both statistics (upd = the tiled
+ * statistics after the batch-norm call: one momentum update per group from the common start;
+ * coef, beta as GroupedBatchNorm2d._fold_running derives them: the G sequential updates of the
+ * per-call form), *num_batches_tracked += G (nullable).  coef: HOST array of G <= 32 floats. */
+MVF_API int mvf_bn_fold_running(float *running_mean, float *running_var, const float *upd_mean,
+                        const float *upd_var, const float *coef, float beta, int C, int G,
+                        int64_t *num_batches_tracked, void *stream);
+/* adjoint of the tiling: g_out [2][C] = per channel the sum over the G groups of the tiled weight /
+ * bias gradients, in group order. */
+MVF_API int mvf_bn_untile(const float *g_weight_tiled, const float *g_bias_tiled, float *g_out, int C, int G,
+                  void *stream);
+
 /* ---- f4: step glue either side of the hot path ------------------
  * Decoder stage glue (networks/monodepth2.py:84-90 with layers.py:121-138, 225-228): the padded
  * input of upconv_1, out [B, C1+C2, 2h+2, 2w+2] = ReflectionPad2d(1)(cat([upsample_nearest_x2(x),

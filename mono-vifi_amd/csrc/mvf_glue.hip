@@ -1064,6 +1064,50 @@ __global__ void __launch_bounds__(NT) k_jitter_apply(const float *__restrict__ i
 }
 
 
+// ---- grouped batch norm: the per-layer vector glue (networks/grouped.py) -----------------------------------------
+// A grouped layer normalises [B, G*C, ...] with its C-vectors repeated G times.  Around every MIOpen batch-norm call
+// that was five tiny ATen launches forward (stack, repeat, two matrix-vector updates of the running statistics, the
+// step counter) and two backward (stack, sum): 325 such layers in an HRNet18 step.  One launch each here.
+// tiled[4][G*C] = (weight, bias, running_mean, running_var) repeated G times
+__global__ void __launch_bounds__(NT) k_bn_tile(const float *__restrict__ w, const float *__restrict__ b,
+                                                const float *__restrict__ rm, const float *__restrict__ rv,
+                                                float *__restrict__ tiled, int C, int G)
+{
+    const int i = blockIdx.x * NT + threadIdx.x, n = G * C;
+    if (i >= n) return;
+    const int c = i % C;
+    tiled[i] = w[c]; tiled[n + i] = b[c]; tiled[2 * n + i] = rm[c]; tiled[3 * n + i] = rv[c];
+}
+// The tiled statistics come back holding, per group, ONE momentum update from the common start.  The G sequential
+// updates of the per-call form are r <- beta r + sum_g coef[g] upd[g][c] (GroupedBatchNorm2d._fold_running); both
+// statistics and the step counter in one launch.
+struct BnFoldCoef { float c[32]; };
+__global__ void __launch_bounds__(NT) k_bn_fold_running(float *__restrict__ run_mean, float *__restrict__ run_var,
+                                                        const float *__restrict__ upd_mean, const float *__restrict__ upd_var,
+                                                        BnFoldCoef coef, float beta, int C, int G, int64_t *tracked)
+{
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c == 0 && tracked) *tracked += G;
+    if (c >= C) return;
+    float am = 0.0f, av = 0.0f;
+    for (int g = 0; g < G; ++g) {
+        am = fmaf(coef.c[g], upd_mean[g * C + c], am);
+        av = fmaf(coef.c[g], upd_var[g * C + c], av);
+    }
+    run_mean[c] = fmaf(beta, run_mean[c], am);
+    run_var[c] = fmaf(beta, run_var[c], av);
+}
+// adjoint of the tiling: out[0][c] = sum_g gw[g*C + c], out[1][c] = sum_g gb[g*C + c] (group order)
+__global__ void __launch_bounds__(NT) k_bn_untile(const float *__restrict__ gw, const float *__restrict__ gb,
+                                                  float *__restrict__ out, int C, int G)
+{
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.0f, b = 0.0f;
+    for (int g = 0; g < G; ++g) { a += gw[g * C + c]; b += gb[g * C + c]; }
+    out[c] = a; out[C + c] = b;
+}
+
 // ---- regrouping of interleaved group batches (networks/grouped.py) ----------------------------------------------
 // One optimisation step of the reference calls the depth encoder once per input and hands each call's feature
 // pyramid to the decoder / fusion module calls that need it (train.py:745-747, 788-797, 830-868).  Here the G
@@ -1579,6 +1623,38 @@ int mvf_interleave_fwd(const float *const *src, const int64_t *len, const int64_
     const dim3 grid((unsigned)blocks, (unsigned)n_slots, (unsigned)B);
     if (vec) hipLaunchKernelGGL(k_interleave_fwd<true>, grid, dim3(NT), 0, (hipStream_t)stream, pl, dst, G, total / 4);
     else hipLaunchKernelGGL(k_interleave_fwd<false>, grid, dim3(NT), 0, (hipStream_t)stream, pl, dst, G, total);
+    return hip_check_launch();
+}
+
+
+int mvf_bn_tile(const float *weight, const float *bias, const float *running_mean, const float *running_var, float *tiled,
+                int C, int G, void *stream)
+{
+    if (C <= 0 || G <= 0) return 0;
+    if (!weight || !bias || !running_mean || !running_var || !tiled) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bn_tile, dim3((unsigned)((G * C + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, weight, bias,
+                       running_mean, running_var, tiled, C, G);
+    return hip_check_launch();
+}
+
+int mvf_bn_fold_running(float *running_mean, float *running_var, const float *upd_mean, const float *upd_var,
+                        const float *coef, float beta, int C, int G, int64_t *num_batches_tracked, void *stream)
+{
+    if (C <= 0 || G <= 0) return 0;
+    if (!running_mean || !running_var || !upd_mean || !upd_var || !coef || G > 32) return (int)hipErrorInvalidValue;
+    BnFoldCoef cf;
+    for (int g = 0; g < 32; ++g) cf.c[g] = g < G ? coef[g] : 0.0f;
+    hipLaunchKernelGGL(k_bn_fold_running, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream,
+                       running_mean, running_var, upd_mean, upd_var, cf, beta, C, G, num_batches_tracked);
+    return hip_check_launch();
+}
+
+int mvf_bn_untile(const float *g_weight_tiled, const float *g_bias_tiled, float *g_out, int C, int G, void *stream)
+{
+    if (C <= 0 || G <= 0) return 0;
+    if (!g_weight_tiled || !g_bias_tiled || !g_out) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_bn_untile, dim3((unsigned)((C + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, g_weight_tiled,
+                       g_bias_tiled, g_out, C, G);
     return hip_check_launch();
 }
 

@@ -32,6 +32,18 @@ def _count(kind):
     count_collective(kind)
 
 
+def _native_vectors(*tensors):
+    """The one-launch forms of the per-layer vector glue (`mvf_bn_tile / _fold_running / _untile`) apply to
+    contiguous fp32 vectors on the HIP device; anything else (the CPU gloo tests, reduced precision) keeps the
+    tensor-op formulation."""
+    return all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors)
+
+
+def _nat():
+    from .. import _native as nat
+    return nat, torch.cuda.current_stream().cuda_stream
+
+
 def merge_groups(tensors):
     """G tensors [B, ...] -> [B*G, ...] interleaved (sample n = b*G + g)."""
     return torch.stack(list(tensors), 1).flatten(0, 1)
@@ -67,7 +79,14 @@ class _FoldedBN(torch.autograd.Function):
     def forward(ctx, x, weight, bias, running_mean, running_var, groups, momentum, eps):
         N, C = x.shape[0], x.shape[1]
         xv = x.view(N // groups, groups * C, *x.shape[2:])
-        wG, bG, rmG, rvG = torch.stack([weight, bias, running_mean, running_var]).repeat(1, groups).unbind(0)
+        if _native_vectors(weight, bias, running_mean, running_var):
+            nat, st = _nat()
+            tiled = torch.empty((4, groups * C), dtype=torch.float32, device=x.device)
+            nat.check(nat.lib().mvf_bn_tile(nat.ptr(weight), nat.ptr(bias), nat.ptr(running_mean), nat.ptr(running_var),
+                                            nat.ptr(tiled), C, groups, st), "bn_tile")
+            wG, bG, rmG, rvG = tiled.unbind(0)
+        else:
+            wG, bG, rmG, rvG = torch.stack([weight, bias, running_mean, running_var]).repeat(1, groups).unbind(0)
         y, save_mean, save_var, reserve, impl = torch._batch_norm_impl_index(
             xv, wG, bG, rmG, rvG, True, momentum, eps, True)
         ctx.save_for_backward(xv, wG, rmG, rvG, save_mean, save_var, reserve)
@@ -87,7 +106,13 @@ class _FoldedBN(torch.autograd.Function):
             ctx.impl, xv, gy.contiguous().view_as(xv), wG, rm, rv, save_mean, save_var, True, ctx.eps,
             [True, True, True], reserve)
         G = ctx.groups
-        gwb = torch.stack([gw, gb]).view(2, G, gw.numel() // G).sum(1)      # adjoint of the tiling
+        if _native_vectors(gw, gb):
+            nat, st = _nat()
+            Cn = gw.numel() // G
+            gwb = torch.empty((2, Cn), dtype=torch.float32, device=gw.device)
+            nat.check(nat.lib().mvf_bn_untile(nat.ptr(gw), nat.ptr(gb), nat.ptr(gwb), Cn, G, st), "bn_untile")
+        else:
+            gwb = torch.stack([gw, gb]).view(2, G, gw.numel() // G).sum(1)      # adjoint of the tiling
         return gx.view_as(gy), gwb[0], gwb[1], None, None, None, None, None
 
 
@@ -239,8 +264,16 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         launches)."""
         m = self.momentum
         c = [(1 - m) ** (G - 1 - g) for g in range(G)]
-        coef = const_tensor(c, rm.device, rm.dtype)
         beta = (1 - m) ** G - (1 - m) * sum(c)
+        if G <= 32 and _native_vectors(self.running_mean, self.running_var, rm, rv) and \
+                self.num_batches_tracked.is_cuda and self.num_batches_tracked.dtype == torch.int64:
+            import ctypes as C_
+            nat, st = _nat()
+            nat.check(nat.lib().mvf_bn_fold_running(nat.ptr(self.running_mean), nat.ptr(self.running_var), nat.ptr(rm),
+                                                    nat.ptr(rv), (C_.c_float * G)(*c), float(beta), C, G,
+                                                    nat.ptr(self.num_batches_tracked), st), "bn_fold_running")
+            return
+        coef = const_tensor(c, rm.device, rm.dtype)
         for run, upd in ((self.running_mean, rm), (self.running_var, rv)):
             run.addmv_(upd.view(G, C).t(), coef, beta=beta, alpha=1.0)
         self.num_batches_tracked += G

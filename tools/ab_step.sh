@@ -1,6 +1,6 @@
 #!/bin/bash
-# Same-box A/B of the training step: tools/ab_step.sh "<label_a>:<env or flags a>" "<label_b>:<env or flags b>" ...
-# Each variant = "label:ENV=V ... -- bench flags"; runs every variant ROUNDS times alternating, as HIP graph steps
+# Same-box A/B of the training step: tools/ab_step.sh "a:ENV=1" "b:ENV=0 @ --no-regroup" ...
+# Each variant = "label:ENV=V ... @ bench flags"; runs every variant ROUNDS times alternating, as HIP graph steps
 # (device time, host-independent) and eager.  Output: gpurun_out/ab_step.txt
 ROUNDS=${ROUNDS:-2}
 OUT=gpurun_out/ab_step.txt
@@ -9,8 +9,8 @@ COMMON="--no-cpu-baseline --no-hotpath-leg --no-graph-leg --no-pmc-leg --no-mfma
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do
     label=${v%%:*}; rest=${v#*:}
-    envs=${rest%%--*}; flags=""
-    case "$rest" in *--*) flags="--${rest#*--}";; esac
+    envs=${rest%%@*}; flags=""
+    case "$rest" in *@*) flags="${rest#*@}";; esac
     for mode in "--hip-graph" ""; do
       line=$(env $envs python bench.py $COMMON $flags $mode 2>/dev/null | tail -1)
       ms=$(python -c "import json,sys; print(json.loads(sys.argv[1])['ms_per_step'])" "$line" 2>/dev/null)
