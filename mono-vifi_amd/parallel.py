@@ -11,12 +11,18 @@ trainable parameters:
 * parameters are de-duplicated by identity and laid out, in reverse registration order
   (the order backward produces them), in a few large flat fp32 buckets -- xGMI is
   point-to-point, so fewer / larger collectives win (bucket default 32 MB);
-* ``param.grad`` is a *view* into its bucket, so there is no copy in or out;
-* a post-accumulate-grad hook counts arrivals; when a bucket is complete its
-  ``all_reduce`` is issued asynchronously (RCCL runs it on its own stream) and overlaps
-  the rest of backward; ``finish()`` waits, and also reduces buckets whose parameters got
-  no gradient this step (so every rank issues the same collectives -- no
-  ``find_unused_parameters`` graph walk);
+* ``zero_grad()`` sets every ``param.grad`` to None, so autograd's accumulation node *keeps* the gradient tensor
+  backward produced instead of adding it into a zeroed buffer: no launch per parameter (round 3 kept
+  ``param.grad`` aliased to a zeroed bucket -- ~200 tiny ``add_`` launches per ResNet18 step, ~1,100 per HRNet18
+  step, plus the memsets);
+* a post-accumulate-grad hook counts arrivals; when a bucket is complete its gradients are packed into the
+  flat buffer with ONE multi-tensor copy, ``param.grad`` becomes the view into the bucket and the
+  ``all_reduce`` is issued asynchronously (RCCL runs it on its own stream) and overlaps the rest of backward;
+  ``finish()`` waits, and also reduces buckets whose parameters got no gradient this step (their slices are
+  zero, so every rank issues the same collectives -- no ``find_unused_parameters`` graph walk).  With nothing to
+  exchange (one process, no forced collectives) nothing is packed: the gradients stay where backward put them
+  and a parameter without a gradient keeps ``grad = None`` (the optimiser skips it, as in the reference's
+  single-process run);
 * works unchanged on ``gloo`` (CPU) -- that is how tests/test_parallel.py covers N > 1;
 * ``exchange="reduce_scatter"`` replaces each bucket's all-reduce by the two halves a ring
   all-reduce consists of, issued explicitly on the flat buffer: ``reduce_scatter_tensor``
@@ -41,6 +47,10 @@ import torch.distributed as dist
 # kind -> number of collectives issued since reset_comm_counts(); kinds: grad_all_reduce,
 # grad_reduce_scatter, grad_all_gather, bn_all_gather, bn_all_reduce, broadcast, loss_all_reduce
 COMM_COUNTS = collections.Counter()
+
+
+import os as _os
+_BUCKET_VIEWS = _os.environ.get("MVF_GRAD_BUCKET_VIEWS", "0") == "1"
 
 
 def count_collective(kind, n=1):
@@ -126,10 +136,10 @@ def broadcast_module_states(modules, src=0):
 
 
 class _Bucket:
-    __slots__ = ("buf", "params", "pending", "handle", "launched", "shard")
+    __slots__ = ("buf", "params", "views", "pending", "handle", "launched", "shard")
 
-    def __init__(self, buf, params):
-        self.buf, self.params = buf, params
+    def __init__(self, buf, params, views):
+        self.buf, self.params, self.views = buf, params, views
         self.pending, self.handle, self.launched = len(params), None, False
         self.shard = None       # reduce_scatter exchange: this rank's 1/N-th of `buf` (a view)
 
@@ -191,17 +201,23 @@ class BucketedGradReducer:
         self._ev_issue, self._ev_end = [], None
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
+    @property
+    def exchanging(self):
+        """Whether a step issues collectives at all (N > 1, or a group of one forced through them)."""
+        return self.world > 1 or self.always_reduce
+
     def _seal(self, params):
         n = sum(p.numel() for p in params)
         # reduce_scatter exchange: every rank owns an equal slice, so the flat buffer is padded
-        # to a multiple of the group size (the padding stays zero)
+        # to a multiple of the group size (the padding stays zero: nothing ever writes it)
         n_pad = -(-n // self.world) * self.world if self.exchange == "reduce_scatter" else n
         buf = torch.zeros(n_pad, dtype=torch.float32, device=params[0].device)
-        off = 0
+        views, off = [], 0
         for p in params:
-            p.grad = buf[off:off + p.numel()].view_as(p)
+            views.append(buf[off:off + p.numel()].view_as(p))
             off += p.numel()
-        b = _Bucket(buf, params)
+            p.grad = None
+        b = _Bucket(buf, params, views)
         if self.exchange == "reduce_scatter":
             per = n_pad // self.world
             b.shard = buf[self._rank * per:(self._rank + 1) * per]
@@ -211,17 +227,36 @@ class BucketedGradReducer:
 
     # ---------------------------------------------------------------- step protocol
     def zero_grad(self):
-        """Replaces optimizer.zero_grad(): keeps ``param.grad`` aliased to the buckets."""
+        """Replaces optimizer.zero_grad(set_to_none=True): every gradient starts the step as None, so the
+        accumulation node keeps the tensor backward hands it (no add into a zeroed buffer, no memset)."""
         self.issued_from_hook = self.issued_from_finish = 0
         self._ev_issue, self._ev_end = [], None
         for b in self.buckets:
-            b.buf.zero_()
             b.pending, b.handle, b.launched = len(b.params), None, False
-            off = 0
-            for p in b.params:      # re-alias if something replaced .grad (set_to_none etc.)
-                if p.grad is None or p.grad.data_ptr() != b.buf.data_ptr() + 4 * off:
-                    p.grad = b.buf[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            if _BUCKET_VIEWS:       # round-3 form, kept as a developer knob for same-box A/B timing
+                b.buf.zero_()
+                for p, v in zip(b.params, b.views):
+                    p.grad = v
+                continue
+            for p in b.params:
+                p.grad = None
+
+    def _pack(self, b):
+        """Gradients of a bucket -> its flat buffer (one multi-tensor copy; a parameter that got no gradient
+        contributes zeros), and ``param.grad`` -> the view, so that what the collective averages in place is
+        what clipping and the optimiser read."""
+        src, dst = [], []
+        for p, v in zip(b.params, b.views):
+            g = p.grad
+            if g is None:
+                v.zero_()
+            elif g.data_ptr() != v.data_ptr():
+                src.append(g if g.dtype == v.dtype else g.to(v.dtype))
+                dst.append(v)
+        if src:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(b.params, b.views):
+            p.grad = v
 
     def _chained(self):
         """True when two collectives issued back to back on the group run in issue order
@@ -230,8 +265,10 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         b.launched = True
-        if not (self.world > 1 or self.always_reduce):
+        if not self.exchanging:
             return
+        with torch.no_grad():
+            self._pack(b)
         b.buf.div_(self.world)
         if self.exchange == "all_reduce":
             b.handle = dist.all_reduce(b.buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -297,3 +334,8 @@ class BucketedGradReducer:
     @property
     def total_bytes(self):
         return sum(b.buf.numel() for b in self.buckets) * 4
+
+    def bucket_view(self, p):
+        """The slice of its bucket a parameter's gradient is packed into (and, after the exchange, is)."""
+        b = self._owner[id(p)]
+        return b.views[[id(q) for q in b.params].index(id(p))]

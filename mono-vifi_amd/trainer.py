@@ -814,7 +814,8 @@ class _StepGraph:
     A training step is several thousand launches (ResNet18: ~2,500, DHRNet: ~13,500 -- at
     26 us of host time per launch the DHRNet step is bound by the enqueueing Python thread, not
     by the GPU).  Shapes are static, nothing in the step reads a value back to the host, the
-    gradients live in the reducer's persistent flat buckets and the optimiser is capturable, so
+    gradients are the capture's own allocations (or the reducer's persistent flat buckets when there is an
+    exchange: both keep their addresses across replays) and the optimiser is capturable, so
     the whole step -- teacher, encoders, decoders, the nine unit kernels, backward, gradient
     clipping, AdamW -- is captured once and replayed with one launch per step.
 

@@ -51,7 +51,7 @@ def _worker(rank, world, port, q, exchange="all_reduce", overlap=True):
         torch.manual_seed(100)
         x_all = torch.randn(4 * world, 8)
         x = x_all[rank * 4:(rank + 1) * 4]
-        for it in range(2):                # twice: zero_grad must keep the bucket views
+        for it in range(2):                # twice: zero_grad starts every step from grad = None
             red.zero_grad()
             y = net["b"](torch.relu(net["a"](x)) + net["a_alias"](x))   # shared module used twice
             y.pow(2).mean().backward()
@@ -64,6 +64,8 @@ def _worker(rank, world, port, q, exchange="all_reduce", overlap=True):
                 assert red.issued_from_finish <= nb_unused
             else:
                 assert in_backward == 0 and red.issued_from_finish == red.num_buckets
+        # after the exchange every gradient IS its bucket slice (packed by one multi-tensor copy per bucket)
+        assert all(p.grad.data_ptr() == red.bucket_view(p).data_ptr() for p in params)
         grads = [p.grad.clone() for p in params]
         # exactly one exchange per bucket per step, whichever form it takes
         cnt, nb = parallel.comm_counts(), red.num_buckets
@@ -153,9 +155,11 @@ def test_tail_bucket_holds_the_last_arriving_gradients():
     # gives its last-arriving <= 1 MiB to a bucket of their own
     assert got == [[6 * mb], [4 * mb, 2 * mb], [3 * mb, mb], [mb // 2, mb // 2]]
     assert red.buckets[-1].params[-1] is params[0]
-    for p in params:                               # every gradient is a view of its bucket
-        assert any(p.grad.data_ptr() >= b.buf.data_ptr() and
-                   p.grad.data_ptr() < b.buf.data_ptr() + 4 * b.buf.numel() for b in red.buckets)
+    for p in params:                               # every parameter owns a slice of its bucket; no gradient yet
+        v = red.bucket_view(p)
+        assert v.shape == p.shape and p.grad is None
+        assert any(v.data_ptr() >= b.buf.data_ptr() and
+                   v.data_ptr() < b.buf.data_ptr() + 4 * b.buf.numel() for b in red.buckets)
     # no split when the last bucket is small anyway, or when switched off
     red2 = parallel.BucketedGradReducer([nn.Parameter(torch.zeros(n)) for n in sizes], world_size=1,
                                         bucket_mb=8.0, tail_mb=0.0)

@@ -19,6 +19,11 @@ def make_trainer(tmp_path, **kw):
     return Trainer(opts)
 
 
+def flat_grads(t):
+    """All parameter gradients of a trainer as one vector (a parameter the step did not reach has grad None: zeros)."""
+    return torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in t.parameters_to_train])
+
+
 def device_batch(B, H, W, dev, seed=5):
     from mono_vifi_amd import synthetic
     b = synthetic.training_batch(seed, B, H, W)
@@ -36,7 +41,7 @@ def test_optimisation_steps_run_and_update(tmp_path):
         vals.append(float(losses["loss"]))
         assert all(np.isfinite(float(losses[k])) for k in ("loss", "loss_base", "loss_dc"))
     assert any(not torch.equal(a, p.detach()) for a, p in zip(before, t.parameters_to_train[:4]))
-    gn = torch.sqrt(sum((p.grad.float() ** 2).sum() for p in t.parameters_to_train))
+    gn = flat_grads(t).float().norm()
     assert torch.isfinite(gn) and float(gn) > 0
     # aliased encoder_mf parameters are trained once
     assert len({id(p) for p in t.parameters_to_train}) == len(t.parameters_to_train)
@@ -58,7 +63,7 @@ def test_fused_units_equal_staged_path(tmp_path):
         losses["loss"].backward()
         t.reducer.finish()
         out[fused] = (float(losses["loss"]), float(losses["loss_base"]),
-                      torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone())
+                      flat_grads(t).clone())
     assert abs(out[True][0] - out[False][0]) <= 2e-6 * abs(out[False][0])
     assert abs(out[True][1] - out[False][1]) <= 2e-6 * abs(out[False][1])
     num = (out[True][2] - out[False][2]).norm()
@@ -165,7 +170,7 @@ def test_other_backbones_step(tmp_path, backbone):
         losses["loss"].backward()
         t.reducer.finish()
         out[tag] = (float(losses["loss"]), float(losses["loss_base"]),
-                    torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone())
+                    flat_grads(t).clone())
     assert all(np.isfinite(v) for v in out["fused"][:2])
     assert abs(out["fused"][0] - out["staged"][0]) <= 2e-6 * abs(out["staged"][0])
     assert abs(out["fused"][1] - out["staged"][1]) <= 2e-6 * abs(out["staged"][1])
@@ -208,7 +213,7 @@ def test_grouped_calls_equal_one_call_at_a_time(tmp_path):
         t.reducer.finish()
         bufs = torch.cat([b.flatten().float() for m in t._modules_unique.values() for b in m.buffers()])
         out[grp] = (float(losses["loss"]), float(losses["loss_dc"]),
-                    torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone(), bufs.clone())
+                    flat_grads(t).clone(), bufs.clone())
     assert abs(out[True][0] - out[False][0]) <= 1e-5 * abs(out[False][0])
     assert abs(out[True][1] - out[False][1]) <= 1e-5 * abs(out[False][1]) + 1e-7
     assert float((out[True][2] - out[False][2]).norm() / out[False][2].norm()) <= 2e-3
@@ -242,7 +247,7 @@ def test_regroup_equals_stack_and_autograd_accumulation(tmp_path, fuse):
         launches = (nat.profile_read(32)[1], nat.profile_read(33)[1])
         nat.lib().mvf_profile_enable(0)
         out[rg] = (float(losses["loss"]), float(losses["loss_dc"]),
-                   torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone(), launches)
+                   flat_grads(t).clone(), launches)
     levels = 5
     n_enc = 2 if fuse == "separate_all" else 1
     assert out[True][3] == (levels * n_enc, levels * n_enc) and out[False][3] == (0, 0)
@@ -370,7 +375,7 @@ def _rccl_worker(port, log_dir, q, exchange="all_reduce"):
             issue = (t.reducer.issued_from_hook, t.reducer.issued_from_finish, t.reducer.timeline_ms())
         bufs = torch.cat([b.flatten().float() for m in t._modules_unique.values() for b in m.buffers()])
         out[forced] = (float(losses["loss"]),
-                       torch.cat([p.grad.flatten() for p in t.parameters_to_train]).clone(), bufs.clone())
+                       flat_grads(t).clone(), bufs.clone())
     dl = abs(out[True][0] - out[False][0]) / abs(out[False][0])
     dg = float((out[True][1] - out[False][1]).norm() / out[False][1].norm())
     db = bool(torch.allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-5))
