@@ -46,7 +46,8 @@ def main():
         losses["loss"].backward()
         t.reducer.finish()
         out[tag] = (float(losses["loss"]), float(losses["loss_base"]), float(losses["loss_dc"]),
-                    torch.cat([p.grad.flatten() for p in t.parameters_to_train]).double().clone())
+                    torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten()
+                               for p in t.parameters_to_train]).double().clone())
     ref = out["staged"][3]
     rn = float(ref.norm())
     res = {"backbone": backbone, "shape": [B, H, W],
