@@ -17,8 +17,8 @@ cp $(ls $O/hp/*/*kernel_stats.csv | head -1) $O/r04_hotpath_kernel_stats.csv; rm
 cp $(ls $O/tr/*/*kernel_stats.csv | head -1) $O/r04_train_kernel_stats.csv
 python tools/step_breakdown.py $(ls $O/tr/*/*kernel_stats.csv | head -1) 9 > $O/r04_train_step_kernel_breakdown.csv 2>/dev/null; rm -rf $O/tr
 head -5 $O/r04_hotpath_kernel_stats.csv | cut -c1-150
-bash tools/pmc.sh > /dev/null; cp gpurun_out/pmc_summary.csv $O/r04_pmc_valu.csv
-bash tools/pmc_traffic.sh > /dev/null; cp gpurun_out/pmc_traffic.csv $O/r04_pmc_fetch_write.csv
-bash tools/pmc_mfma.sh > /dev/null 2>&1; cp gpurun_out/pmc_mfma_summary.csv $O/r04_train_pmc_mfma.csv
+timeout 900 bash tools/pmc.sh > /dev/null; cp gpurun_out/pmc_summary.csv $O/r04_pmc_valu.csv
+timeout 900 bash tools/pmc_traffic.sh > /dev/null; cp gpurun_out/pmc_traffic.csv $O/r04_pmc_fetch_write.csv
+timeout 1200 bash tools/pmc_mfma.sh > /dev/null 2>&1; cp gpurun_out/pmc_mfma_summary.csv $O/r04_train_pmc_mfma.csv
 grep -E "k_unit_fb" $O/r04_pmc_valu.csv $O/r04_pmc_fetch_write.csv | cut -c1-30,100-
 head -4 $O/r04_train_step_kernel_breakdown.csv | cut -c1-120
