@@ -438,9 +438,12 @@ MVF_API int mvf_bias_act_bwd(const float *g, const float *out, float *g_x, float
  * in/out), as fp32.  One lane per output element; planes <= 262,140. */
 MVF_API int mvf_resize_bilinear_fwd(const float *x, float *out, int planes, int ih, int iw, int oh, int ow,
                             float scale_h, float scale_w, int align_corners, void *stream);
-/* adjoint: deterministic gather (no float atomics), g_x [planes, ih, iw] fully written */
-MVF_API int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, int planes, int ih, int iw, int oh, int ow,
-                            float scale_h, float scale_w, int align_corners, void *stream);
+/* adjoint: deterministic gather (no float atomics), g_x [planes, ih, iw] fully written.  With a
+ * workspace of mvf_resize_bilinear_bwd_workspace_floats(planes, ih, ow) floats: two separable
+ * passes (rows of g_out folded into the workspace, then its columns); workspace NULL: one pass. */
+MVF_API size_t mvf_resize_bilinear_bwd_workspace_floats(int planes, int ih, int ow);
+MVF_API int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, float *workspace, int planes, int ih, int iw,
+                            int oh, int ow, float scale_h, float scale_w, int align_corners, void *stream);
 /* F.interpolate(x, scale_factor=f, mode="nearest") for an integer factor (layers.py:225-228
  * `upsample`; DHRNet decoder networks/DHRNet.py branch merges): [planes, ih, iw] -> [planes, ih*f, iw*f];
  * adjoint = the f x f block sum (gather, deterministic). */

@@ -93,7 +93,8 @@ _SIGNATURES = {
     "mvf_bias_act_workspace_floats": [_i, _i, _i],
     "mvf_bias_act_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_resize_bilinear_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp],
-    "mvf_resize_bilinear_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp],
+    "mvf_resize_bilinear_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _i, _vp],
+    "mvf_resize_bilinear_bwd_workspace_floats": [_i, _i, _i],
     "mvf_upsample_nearest_fwd": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_upsample_nearest_bwd": [_vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_maxpool3s2_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
@@ -143,7 +144,8 @@ TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine"}
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_profile_name": C.c_char_p, "mvf_profile_read_launches": C.c_int64, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,
             "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t,
-            "mvf_units_workspace_floats": C.c_size_t, "mvf_units_ticket_ints": C.c_size_t}
+            "mvf_units_workspace_floats": C.c_size_t, "mvf_units_ticket_ints": C.c_size_t,
+            "mvf_resize_bilinear_bwd_workspace_floats": C.c_size_t}
 
 EXPORTS = tuple(_SIGNATURES)
 

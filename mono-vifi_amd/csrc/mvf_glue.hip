@@ -679,6 +679,78 @@ __global__ void __launch_bounds__(NT) k_resize_bilinear_bwd(const float *__restr
         if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
 }
 
+// The same adjoint as two separable passes (round 4): bilinear resizing is out = Ry x Rx^T, so g_x = Ry^T (g Rx).
+// The one-pass gather above walks (2f+3) x (2f+1) candidate outputs per input pixel with a dependent load behind every
+// weight test -- 0.08 of the HBM peak on the HRNet fuse layers (up to 8x: ~300 iterations per lane on a 6 x 20 input) and
+// only ih * iw * planes / 4 lanes.  Pass 1 folds the rows: t[iy][ox] = sum over the output rows touching iy (a
+// wave-uniform run, every load a coalesced 16-byte access along ox); pass 2 folds the columns of t (1/f of the size of
+// g).  Same weights (the forward's own arithmetic), fixed order, no atomics; the order of the additions differs from
+// the one-pass form (tolerance-level quantity).
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_resize_bwd_rows(const float *__restrict__ g, float *__restrict__ t, int planes,
+                                                        int ih, int oh, int ow, float sh, int align)
+{
+    constexpr int PV = 2;                                   // planes per lane
+    const int per = VEC ? ow >> 2 : ow;
+    // lanes walk (iy, q) row-major: a row of the fine grid is often narrower than a workgroup (ow / 4 = 40 at 48 x 160)
+    const int i = blockIdx.x * NT + threadIdx.x, p0 = blockIdx.y * PV;
+    if (i >= ih * per) return;
+    const int iy = i / per, q = i - iy * per;
+    int ylo, yhi;
+    resize_run(iy, sh, oh, align, ylo, yhi);
+    const size_t no = (size_t)oh * ow, nt = (size_t)ih * ow;
+    float4 acc[PV];
+#pragma unroll
+    for (int k = 0; k < PV; ++k) acc[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int dy = ylo; dy <= yhi; ++dy) {
+        const float wy = resize_weight(dy, iy, sh, ih, align);
+        if (wy == 0.0f) continue;
+#pragma unroll
+        for (int k = 0; k < PV; ++k) {
+            const float *gp = g + (size_t)min(p0 + k, planes - 1) * no + (size_t)dy * ow;
+            if (VEC) {
+                const float4 v = reinterpret_cast<const float4 *>(gp)[q];
+                acc[k].x += wy * v.x; acc[k].y += wy * v.y; acc[k].z += wy * v.z; acc[k].w += wy * v.w;
+            } else {
+                acc[k].x += wy * gp[q];
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PV; ++k) {
+        if (p0 + k >= planes) continue;
+        float *tp = t + (size_t)(p0 + k) * nt + (size_t)iy * ow;
+        if (VEC) reinterpret_cast<float4 *>(tp)[q] = acc[k];
+        else tp[q] = acc[k].x;
+    }
+}
+// grid (input pixel blocks, plane chunks): g_x[iy][ix] = sum over the columns of t touching ix
+__global__ void __launch_bounds__(NT) k_resize_bwd_cols(const float *__restrict__ t, float *__restrict__ gx, int planes,
+                                                        int ih, int iw, int ow, float sw, int align)
+{
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= ih * iw) return;
+    const int iy = i / iw, ix = i - iy * iw;
+    int xlo, xhi;
+    resize_run(ix, sw, ow, align, xlo, xhi);
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)ih * iw, nt = (size_t)ih * ow;
+    float acc[PLR];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) acc[k] = 0.0f;
+    for (int dx = xlo; dx <= xhi; ++dx) {
+        const float wx = resize_weight(dx, ix, sw, iw, align);
+        if (wx == 0.0f) continue;
+        const float *tp = t + (size_t)p0 * nt + (size_t)iy * ow + dx;
+#pragma unroll
+        for (int k = 0; k < PLR; ++k)
+            if (p0 + k < planes) acc[k] += wx * tp[(size_t)k * nt];
+    }
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
+}
+
 // nearest-neighbour upsampling by an integer factor f (layers.py:225-228 `upsample`, the DHRNet
 // decoder's branch merges): out[Y][X] = x[Y/f][X/f]; adjoint = the f x f block sum (a gather).
 // ATen's NCHW kernels are position-parallel like the bilinear ones (4.6 ms backward per DHRNet step).
@@ -723,6 +795,57 @@ __global__ void __launch_bounds__(NT) k_upsample_nearest_bwd(const float *__rest
 #pragma unroll
     for (int k = 0; k < PLR; ++k)
         if (p0 + k < planes) gx[(size_t)(p0 + k) * ni + i] = acc[k];
+}
+
+// factor 2, even input width, aligned planes (every `upsample` of the decoders): a lane owns TWO input pixels = a 2 x 4
+// output block -- one 8-byte access on the input side, two 16-byte accesses on the output side (the element-per-lane
+// kernels above: 0.45 / 0.34 of the HBM peak).  Same values; the adjoint adds its four terms in the same order.
+__global__ void __launch_bounds__(NT) k_upsample_nearest2_fwd_w(const float *__restrict__ x, float *__restrict__ out,
+                                                                int planes, int ih, int iw)
+{
+    const int iw2 = iw >> 1, ow = iw * 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= ih * iw2) return;
+    const int iy = i / iw2, j = i - iy * iw2;
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)ih * iw, no = ni * 4;
+    float2 v[PLR];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k)
+        v[k] = *reinterpret_cast<const float2 *>(x + (size_t)min(p0 + k, planes - 1) * ni + (size_t)iy * iw + 2 * j);
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) {
+        if (p0 + k >= planes) continue;
+        float *op = out + (size_t)(p0 + k) * no + (size_t)(2 * iy) * ow + 4 * j;
+        const float4 w = make_float4(v[k].x, v[k].x, v[k].y, v[k].y);
+        *reinterpret_cast<float4 *>(op) = w;
+        *reinterpret_cast<float4 *>(op + ow) = w;
+    }
+}
+__global__ void __launch_bounds__(NT) k_upsample_nearest2_bwd_w(const float *__restrict__ g, float *__restrict__ gx,
+                                                                int planes, int ih, int iw)
+{
+    const int iw2 = iw >> 1, ow = iw * 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= ih * iw2) return;
+    const int iy = i / iw2, j = i - iy * iw2;
+    const int p0 = blockIdx.y * PLR;
+    const size_t ni = (size_t)ih * iw, no = ni * 4;
+    float4 a[PLR], b[PLR];
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) {
+        const float *gp = g + (size_t)min(p0 + k, planes - 1) * no + (size_t)(2 * iy) * ow + 4 * j;
+        a[k] = *reinterpret_cast<const float4 *>(gp);
+        b[k] = *reinterpret_cast<const float4 *>(gp + ow);
+    }
+#pragma unroll
+    for (int k = 0; k < PLR; ++k) {
+        if (p0 + k >= planes) continue;
+        // (dy, dx) = (0,0), (0,1), (1,0), (1,1), starting from 0.0f like the element-per-lane kernel
+        const float2 r = make_float2((((0.0f + a[k].x) + a[k].y) + b[k].x) + b[k].y,
+                                     (((0.0f + a[k].z) + a[k].w) + b[k].z) + b[k].w);
+        *reinterpret_cast<float2 *>(gx + (size_t)(p0 + k) * ni + (size_t)iy * iw + 2 * j) = r;
+    }
 }
 
 // ---- 3x3 / stride 2 / pad 1 max pooling of the ResNet stems ------------------------------------
@@ -1466,14 +1589,31 @@ int mvf_resize_bilinear_fwd(const float *x, float *out, int planes, int ih, int 
     return hip_check_launch();
 }
 
-int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, int planes, int ih, int iw, int oh, int ow, float scale_h,
-                            float scale_w, int align_corners, void *stream)
+size_t mvf_resize_bilinear_bwd_workspace_floats(int planes, int ih, int ow)
+{
+    return (planes > 0 && ih > 0 && ow > 0) ? (size_t)planes * ih * ow : 0;
+}
+
+int mvf_resize_bilinear_bwd(const float *g_out, float *g_x, float *workspace, int planes, int ih, int iw, int oh, int ow,
+                            float scale_h, float scale_w, int align_corners, void *stream)
 {
     if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
     if (!g_out || !g_x || oh <= 0 || ow <= 0 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     ProfScope ps(MVF_PROF_RESIZE_BWD, stream, 4LL * planes * ((int64_t)ih * iw + (int64_t)oh * ow));
+    hipStream_t st = (hipStream_t)stream;
+    if (workspace && (planes + 1) / 2 <= 65535 && !getenv("MVF_RESIZE_ONEPASS")) {
+        // rows, then columns (workspace: mvf_resize_bilinear_bwd_workspace_floats(planes, ih, ow) floats)
+        const bool vec = (ow & 3) == 0 && (((uintptr_t)g_out) & 15) == 0 && (((uintptr_t)workspace) & 15) == 0;
+        const int per = vec ? ow >> 2 : ow;
+        const dim3 ga((unsigned)((ih * per + NT - 1) / NT), (unsigned)((planes + 1) / 2));
+        if (vec) hipLaunchKernelGGL(k_resize_bwd_rows<true>, ga, dim3(NT), 0, st, g_out, workspace, planes, ih, oh, ow, scale_h, align_corners);
+        else hipLaunchKernelGGL(k_resize_bwd_rows<false>, ga, dim3(NT), 0, st, g_out, workspace, planes, ih, oh, ow, scale_h, align_corners);
+        hipLaunchKernelGGL(k_resize_bwd_cols, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                           dim3(NT), 0, st, workspace, g_x, planes, ih, iw, ow, scale_w, align_corners);
+        return hip_check_launch();
+    }
     hipLaunchKernelGGL(k_resize_bilinear_bwd, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
-                       dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw, oh, ow, scale_h, scale_w,
+                       dim3(NT), 0, st, g_out, g_x, planes, ih, iw, oh, ow, scale_h, scale_w,
                        align_corners);
     return hip_check_launch();
 }
@@ -1484,6 +1624,11 @@ int mvf_upsample_nearest_fwd(const float *x, float *out, int planes, int ih, int
     if (!x || !out || factor < 1 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     const int no = ih * factor * iw * factor;
     ProfScope ps(MVF_PROF_NEAREST_FWD, stream, 4LL * planes * ((int64_t)ih * iw + no));
+    if (factor == 2 && (iw & 1) == 0 && (((uintptr_t)x) & 7) == 0 && (((uintptr_t)out) & 15) == 0 && !getenv("MVF_NEAREST_NARROW")) {
+        hipLaunchKernelGGL(k_upsample_nearest2_fwd_w, dim3((unsigned)((ih * (iw / 2) + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                           dim3(NT), 0, (hipStream_t)stream, x, out, planes, ih, iw);
+        return hip_check_launch();
+    }
     hipLaunchKernelGGL(k_upsample_nearest_fwd, dim3((unsigned)((no + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, x, out, planes, ih, iw, factor);
     return hip_check_launch();
@@ -1494,6 +1639,11 @@ int mvf_upsample_nearest_bwd(const float *g_out, float *g_x, int planes, int ih,
     if (planes <= 0 || ih <= 0 || iw <= 0) return 0;
     if (!g_out || !g_x || factor < 1 || (planes + PLR - 1) / PLR > 65535) return (int)hipErrorInvalidValue;
     ProfScope ps(MVF_PROF_NEAREST_BWD, stream, 4LL * planes * (int64_t)ih * iw * (1 + factor * factor));
+    if (factor == 2 && (iw & 1) == 0 && (((uintptr_t)g_x) & 7) == 0 && (((uintptr_t)g_out) & 15) == 0 && !getenv("MVF_NEAREST_NARROW")) {
+        hipLaunchKernelGGL(k_upsample_nearest2_bwd_w, dim3((unsigned)((ih * (iw / 2) + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
+                           dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw);
+        return hip_check_launch();
+    }
     hipLaunchKernelGGL(k_upsample_nearest_bwd, dim3((unsigned)((ih * iw + NT - 1) / NT), (unsigned)((planes + PLR - 1) / PLR)),
                        dim3(NT), 0, (hipStream_t)stream, g_out, g_x, planes, ih, iw, factor);
     return hip_check_launch();

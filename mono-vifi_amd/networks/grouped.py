@@ -20,6 +20,7 @@ reference's ``.pth`` files).
 from __future__ import annotations
 
 import contextlib
+import ctypes
 
 import torch
 import torch.distributed as dist
@@ -267,10 +268,9 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         beta = (1 - m) ** G - (1 - m) * sum(c)
         if G <= 32 and _native_vectors(self.running_mean, self.running_var, rm, rv) and \
                 self.num_batches_tracked.is_cuda and self.num_batches_tracked.dtype == torch.int64:
-            import ctypes as C_
             nat, st = _nat()
             nat.check(nat.lib().mvf_bn_fold_running(nat.ptr(self.running_mean), nat.ptr(self.running_var), nat.ptr(rm),
-                                                    nat.ptr(rv), (C_.c_float * G)(*c), float(beta), C, G,
+                                                    nat.ptr(rv), (ctypes.c_float * G)(*c), float(beta), C, G,
                                                     nat.ptr(self.num_batches_tracked), st), "bn_fold_running")
             return
         coef = const_tensor(c, rm.device, rm.dtype)

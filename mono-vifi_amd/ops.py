@@ -1107,8 +1107,12 @@ class ResizeBilinear(torch.autograd.Function):
         N, C, ih, iw, oh, ow, sh, sw, align = ctx.geom
         g = _c(g)
         gx = torch.empty((N, C, ih, iw), dtype=torch.float32, device=g.device)
-        nat.check(nat.lib().mvf_resize_bilinear_bwd(nat.ptr(g), nat.ptr(gx), N * C, ih, iw, oh, ow, sh, sw, align,
-                                                    _stream()), "resize_bilinear_bwd")
+        # rows of g folded first (N*C x ih x ow floats), then the columns: two coalesced passes instead of a
+        # (2f+3) x (2f+1) candidate walk per input pixel
+        ws = torch.empty(int(nat.lib().mvf_resize_bilinear_bwd_workspace_floats(N * C, ih, ow)), dtype=torch.float32,
+                         device=g.device)
+        nat.check(nat.lib().mvf_resize_bilinear_bwd(nat.ptr(g), nat.ptr(gx), nat.ptr(ws), N * C, ih, iw, oh, ow, sh, sw,
+                                                    align, _stream()), "resize_bilinear_bwd")
         return gx, None, None, None, None, None
 
 

@@ -7,6 +7,7 @@ grid, SSIM, reprojection, to_optimise); <= 1e-4 relative (tensor level: max|a-b|
 for bilinear values, reductions and gradients -- the tolerance north_star states.
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -1122,6 +1123,15 @@ def test_resize_bilinear_vs_oracle(dev):
         (ops.resize_bilinear(x2, size=None if sf is not None else (oh, ow), scale_factor=sf, align_corners=ac)
          * T(w, dev)).sum().backward()
         assert torch.equal(x2.grad, xt.grad)
+        # the one-pass gather (workspace-free form) and the separable two-pass adjoint agree
+        os.environ["MVF_RESIZE_ONEPASS"] = "1"
+        try:
+            x4 = T(x, dev, True)
+            (ops.resize_bilinear(x4, size=None if sf is not None else (oh, ow), scale_factor=sf, align_corners=ac)
+             * T(w, dev)).sum().backward()
+        finally:
+            del os.environ["MVF_RESIZE_ONEPASS"]
+        assert rel_err(N(x4.grad), gref) <= 1e-5 and rel_err(N(x4.grad), N(xt.grad)) <= 2e-6
         # ATen's own device kernel agrees
         x3 = T(x, dev, True)
         y3 = (F.interpolate(x3, scale_factor=sf, mode="bilinear", align_corners=ac) if sf is not None
@@ -1198,7 +1208,8 @@ def test_upsample_nearest_vs_torch(dev):
     import torch.nn.functional as F
     from mono_vifi_amd import layers, ops
     g = torch.Generator(device="cpu").manual_seed(17)
-    for (B, C, h, w, f) in ((2, 18, 24, 80, 2), (1, 5, 3, 7, 4), (2, 36, 12, 40, 8), (1, 1, 1, 1, 2), (2, 7, 9, 5, 1)):
+    for (B, C, h, w, f) in ((2, 18, 24, 80, 2), (1, 5, 3, 7, 4), (2, 36, 12, 40, 8), (1, 1, 1, 1, 2), (2, 7, 9, 5, 1),
+                            (3, 5, 7, 6, 2), (1, 3, 4, 5, 2)):
         x = torch.randn(B, C, h, w, generator=g).to(dev)
         xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
         ya = layers.upsample(xa, f)
@@ -1208,6 +1219,15 @@ def test_upsample_nearest_vs_torch(dev):
         (ya * wgt).sum().backward()
         (yb * wgt).sum().backward()
         assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * max(1.0, float(xb.grad.abs().max()))
+        # the wide factor-2 kernels and the element-per-lane kernels: same bits
+        os.environ["MVF_NEAREST_NARROW"] = "1"
+        try:
+            xc = x.clone().requires_grad_(True)
+            yc = layers.upsample(xc, f)
+            (yc * wgt).sum().backward()
+        finally:
+            del os.environ["MVF_NEAREST_NARROW"]
+        assert torch.equal(yc, ya) and torch.equal(xc.grad, xa.grad)
 
 
 # ------------------------------------------------------------------ f4: on-device augmentation
