@@ -164,3 +164,32 @@ def test_tail_bucket_holds_the_last_arriving_gradients():
     red2 = parallel.BucketedGradReducer([nn.Parameter(torch.zeros(n)) for n in sizes], world_size=1,
                                         bucket_mb=8.0, tail_mb=0.0)
     assert [[p.numel() for p in b.params] for b in red2.buckets][-1] == [3 * mb, mb, mb // 2, mb // 2]
+
+
+def test_single_process_keeps_backward_gradients_and_none_for_unused():
+    """Without an exchange (one process, no forced collectives) nothing is packed: a gradient stays the tensor backward
+    produced (no add into a zeroed bucket, no memset), a parameter the step does not reach keeps grad None (the
+    optimiser skips it, as in the reference's single-process run), and zero_grad() resets both every step."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from mono_vifi_amd import parallel
+    torch.manual_seed(0)
+    net = _net()
+    params = parallel.unique_parameters(net.values())
+    red = parallel.BucketedGradReducer(params, world_size=1, bucket_mb=0.0001)
+    assert not red.exchanging and red.num_buckets > 1
+    x = torch.randn(4, 8)
+    ref = None
+    for it in range(2):
+        red.zero_grad()
+        assert all(p.grad is None for p in params)
+        net["b"](torch.relu(net["a"](x)) + net["a_alias"](x)).pow(2).mean().backward()
+        red.finish()
+        assert red.issued_from_hook + red.issued_from_finish == red.num_buckets
+        used = [p for k in ("a", "b") for p in net[k].parameters()]
+        assert all(p.grad is not None and p.grad.data_ptr() != red.bucket_view(p).data_ptr() for p in used)
+        assert all(p.grad is None for p in net["unused"].parameters())
+        got = [p.grad.clone() for p in used]
+        if ref is not None:
+            assert all(torch.equal(a, b) for a, b in zip(got, ref))     # no accumulation across steps
+        ref = got
