@@ -398,6 +398,16 @@ MVF_API int mvf_bn_fold_running(float *running_mean, float *running_var, const f
 MVF_API int mvf_bn_untile(const float *g_weight_tiled, const float *g_bias_tiled, float *g_out, int C, int G,
                   void *stream);
 
+/* The same two steps for ALL grouped batch-norm layers of a network at once.  rows: DEVICE array of
+ * n_layers records of eight 8-byte fields { const float *weight, *bias; float *running_mean,
+ * *running_var, *tiled [4][G*C]; int64_t *num_batches_tracked (nullable); int64_t C; int64_t pad }.
+ * mvf_bn_tile_many fills every layer's `tiled` (when the grouped call begins); mvf_bn_fold_many
+ * folds rows 2, 3 of every `tiled` into the running statistics and advances the counters (when
+ * it ends).  max_channels = the largest C of the table. */
+MVF_API int mvf_bn_tile_many(const void *rows, int n_layers, int max_channels, int G, void *stream);
+MVF_API int mvf_bn_fold_many(const void *rows, int n_layers, int max_channels, const float *coef, float beta,
+                     int G, void *stream);
+
 /* ---- f4: step glue either side of the hot path ------------------
  * Decoder stage glue (networks/monodepth2.py:84-90 with layers.py:121-138, 225-228): the padded
  * input of upconv_1, out [B, C1+C2, 2h+2, 2w+2] = ReflectionPad2d(1)(cat([upsample_nearest_x2(x),

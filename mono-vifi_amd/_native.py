@@ -103,6 +103,8 @@ _SIGNATURES = {
     "mvf_bn_tile": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "mvf_bn_fold_running": [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp],
     "mvf_bn_untile": [_vp, _vp, _vp, _i, _i, _vp],
+    "mvf_bn_tile_many": [_vp, _i, _i, _i, _vp],
+    "mvf_bn_fold_many": [_vp, _i, _i, _vp, _f, _i, _vp],
     "mvf_regroup_fwd": [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp],
     "mvf_regroup_bwd": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp],
     "mvf_interleave_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i64, _vp],

@@ -21,6 +21,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -31,6 +32,9 @@ from ..consts import const_tensor
 def _count(kind):
     from ..parallel import count_collective
     count_collective(kind)
+
+
+_BN_PLAN = os.environ.get("MVF_BN_PLAN", "1") != "0"      # developer knob: per-layer launches instead of the layer plan
 
 
 def _native_vectors(*tensors):
@@ -77,10 +81,12 @@ class _FoldedBN(torch.autograd.Function):
     one momentum update from the common starting value (folded by the caller)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, groups, momentum, eps):
+    def forward(ctx, x, weight, bias, running_mean, running_var, groups, momentum, eps, tiled=None):
         N, C = x.shape[0], x.shape[1]
         xv = x.view(N // groups, groups * C, *x.shape[2:])
-        if _native_vectors(weight, bias, running_mean, running_var):
+        if tiled is not None:            # filled for every layer of the network when the grouped call began (_BnPlan)
+            wG, bG, rmG, rvG = tiled.unbind(0)
+        elif _native_vectors(weight, bias, running_mean, running_var):
             nat, st = _nat()
             tiled = torch.empty((4, groups * C), dtype=torch.float32, device=x.device)
             nat.check(nat.lib().mvf_bn_tile(nat.ptr(weight), nat.ptr(bias), nat.ptr(running_mean), nat.ptr(running_var),
@@ -101,7 +107,7 @@ class _FoldedBN(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy, _grm, _grv):
         if gy is None:
-            return (None,) * 8
+            return (None,) * 9
         xv, wG, rm, rv, save_mean, save_var, reserve = ctx.saved_tensors
         gx, gw, gb = torch.ops.aten._batch_norm_impl_index_backward(
             ctx.impl, xv, gy.contiguous().view_as(xv), wG, rm, rv, save_mean, save_var, True, ctx.eps,
@@ -114,7 +120,7 @@ class _FoldedBN(torch.autograd.Function):
             nat.check(nat.lib().mvf_bn_untile(nat.ptr(gw), nat.ptr(gb), nat.ptr(gwb), Cn, G, st), "bn_untile")
         else:
             gwb = torch.stack([gw, gb]).view(2, G, gw.numel() // G).sum(1)      # adjoint of the tiling
-        return gx.view_as(gy), gwb[0], gwb[1], None, None, None, None, None
+        return gx.view_as(gy), gwb[0], gwb[1], None, None, None, None, None, None
 
 
 class _AllReduceSyncBN(torch.autograd.Function):
@@ -216,6 +222,7 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.groups = 1
+        self._plan, self._tiled, self._called = None, None, False     # see _BnPlan
         self.sync = False            # synchronise statistics across ranks (SyncBatchNorm semantics)
         self.force_sync = False      # take the synchronised branch even in a group of one (tests)
         self.process_group = None
@@ -244,16 +251,35 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
             raise RuntimeError(f"batch {N} is not a multiple of the group count {G}")
         if not x.is_contiguous():
             x = x.contiguous()
+        plan = self._plan                   # set by grouped() while a call with a prepared plan is running
+        tiled = None
+        if plan is not None and plan.tiled_for(self, G):
+            if self._called:
+                raise RuntimeError("a GroupedBatchNorm2d layer ran twice inside one grouped() call: its prepared "
+                                   "statistics buffer holds the first call's update (set MVF_BN_PLAN=0 for such a network)")
+            tiled = self._tiled
+            self._called = True
         if sync:
             xv = x.view(N // G, G * C, *x.shape[2:])
+            # (weight and bias reach the synchronised function through autograd: their tiling stays a differentiable repeat)
             w, b = self.weight.repeat(G), self.bias.repeat(G)
-            rm, rv = self.running_mean.repeat(G), self.running_var.repeat(G)
+            if tiled is not None:
+                rm, rv = tiled[2], tiled[3]
+            else:
+                rm, rv = self.running_mean.repeat(G), self.running_var.repeat(G)
             y = self._sync_bn(xv, w, b, rm, rv, world, x.shape)
         else:
             y, rm, rv = _FoldedBN.apply(x, self.weight, self.bias, self.running_mean, self.running_var, G,
-                                        self.momentum, self.eps)
-        self._fold_running(rm, rv, G, C)
+                                        self.momentum, self.eps, tiled)
+        if tiled is None:                   # (with a plan, every layer's fold runs in ONE launch when the call ends)
+            self._fold_running(rm, rv, G, C)
         return y
+
+    @staticmethod
+    def fold_coefficients(m, G):
+        """(c_g, beta) of `_fold_running` for momentum m and G groups."""
+        c = [(1 - m) ** (G - 1 - g) for g in range(G)]
+        return c, (1 - m) ** G - (1 - m) * sum(c)
 
     @torch.no_grad()
     def _fold_running(self, rm, rv, G, C):
@@ -263,9 +289,7 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         With upd_g = r_g this is r <- [(1-m)^G - (1-m) sum_g c_g] r + sum_g c_g upd_g,
         c_g = (1-m)^(G-1-g): ONE matrix-vector launch per statistic (it was eight element-wise
         launches)."""
-        m = self.momentum
-        c = [(1 - m) ** (G - 1 - g) for g in range(G)]
-        beta = (1 - m) ** G - (1 - m) * sum(c)
+        c, beta = self.fold_coefficients(self.momentum, G)
         if G <= 32 and _native_vectors(self.running_mean, self.running_var, rm, rv) and \
                 self.num_batches_tracked.is_cuda and self.num_batches_tracked.dtype == torch.int64:
             nat, st = _nat()
@@ -300,6 +324,87 @@ def convert_grouped_batchnorm(module, sync=False, process_group=None, force_sync
     return out
 
 
+class _BnPlan:
+    """The vector glue of ALL grouped batch-norm layers of a network as one launch per grouped call each way.
+
+    Per layer a persistent ``_tiled [4, G*C]`` buffer (weight | bias | running_mean | running_var repeated G times)
+    and one row of a device table (`mvf_bn_tile_many` / `mvf_bn_fold_many`, include/mvf_hotpath.h).  ``begin()`` fills
+    every buffer from the current parameters and statistics; the layers' forwards hand their buffer to the
+    batch-norm call (which advances rows 2, 3 in place, one momentum update per group); ``end()`` folds those rows into
+    the running statistics and advances the step counters -- for the layers that ran; if some did not (a network
+    with a conditional branch), the per-layer fold is used for the ones that did.  The table is rebuilt only when a
+    parameter or buffer moved (``.to()``, a replaced tensor)."""
+    PLANS = {}
+
+    def __init__(self, bns, groups):
+        self.bns, self.G = bns, groups
+        self.key = self.table = None
+        self.max_c = max(m.num_features for m in bns)
+        self.live = False
+
+    @classmethod
+    def of(cls, module, bns, groups):
+        """The plan of (module, groups), or None where it does not apply (CPU, mixed momenta / devices, G > 32)."""
+        if groups < 2 or groups > 32 or not bns or not _BN_PLAN:
+            return None
+        m0 = bns[0]
+        if not all(m.training and m.affine and m.track_running_stats and m.momentum == m0.momentum and
+                   m.momentum is not None and m.weight.device == m0.weight.device and
+                   _native_vectors(m.weight, m.bias, m.running_mean, m.running_var) and
+                   m.num_batches_tracked.is_cuda and m.num_batches_tracked.dtype == torch.int64 for m in bns):
+            return None
+        key = (id(module), groups)
+        plan = cls.PLANS.get(key)
+        if plan is None or plan.bns != bns:
+            plan = cls.PLANS[key] = cls(bns, groups)
+        return plan
+
+    def _ensure_table(self):
+        G = self.G
+        for m in self.bns:
+            if m._tiled is None or m._tiled.shape[1] != G * m.num_features or m._tiled.device != m.weight.device:
+                m._tiled = torch.empty((4, G * m.num_features), dtype=torch.float32, device=m.weight.device)
+        key = tuple(p for m in self.bns for p in (m.weight.data_ptr(), m.bias.data_ptr(), m.running_mean.data_ptr(),
+                                                  m.running_var.data_ptr(), m._tiled.data_ptr(),
+                                                  m.num_batches_tracked.data_ptr()))
+        if key != self.key:
+            rows = []
+            for i, m in enumerate(self.bns):
+                rows.append(list(key[6 * i:6 * i + 6]) + [m.num_features, 0])
+            host = torch.tensor(rows, dtype=torch.int64).pin_memory()
+            self.table = host.to(self.bns[0].weight.device, non_blocking=True)
+            self._host = host           # keep the pinned source alive until the copy has run
+            self.key = key
+
+    def begin(self):
+        self._ensure_table()
+        nat, st = _nat()
+        nat.check(nat.lib().mvf_bn_tile_many(nat.ptr(self.table), len(self.bns), self.max_c, self.G, st), "bn_tile_many")
+        for m in self.bns:
+            m._plan, m._called = self, False
+        self.live = True
+
+    def tiled_for(self, m, G):
+        return self.live and G == self.G and m._tiled is not None
+
+    def end(self):
+        self.live = False
+        called = [m for m in self.bns if m._called]
+        for m in self.bns:
+            m._plan = None
+        if not called:
+            return
+        G = self.G
+        if len(called) == len(self.bns):
+            c, beta = GroupedBatchNorm2d.fold_coefficients(self.bns[0].momentum, G)
+            nat, st = _nat()
+            nat.check(nat.lib().mvf_bn_fold_many(nat.ptr(self.table), len(self.bns), self.max_c, (ctypes.c_float * G)(*c),
+                                                 float(beta), G, st), "bn_fold_many")
+            return
+        for m in called:
+            m._fold_running(m._tiled[2], m._tiled[3], G, m.num_features)
+
+
 @contextlib.contextmanager
 def grouped(module, groups):
     """Within the block, the BatchNorm layers of ``module`` treat their input as ``groups``
@@ -309,8 +414,13 @@ def grouped(module, groups):
         raise RuntimeError("grouped(): convert the module with convert_grouped_batchnorm() first")
     for m in bns:
         m.groups = groups
+    plan = _BnPlan.of(module, bns, groups)
+    if plan is not None:
+        plan.begin()
     try:
         yield module
     finally:
         for m in bns:
             m.groups = 1
+        if plan is not None:
+            plan.end()
