@@ -398,6 +398,13 @@ MVF_API int mvf_bn_fold_running(float *running_mean, float *running_var, const f
 MVF_API int mvf_bn_untile(const float *g_weight_tiled, const float *g_bias_tiled, float *g_out, int C, int G,
                   void *stream);
 
+/* out = act(((t0 + t1) + t2) + ...) over `total` elements, act in {0 none, 2 relu}: the branch sum of
+ * an HRNet fuse layer (networks/hrnet_encoder.py: y = y + term per branch, then self.relu(y)) in one
+ * pass.  terms: HOST array of n_terms <= 8 device pointers.  Left-to-right sum (bit-identical to
+ * the term-at-a-time form); the adjoint is mvf_bias_act_bwd's activation pass, shared by all terms. */
+MVF_API int mvf_sum_act_fwd(const float *const *terms, int n_terms, float *out, int64_t total, int act,
+                    void *stream);
+
 /* The same two steps for ALL grouped batch-norm layers of a network at once.  rows: DEVICE array of
  * n_layers records of eight 8-byte fields { const float *weight, *bias; float *running_mean,
  * *running_var, *tiled [4][G*C]; int64_t *num_batches_tracked (nullable); int64_t C; int64_t pad }.
@@ -530,7 +537,8 @@ MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32
 #define MVF_PROF_REGROUP_FWD 32      /* k_regroup_fwd */
 #define MVF_PROF_REGROUP_BWD 33      /* k_regroup_bwd */
 #define MVF_PROF_INTERLEAVE_FWD 34   /* k_interleave_fwd */
-#define MVF_PROF_COUNT 35
+#define MVF_PROF_SUM_ACT_FWD 35      /* k_sum_act_fwd */
+#define MVF_PROF_COUNT 36
 /* launch tags of MVF_PROF_UNIT_FWDBWD (mvf_profile_read_launches): what kind of unit group a launch carried */
 #define MVF_TAG_SINGLE_FRAME 0  /* identity candidates evaluated (and possibly handed over: ident_out) */
 #define MVF_TAG_MULTI_FRAME 1   /* identity maps taken from another unit (ident_in) */

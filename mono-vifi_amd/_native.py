@@ -105,6 +105,7 @@ _SIGNATURES = {
     "mvf_bn_untile": [_vp, _vp, _vp, _i, _i, _vp],
     "mvf_bn_tile_many": [_vp, _i, _i, _i, _vp],
     "mvf_bn_fold_many": [_vp, _i, _i, _vp, _f, _i, _vp],
+    "mvf_sum_act_fwd": [_vp, _i, _vp, _i64, _i, _vp],
     "mvf_regroup_fwd": [_vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp],
     "mvf_regroup_bwd": [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp],
     "mvf_interleave_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i64, _vp],
@@ -141,7 +142,7 @@ _SIGNATURES = {
 }
 (PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD,
  PROF_UNIT_FWDBWD) = range(7)
-PROF_FIRST_GLUE, PROF_COUNT = 7, 35         # ids >= 7: glue kernels, profile level 2, work = algorithmic bytes
+PROF_FIRST_GLUE, PROF_COUNT = 7, 36         # ids >= 7: glue kernels, profile level 2, work = algorithmic bytes
 TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine"}
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_profile_name": C.c_char_p, "mvf_profile_read_launches": C.c_int64, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,

@@ -875,7 +875,7 @@ const char *mvf_profile_name(int id)
         "k_reflect_pad1_bwd", "k_maxpool3s2_fwd", "k_maxpool3s2_bwd", "k_fusion_level_fwd",
         "k_fusion_level_bwd_gather", "k_flow_warp_fwd", "k_disp_head_fwd", "k_disp_head_bwd",
         "k_resize_bilinear_fwd", "k_resize_bilinear_bwd", "k_upsample_nearest_fwd", "k_upsample_nearest_bwd",
-        "k_silog_fwd", "k_silog_bwd", "k_affine", "k_regroup_fwd", "k_regroup_bwd", "k_interleave_fwd"};
+        "k_silog_fwd", "k_silog_bwd", "k_affine", "k_regroup_fwd", "k_regroup_bwd", "k_interleave_fwd", "k_sum_act_fwd"};
     return (id >= 0 && id < MVF_PROF_COUNT) ? names[id] : "?";
 }
 

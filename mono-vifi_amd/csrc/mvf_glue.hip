@@ -395,6 +395,40 @@ __global__ void __launch_bounds__(NT) k_bias_act_fwd(const float *__restrict__ x
     }
 }
 
+// out = act(((t0 + t1) + t2) + ...): the branch sum of an HRNet fuse layer (reference networks/hrnet_encoder.py:
+// `y = y + ...` per branch, then ReLU) in one pass -- the term-at-a-time form reads and writes the accumulator once
+// per branch (11 tensor passes for four branches; 5 here).  Same left-to-right sum, same bits.
+constexpr int SUM_MAX = 8;
+MVF_DEV float relu_nan(float v) { return (v < 0.0f) ? 0.0f : v; }       // ATen's relu: NaN stays NaN, -0.0 stays -0.0
+struct SumTerms {
+    const float *t[SUM_MAX];
+    int n;
+};
+template <bool VEC>
+__global__ void __launch_bounds__(NT) k_sum_act_fwd(SumTerms ts, float *__restrict__ out, int64_t total, int act)
+{
+    constexpr int U = 4;
+    const int64_t i0 = (int64_t)blockIdx.x * (NT * U) + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        const int64_t i = i0 + k * NT;
+        if (i >= total) continue;
+        if (VEC) {
+            float4 a = reinterpret_cast<const float4 *>(ts.t[0])[i];
+            for (int j = 1; j < ts.n; ++j) {
+                const float4 b = reinterpret_cast<const float4 *>(ts.t[j])[i];
+                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            }
+            if (act == ACT_RELU) { a.x = relu_nan(a.x); a.y = relu_nan(a.y); a.z = relu_nan(a.z); a.w = relu_nan(a.w); }
+            reinterpret_cast<float4 *>(out)[i] = a;
+        } else {
+            float a = ts.t[0][i];
+            for (int j = 1; j < ts.n; ++j) a += ts.t[j][i];
+            out[i] = (act == ACT_RELU) ? relu_nan(a) : a;
+        }
+    }
+}
+
 // g_x = g * act'(out) alone (no bias to reduce for): flat, ELU / ReLU
 template <bool VEC>
 __global__ void __launch_bounds__(NT) k_act_bwd_flat(const float *__restrict__ g, const float *__restrict__ out,
@@ -1757,6 +1791,26 @@ int mvf_bn_fold_many(const void *rows, int n_layers, int max_channels, const flo
     const int bx = (max_channels + NT - 1) / NT;
     hipLaunchKernelGGL(k_bn_fold_many, dim3((unsigned)(bx < 8 ? bx : 8), (unsigned)n_layers), dim3(NT), 0, (hipStream_t)stream,
                        reinterpret_cast<const BnRow *>(rows), cf, beta, G);
+    return hip_check_launch();
+}
+
+
+int mvf_sum_act_fwd(const float *const *terms, int n_terms, float *out, int64_t total, int act, void *stream)
+{
+    if (total <= 0 || n_terms <= 0) return 0;
+    if (!terms || !out || n_terms > SUM_MAX || (act != ACT_NONE && act != ACT_RELU)) return (int)hipErrorInvalidValue;
+    SumTerms ts;
+    bool vec = (total & 3) == 0 && (((uintptr_t)out) & 15) == 0;
+    for (int j = 0; j < SUM_MAX; ++j) {
+        ts.t[j] = j < n_terms ? terms[j] : nullptr;
+        if (j < n_terms && (!terms[j] || (((uintptr_t)terms[j]) & 15))) { if (!terms[j]) return (int)hipErrorInvalidValue; vec = false; }
+    }
+    ts.n = n_terms;
+    const int64_t per = vec ? total / 4 : total, blocks = (per + NT * 4 - 1) / (NT * 4);
+    if (blocks > 0x7fffffffLL) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_SUM_ACT_FWD, stream, 4LL * (n_terms + 1) * total);
+    if (vec) hipLaunchKernelGGL(k_sum_act_fwd<true>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, ts, out, per, act);
+    else hipLaunchKernelGGL(k_sum_act_fwd<false>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, ts, out, per, act);
     return hip_check_launch();
 }
 

@@ -333,8 +333,7 @@ class _BnPlan:
     batch-norm call (which advances rows 2, 3 in place, one momentum update per group); ``end()`` folds those rows into
     the running statistics and advances the step counters -- for the layers that ran; if some did not (a network
     with a conditional branch), the per-layer fold is used for the ones that did.  The table is rebuilt only when a
-    parameter or buffer moved (``.to()``, a replaced tensor)."""
-    PLANS = {}
+    parameter or buffer moved (``.to()``, a replaced tensor).  Plans live on the network module they belong to."""
 
     def __init__(self, bns, groups):
         self.bns, self.G = bns, groups
@@ -353,10 +352,10 @@ class _BnPlan:
                    _native_vectors(m.weight, m.bias, m.running_mean, m.running_var) and
                    m.num_batches_tracked.is_cuda and m.num_batches_tracked.dtype == torch.int64 for m in bns):
             return None
-        key = (id(module), groups)
-        plan = cls.PLANS.get(key)
+        plans = module.__dict__.setdefault("_mvf_bn_plans", {})
+        plan = plans.get(groups)
         if plan is None or plan.bns != bns:
-            plan = cls.PLANS[key] = cls(bns, groups)
+            plan = plans[groups] = cls(bns, groups)
         return plan
 
     def _ensure_table(self):

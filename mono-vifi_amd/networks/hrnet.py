@@ -13,7 +13,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from .resnet import BasicBlock, Bottleneck
+
+FUSED_SUM = os.environ.get("MVF_HRNET_FUSED_SUM", "1") != "0"      # developer knob for A/B timing (ops.sum_act)
 
 
 def _resize_ac(x, size):
@@ -72,7 +76,7 @@ class ExchangeModule(nn.Module):
         xs = [branch(x) for branch, x in zip(self.branches, xs)]
         out = []
         for i in range(self.num_branches):
-            acc = None
+            terms = []
             for j in range(self.num_branches):
                 if j == i:
                     term = xs[j]
@@ -80,6 +84,15 @@ class ExchangeModule(nn.Module):
                     term = _resize_ac(self.fuse_layers[i][j](xs[j]), xs[i].shape[-2:])
                 else:
                     term = self.fuse_layers[i][j](xs[j])
+                terms.append(term)
+            t0 = terms[0]
+            if (FUSED_SUM and len(terms) > 1 and t0.is_cuda and t0.dtype == torch.float32 and
+                    not torch.is_autocast_enabled() and all(t.shape == t0.shape and t.dtype == t0.dtype for t in terms)):
+                from .. import ops
+                out.append(ops.sum_act(terms, "relu"))       # ((t0 + t1) + t2) + ... and the ReLU in one pass
+                continue
+            acc = None
+            for term in terms:
                 acc = term if acc is None else acc + term
             out.append(self.relu(acc))
         return out

@@ -1426,6 +1426,47 @@ def bias_act(x, bias=None, act="none", slope=None, res=None, inplace=False):
     return BiasAct.apply(x, bias, slope, res, _ACT_CODES[act], bool(inplace))
 
 
+class SumAct(torch.autograd.Function):
+    """act(((t0 + t1) + t2) + ...) in one pass (the branch sum + ReLU of an HRNet fuse layer: reference
+    networks/hrnet_encoder.py `y = y + ...; self.relu(y)`).  The gradient g * act'(out) is the same tensor for
+    every term."""
+
+    @staticmethod
+    def forward(ctx, act, *terms):
+        nat.require_device(*terms)
+        ts = [_c(t) for t in terms]
+        if any(t.shape != ts[0].shape or t.dtype != torch.float32 for t in ts):
+            raise RuntimeError("sum_act: terms must be float32 tensors of one shape")
+        if not 1 <= len(ts) <= 8:
+            raise RuntimeError("sum_act: 1..8 terms")
+        out = torch.empty_like(ts[0])
+        arr, keep = nat.ptr_array(ts)
+        nat.check(nat.lib().mvf_sum_act_fwd(arr, len(ts), nat.ptr(out), out.numel(), act, _stream()), "sum_act_fwd")
+        del keep
+        ctx.act, ctx.n = act, len(ts)
+        ctx.save_for_backward(out if act == 2 else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _c(g)
+        if ctx.act == 2:
+            (out,) = ctx.saved_tensors
+            gx = torch.empty_like(g)
+            N, C = (g.shape[0], g.shape[1]) if g.dim() >= 2 else (1, g.numel())
+            HW = g.numel() // (N * C)
+            nat.check(nat.lib().mvf_bias_act_bwd(nat.ptr(g), nat.ptr(out), nat.ptr(gx), None, None, N, C, HW, 2, _stream()),
+                      "sum_act_bwd")
+        else:
+            gx = g
+        return (None,) + (gx,) * ctx.n
+
+
+def sum_act(terms, act="relu"):
+    """act(sum of terms, left to right); act in {"none", "relu"}."""
+    return SumAct.apply(_ACT_CODES[act], *terms)
+
+
 def color_jitter(img, factors, order, apply, flip, frames=1, want_raw=False):
     """Flip + torchvision-style ColorJitter for a batch on the device (reference: the per-item
     host work of datasets/mono_dataset.py:214-256).  img [samples*frames,3,H,W] with the frames of

@@ -1389,3 +1389,36 @@ def test_maxpool_tap_adds_the_other_gradient_in_the_pass(shape):
     xd = x.clone().requires_grad_(True)
     (ops.maxpool3s2(xd) * w1).sum().backward()
     assert torch.equal(xc.grad, xd.grad)
+
+
+@pytest.mark.parametrize("shape,n", [((3, 18, 12, 40), 4), ((2, 5, 7, 9), 3), ((1, 4, 4, 4), 2), ((2, 3, 5, 7), 1)])
+def test_sum_act_equals_term_at_a_time(shape, n):
+    """ops.sum_act == relu(((t0 + t1) + t2) + ...) bit for bit (NaN and -0.0 like ATen's relu), gradient
+    g * (out > 0) for every term; the scalar route for sizes that are no multiple of four."""
+    from mono_vifi_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ts = [torch.randn(shape, device="cuda", generator=g) for _ in range(n)]
+    ts[0].view(-1)[0] = float("nan")
+    ts[0].view(-1)[1] = -0.0
+    for t in ts[1:]:
+        t.view(-1)[1] = -0.0
+    a = [t.clone().requires_grad_(True) for t in ts]
+    b = [t.clone().requires_grad_(True) for t in ts]
+    out = ops.sum_act(a, "relu")
+    acc = None
+    for t in b:
+        acc = t if acc is None else acc + t
+    ref = torch.relu(acc)
+    assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(ref, nan=7.0))
+    assert bool(torch.isnan(out.view(-1)[0])) and bool(torch.isnan(ref.view(-1)[0]))
+    w = torch.randn(shape, device="cuda", generator=g)
+    w.view(-1)[0] = 0.0
+    (torch.nan_to_num(out) * w).sum().backward()
+    (torch.nan_to_num(ref) * w).sum().backward()
+    for x, y in zip(a, b):
+        assert torch.equal(torch.nan_to_num(x.grad), torch.nan_to_num(y.grad))
+    lin = ops.sum_act([t.clone() for t in ts[1:]] or [ts[0].clone()], "none")
+    acc = None
+    for t in (ts[1:] or [ts[0]]):
+        acc = t if acc is None else acc + t
+    assert torch.equal(torch.nan_to_num(lin, nan=7.0), torch.nan_to_num(acc, nan=7.0))
