@@ -399,7 +399,7 @@ MVF_API int mvf_bn_untile(const float *g_weight_tiled, const float *g_bias_tiled
                   void *stream);
 
 /* out = act(((t0 + t1) + t2) + ...) over `total` elements, act in {0 none, 2 relu}: the branch sum of
- * an HRNet fuse layer (networks/hrnet_encoder.py: y = y + term per branch, then self.relu(y)) in one
+ * an HRNet fuse layer (networks/hrnet_encoder.py:267-285: y = y + term per branch, self.relu(y)) in one
  * pass.  terms: HOST array of n_terms <= 8 device pointers.  Left-to-right sum (bit-identical to
  * the term-at-a-time form); the adjoint is mvf_bias_act_bwd's activation pass, shared by all terms. */
 MVF_API int mvf_sum_act_fwd(const float *const *terms, int n_terms, float *out, int64_t total, int act,

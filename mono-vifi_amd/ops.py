@@ -1428,7 +1428,7 @@ def bias_act(x, bias=None, act="none", slope=None, res=None, inplace=False):
 
 class SumAct(torch.autograd.Function):
     """act(((t0 + t1) + t2) + ...) in one pass (the branch sum + ReLU of an HRNet fuse layer: reference
-    networks/hrnet_encoder.py `y = y + ...; self.relu(y)`).  The gradient g * act'(out) is the same tensor for
+    networks/hrnet_encoder.py:267-285 `y = y + ...; self.relu(y)`).  The gradient g * act'(out) is the same tensor for
     every term."""
 
     @staticmethod
