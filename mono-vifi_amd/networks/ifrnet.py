@@ -6,6 +6,8 @@ Architecture, call signature and state-dict keys follow reference networks/IFRNe
 (census / geometry / Charbonnier, IFRNet.py:18-126) belong to ``train_vfi.py`` and are out
 of scope: passing ``imgt`` raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -23,6 +25,7 @@ def _hip_flow_warp(img, flow):
 # reference's modules (tests/test_networks_vs_reference.py) can inject a torch restatement;
 # the product default is the gfx950 kernel (no CPU fallback).
 WARP_IMPL = _hip_flow_warp
+RESIZE_KERNEL = os.environ.get("MVF_IFRNET_RESIZE", "1") != "0"      # developer knob for A/B timing
 
 
 def warp(img, flow):
@@ -32,8 +35,20 @@ def warp(img, flow):
     return WARP_IMPL(img, flow)
 
 
-def resize(x, scale_factor):
+def _interp(x, size=None, scale_factor=None):
+    """F.interpolate(..., mode="bilinear", align_corners=False); on the HIP device (fp32) the element-parallel
+    kernel of ops.resize_bilinear -- ATen's NCHW kernel is position-parallel and loops over batch x channels inside a
+    lane (40 us for a 35 MB flow field, eleven of them per teacher pass)."""
+    if RESIZE_KERNEL and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled():
+        from .. import ops
+        return ops.resize_bilinear(x, size=size, scale_factor=scale_factor, align_corners=False)
+    if size is not None:
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
     return F.interpolate(x, scale_factor=scale_factor, mode="bilinear", align_corners=False)
+
+
+def resize(x, scale_factor):
+    return _interp(x, scale_factor=scale_factor)
 
 
 class ConvPReLU(nn.Sequential):
@@ -145,8 +160,8 @@ class IFRNet(nn.Module):
         img0 = img0 - mean_
         img1 = img1 - mean_
         fh, fw = int(H * scale_factor[0]), int(W * scale_factor[1])
-        f0 = self.encoder(F.interpolate(img0, size=(fh, fw), mode="bilinear", align_corners=False))
-        f1 = self.encoder(F.interpolate(img1, size=(fh, fw), mode="bilinear", align_corners=False))
+        f0 = self.encoder(_interp(img0, size=(fh, fw)))
+        f1 = self.encoder(_interp(img1, size=(fh, fw)))
 
         out = self.decoder4(f0[3], f1[3], embt)
         up0, up1, ft = out[:, 0:2], out[:, 2:4], out[:, 4:]
@@ -160,9 +175,9 @@ class IFRNet(nn.Module):
 
         sx, sy = 1.0 / scale_factor[1], 1.0 / scale_factor[0]
         scale = const_tensor((sx, sy), up0.device, up0.dtype).view(1, 2, 1, 1)
-        up0 = F.interpolate(up0, size=(H, W), mode="bilinear", align_corners=False) * scale
-        up1 = F.interpolate(up1, size=(H, W), mode="bilinear", align_corners=False) * scale
-        mask = F.interpolate(mask, size=(H, W), mode="bilinear", align_corners=False)
+        up0 = _interp(up0, size=(H, W)) * scale
+        up1 = _interp(up1, size=(H, W)) * scale
+        mask = _interp(mask, size=(H, W))
         if onlyFlow:
             return up0, up1, mask
         merged = mask * warp(img0, up0) + (1 - mask) * warp(img1, up1)
