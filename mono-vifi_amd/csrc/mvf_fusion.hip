@@ -26,6 +26,10 @@ namespace {
 
 constexpr int NT = 256;
 constexpr int CCH = 8;           // feature channels per lane
+#ifndef MVF_GATHER_CH
+#define MVF_GATHER_CH 16
+#endif
+constexpr int GCH = MVF_GATHER_CH;   // channels per lane of the inverse-list gathers: a cell's list entries are read once per GCH channels
 constexpr int NFREQ = 10;
 constexpr int EMB = 2 * (1 + 2 * NFREQ);   // 42
 // prep planes: 0-1 e_n1, 2-3 e_p1, 4-5 fl_n1, 6-7 fl_p1, 8 mask
@@ -343,6 +347,7 @@ MVF_DEV void gather_list(const float *__restrict__ gb, size_t n, const int2 *__r
     for (int j = 0; j < GE; ++j) e[j] = ent[min(lo + j, last)];
 #pragma unroll
     for (int h0 = 0; h0 < NCH; h0 += 4) {
+        if (h0 >= nc) break;            // (block-uniform: a chunk narrower than NCH, e.g. a 3-channel image)
         float v[GE][4];
 #pragma unroll
         for (int j = 0; j < GE; ++j)
@@ -375,7 +380,7 @@ __global__ void __launch_bounds__(NT) k_fusion_level_bwd_gather(const float *__r
     if (q >= n) return;
     const InvWs W = inv_ws(const_cast<int *>(ws), B, n);
     const int CT = 2 * (C + EMB);
-    const int c0 = blockIdx.y * CCH, nc = min(CCH, C - c0);
+    const int c0 = blockIdx.y * GCH, nc = min(GCH, C - c0);
     const float *gb = g_out + ((size_t)b * CT + C + EMB + c0) * n;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -384,12 +389,12 @@ __global__ void __launch_bounds__(NT) k_fusion_level_bwd_gather(const float *__r
         const size_t sb = (size_t)s * B + b;
         const int *off = W.off + sb * (n + 1);
         const int2 *ent = W.ent + sb * 4 * n;
-        float acc[CCH];
+        float acc[GCH];
 #pragma unroll
-        for (int k = 0; k < CCH; ++k) acc[k] = 0.0f;
-        gather_list<CCH>(gb, (size_t)n, ent, off[q], off[q + 1], nc, acc);
+        for (int k = 0; k < GCH; ++k) acc[k] = 0.0f;
+        gather_list<GCH>(gb, (size_t)n, ent, off[q], off[q + 1], nc, acc);
 #pragma unroll
-        for (int k = 0; k < CCH; ++k)
+        for (int k = 0; k < GCH; ++k)
             if (k < nc) dst[((size_t)b * C + c0 + k) * n + q] = acc[k];
     }
 }
@@ -403,16 +408,16 @@ __global__ void __launch_bounds__(NT) k_flow_warp_bwd_gather(const float *__rest
     const int n = h * w, q = blockIdx.x * NT + threadIdx.x, b = blockIdx.z;
     if (q >= n) return;
     const InvWs W = inv_ws(const_cast<int *>(ws), B, n);
-    const int c0 = blockIdx.y * CCH, nc = min(CCH, C - c0);
+    const int c0 = blockIdx.y * GCH, nc = min(GCH, C - c0);
     const float *gb = g_out + ((size_t)b * C + c0) * n;
     const int *off = W.off + (size_t)b * (n + 1);
     const int2 *ent = W.ent + (size_t)b * 4 * n;
-    float acc[CCH];
+    float acc[GCH];
 #pragma unroll
-    for (int k = 0; k < CCH; ++k) acc[k] = 0.0f;
-    gather_list<CCH>(gb, (size_t)n, ent, off[q], off[q + 1], nc, acc);
+    for (int k = 0; k < GCH; ++k) acc[k] = 0.0f;
+    gather_list<GCH>(gb, (size_t)n, ent, off[q], off[q + 1], nc, acc);
 #pragma unroll
-    for (int k = 0; k < CCH; ++k)
+    for (int k = 0; k < GCH; ++k)
         if (k < nc) g_img[((size_t)b * C + c0 + k) * n + q] = acc[k];
 }
 
@@ -504,7 +509,7 @@ int mvf_fusion_level_bwd_gather(const float *g_out, const float *prep, const flo
     ProfScope ps(MVF_PROF_FUSION_BWD_GATHER, stream, 4LL * B * n * C * (1 + (g_feat_n1 ? 1 : 0) + (g_feat_p1 ? 1 : 0)));
     const int err = build_inverse_lists<false>(prep, xs, ys, workspace, B, h, w, st);
     if (err) return err;
-    const int nchunk = (C + CCH - 1) / CCH;
+    const int nchunk = (C + GCH - 1) / GCH;
     hipLaunchKernelGGL(k_fusion_level_bwd_gather, dim3((unsigned)((n + NT - 1) / NT), (unsigned)nchunk, (unsigned)B),
                        dim3(NT), 0, st, g_out, workspace, g_feat_n1, g_feat_p1, B, C, h, w);
     return hip_check_launch();
@@ -520,7 +525,7 @@ int mvf_flow_warp_bwd_gather(const float *flow, const float *xs, const float *ys
     const int n = H * W;
     const int err = build_inverse_lists<true>(flow, xs, ys, workspace, B, H, W, st);
     if (err) return err;
-    const int nchunk = (C + CCH - 1) / CCH;
+    const int nchunk = (C + GCH - 1) / GCH;
     hipLaunchKernelGGL(k_flow_warp_bwd_gather, dim3((unsigned)((n + NT - 1) / NT), (unsigned)nchunk, (unsigned)B),
                        dim3(NT), 0, st, g_out, workspace, g_img, B, C, H, W);
     return hip_check_launch();
