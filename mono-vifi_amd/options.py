@@ -103,6 +103,9 @@ def build_parser():
                    help="run the mutually independent encoder / decoder / pose / fusion invocations "
                         "of a step as one interleaved batch each, with per-call BatchNorm statistics "
                         "(networks/grouped.py); False = one call at a time like the reference")
+    p.add_argument("--fused_optimizer", type=_str2bool, default=True,
+                   help="AdamW / Adam update as torch's single fused multi-tensor kernel (device only; the whole-step HIP "
+                        "graph keeps the capturable foreach form)")
     p.add_argument("--regroup", type=_str2bool, default=True,
                    help="with --group_calls: the decoder / fusion calls take their interleaved batches of the "
                         "grouped encoder's feature pyramids from one regrouping launch per level (and one adjoint "
