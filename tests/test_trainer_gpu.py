@@ -134,6 +134,20 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     assert (t2.ep_start, t2.batch_start, t2.step) == (0, 3, 7)
     for a, b in zip(t.parameters_to_train, t2.parameters_to_train):
         assert torch.equal(a.detach().cpu(), b.detach().cpu())
+    # the resumed optimiser steps, whichever implementation wrote the state (fused multi-tensor kernel: step counters
+    # on the device; the reference's foreach form: on the host) and whichever one reads it
+    t2.set_train()
+    assert np.isfinite(float(t2.optimisation_step(device_batch(2, 64, 96, t2.device))["loss"]))
+    t3 = make_trainer(tmp_path, resume=True, fused_optimizer=False)
+    assert all(g.get("fused") in (None, False) for g in t3.model_optimizer.param_groups)
+    t3.set_train()
+    assert np.isfinite(float(t3.optimisation_step(device_batch(2, 64, 96, t3.device))["loss"]))
+    t3.step = 8
+    t3.save_model(batch_idx=4)
+    t4 = make_trainer(tmp_path, resume=True)
+    assert all(g.get("fused") for g in t4.model_optimizer.param_groups)
+    t4.set_train()
+    assert np.isfinite(float(t4.optimisation_step(device_batch(2, 64, 96, t4.device))["loss"]))
 
 
 def test_run_epoch_through_dataloader(tmp_path):
