@@ -109,6 +109,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-batch-units", dest="no_batch_units", action="store_true",
                     help="one launch per unit (round-2 launch structure) instead of one per group of three")
+    ap.add_argument("--no-merge-unit-groups", dest="no_merge_unit_groups", action="store_true",
+                    help="hot path / training step: single-frame and affine units as two launches of three (round 4) "
+                         "instead of one launch of six")
     ap.add_argument("--no-share-identity", dest="no_share_identity", action="store_true",
                     help="multi-frame units re-evaluate the identity candidates instead of taking the maps "
                          "of the single-frame unit of the same target")
@@ -317,6 +320,7 @@ class HotPathStep:
         self.l = L()
         self.share = not getattr(args, "no_share_identity", False)
         self.batched = not getattr(args, "no_batch_units", False)
+        self.merged = self.batched and not getattr(args, "no_merge_unit_groups", False)
         self.l.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False,
                                      avg_reprojection=False, disable_automasking=False,
                                      disparity_smoothness=1e-3, inkernel_noise=args.noise == "kernel",
@@ -351,17 +355,22 @@ class HotPathStep:
         for u in self.units:
             u["disp"].grad = None
             u["T"].grad = None
-        total, idents = None, None
-        for g in range(3):
-            us = self.units[3 * g:3 * g + 3]
-            entries = [dict(disp_tgt={("disp", 0): u["disp"]}, img_tgt=u["tgt"], poses=u["T"], imgs_src=u["src"],
-                            K=u["K"], inv_K=u["inv_K"], mask_rec=u["mask"],
-                            ident=(idents[i] if (g == 1 and idents is not None) else None))
-                       for i, u in enumerate(us)]
-            group_sum, ids, _ = self.l.compute_units(entries, want_ident=(g == 0 and self.share), want_sum=True)
-            if g == 0:
-                idents = ids
-            total = group_sum if total is None else total + group_sum
+        def entries(us, idents=None):
+            return [dict(disp_tgt={("disp", 0): u["disp"]}, img_tgt=u["tgt"], poses=u["T"], imgs_src=u["src"],
+                         K=u["K"], inv_K=u["inv_K"], mask_rec=u["mask"],
+                         ident=(idents[i] if idents is not None else None)) for i, u in enumerate(us)]
+        sf, mf, af = self.units[0:3], self.units[3:6], self.units[6:9]
+        if self.merged:
+            # the trainer's issue order (Trainer.process_batch): single-frame + affine units as ONE launch of six,
+            # then the multi-frame ones, whose finishing kernel adds the first launch's total
+            total, ids, _ = self.l.compute_units(entries(sf + af), want_ident=[self.share] * 3 + [False] * 3,
+                                                 want_sum=True)
+            idents = ids[:3] if ids is not None else None
+            total, _, _ = self.l.compute_units(entries(mf, idents), want_sum=True, sum_in=total)
+        else:
+            total, idents, _ = self.l.compute_units(entries(sf), want_ident=self.share, want_sum=True)
+            total, _, _ = self.l.compute_units(entries(mf, idents), want_sum=True, sum_in=total)
+            total, _, _ = self.l.compute_units(entries(af), want_sum=True, sum_in=total)
         total.backward()
         return total
 
@@ -600,7 +609,9 @@ def unit_launch_types(args, nat, fb_bytes_px_base, noise_tensor):
             continue
         med_ms = statistics.median(ms for ms, _ in sel)
         px = statistics.median(p for _, p in sel)
-        bpp = FB_BYTES_PER_PX + (NOISE_BYTES_PER_PX if noise_tensor else 0) + (MASK_BYTES_PER_PX if tag == 2 else 0)
+        # (a mixed launch carries the three single-frame and the three affine units: half of its images bring a mask plane)
+        bpp = FB_BYTES_PER_PX + (NOISE_BYTES_PER_PX if noise_tensor else 0) + \
+            (MASK_BYTES_PER_PX if tag == 2 else MASK_BYTES_PER_PX / 2 if tag == 3 else 0)
         ach = bpp * px / (med_ms / 1e3) / 1e9
         out[name] = {"launches": len(sel), "median_us": round(med_ms * 1e3, 2),
                      "min_us": round(min(ms for ms, _ in sel) * 1e3, 2), "max_us": round(max(ms for ms, _ in sel) * 1e3, 2),

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVF_ABI_VERSION 13
+#define MVF_ABI_VERSION 14
 
 #if defined(__GNUC__)
 #define MVF_API __attribute__((visibility("default")))
@@ -44,7 +44,7 @@ extern "C" {
 #define MVF_NO_AUTOMASK 4
 
 #define MVF_MAX_SRC 4
-#define MVF_MAX_UNITS 4 /* hot-path units one mvf_units_fwdbwd launch can carry */
+#define MVF_MAX_UNITS 8 /* hot-path units one mvf_units_fwdbwd launch can carry */
 
 MVF_API int mvf_abi_version(void);
 MVF_API const char *mvf_error_string(int err);
@@ -230,6 +230,9 @@ typedef struct mvf_unit_desc {
                                                          the units of the launch (unit order), written by the last
                                                          finishing block -- the `losses.sum()` of a group of
                                                          process_batch (train.py:760, 812, 882) without a launch */
+    const float *loss_sum_in;                         /* nullable [1]; read from units[0] only: a running total the sum
+                                                         is added to (loss_sum = *loss_sum_in + the units' losses in unit
+                                                         order): `loss_base +=` of train.py:760, 812, 882 without a launch */
 } mvf_unit_desc;
 MVF_API size_t mvf_units_workspace_floats(int n_units, int B, int H, int W);
 MVF_API size_t mvf_units_ticket_ints(int n_units, int B);
@@ -238,7 +241,8 @@ MVF_API int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int
                      int H, int W, void *stream);
 /* backward() of mvf_units_fwdbwd, one launch for the units' grad_disp and grad_T (formula below);
  * upstream gradient of a unit = *g_loss (device scalar, nullable) + *g_sum (device scalar, nullable: the gradient
- * of the launch's loss_sum); at least one of the two. */
+ * of the launch's loss_sum); at least one of the two.  g_disp == NULL: only grad_T of that unit is formed (its
+ * disparity gradient is consumed raw by mvf_disp_head_bwd_units). */
 typedef struct mvf_unit_scale_desc {
     const float *g_disp_raw; int64_t in_stride;
     const float *g_T_raw, *stats, *g_loss;
@@ -432,6 +436,22 @@ MVF_API int mvf_disp_head_fwd(const float *logit, float *disp, float *depth, flo
 /* g_logit = (g_disp - g_depth*range*depth^2) * disp*(1-disp); g_disp / g_depth nullable */
 MVF_API int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_depth, float *g_logit,
                       int64_t n, float min_disp, float range, void *stream);
+/* The same adjoint fed by the hot-path units directly (reference: the autograd edge between compute_losses_base,
+ * train.py:987-1051, and the decoder's sigmoid, networks/monodepth2.py:93): a unit's disparity gradient is taken RAW,
+ * as mvf_units_fwdbwd left it in g_disp_raw, and g_disp = (raw - shift_b) * (*g_loss + *g_sum) -- the formula of
+ * mvf_units_fwdbwd_scale below, same operations, same bits -- is applied on load; the unit's B images are images
+ * first, first + step, ... of the head's batch [B_head, N] (the interleaved batch of a grouped decoder call).
+ * g_disp (nullable): gradient of disp from any other consumer, added first.  n_units <= MVF_MAX_UNITS. */
+typedef struct mvf_head_unit_grad {
+    const float *g_disp_raw; int64_t raw_stride;      /* [count, N]; stride in floats, 0 = N */
+    const float *stats;                               /* [count, 4] of the unit (mvf_units_fwdbwd) */
+    const float *g_loss, *g_sum;                      /* device scalars, at least one */
+    float smoothness;
+    int32_t first, step, count;
+} mvf_head_unit_grad;
+MVF_API int mvf_disp_head_bwd_units(const float *disp, const float *g_disp, const float *g_depth, float *g_logit,
+                            int B, int N, float min_disp, float range, const mvf_head_unit_grad *units,
+                            int n_units, void *stream);
 /* Convolution epilogue: out = act(x + bias[c] (+ res)) in one pass over [N,C,HW] (x may alias out).
  * Replaces the bias add_ + activation (+ residual add) that follow every biased convolution:
  * decoder ConvBlock (layers.py:106-118: ELU), IFRNet convrelu / ResBlock (networks/IFRNet.py:128-157:
@@ -543,6 +563,7 @@ MVF_API int mvf_color_jitter(const float *img, const float *factors, const int32
 #define MVF_TAG_SINGLE_FRAME 0  /* identity candidates evaluated (and possibly handed over: ident_out) */
 #define MVF_TAG_MULTI_FRAME 1   /* identity maps taken from another unit (ident_in) */
 #define MVF_TAG_AFFINE 2        /* mask_rec supplied */
+#define MVF_TAG_MIXED 3         /* units with and without mask_rec in one launch (single-frame + affine groups) */
 MVF_API int mvf_profile_enable(int level);
 MVF_API int mvf_profile_reset(void);
 MVF_API int mvf_profile_read(int kernel_id, double *total_ms, int64_t *launches);

@@ -12,11 +12,11 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # MVF_HOTPATH_LIB: developer knob (kernel variant builds); the product loads the in-tree library
 LIB_PATH = os.environ.get("MVF_HOTPATH_LIB") or os.path.join(_HERE, "lib", "libmvf_hotpath.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = 1, 2, 4
 MAX_SRC = 4
-MAX_UNITS = 4
+MAX_UNITS = 8
 
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 
@@ -35,7 +35,7 @@ class UnitDesc(C.Structure):
         ("ident_out", _vp), ("loss", _vp), ("stats", _vp),
         ("g_disp_raw", _vp), ("g_stride", _i64),
         ("g_T_raw", _vp), ("argmin", _vp), ("auto_mask", _vp), ("to_opt", _vp), ("idx_xy", _vp),
-        ("noise_out", _vp), ("loss_sum", _vp),
+        ("noise_out", _vp), ("loss_sum", _vp), ("loss_sum_in", _vp),
     ]
 
 
@@ -46,6 +46,15 @@ class UnitScaleDesc(C.Structure):
         ("g_T_raw", _vp), ("stats", _vp), ("g_loss", _vp),
         ("g_disp", _vp), ("out_stride", _i64),
         ("g_T", _vp), ("g_sum", _vp),
+    ]
+
+
+class HeadUnitGrad(C.Structure):
+    """mvf_head_unit_grad: one hot-path unit whose raw disparity gradient mvf_disp_head_bwd_units reads in place."""
+    _fields_ = [
+        ("g_disp_raw", _vp), ("raw_stride", _i64),
+        ("stats", _vp), ("g_loss", _vp), ("g_sum", _vp),
+        ("smoothness", _f), ("first", C.c_int32), ("step", C.c_int32), ("count", C.c_int32),
     ]
 
 
@@ -89,6 +98,7 @@ _SIGNATURES = {
     "mvf_up2cat_pad_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_disp_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp],
     "mvf_disp_head_bwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _vp],
+    "mvf_disp_head_bwd_units": [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _i, _vp],
     "mvf_bias_act_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_bias_act_workspace_floats": [_i, _i, _i],
     "mvf_bias_act_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -143,7 +153,7 @@ _SIGNATURES = {
 (PROF_UNIT_FWD, PROF_UNIT_BWD, PROF_PHOTO_FWD, PROF_PHOTO_BWD, PROF_WARP_FWD, PROF_WARP_BWD,
  PROF_UNIT_FWDBWD) = range(7)
 PROF_FIRST_GLUE, PROF_COUNT = 7, 36         # ids >= 7: glue kernels, profile level 2, work = algorithmic bytes
-TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine"}
+TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine", 3: "single_frame+affine"}
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_profile_name": C.c_char_p, "mvf_profile_read_launches": C.c_int64, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,
             "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t,

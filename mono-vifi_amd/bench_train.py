@@ -31,6 +31,7 @@ class TrainStep:
             hip_graph_scope=getattr(args, "hip_graph_scope", "step"),
             batch_units=not getattr(args, "no_batch_units", False),
             share_identity=not getattr(args, "no_share_identity", False),
+            merge_unit_groups=not getattr(args, "no_merge_unit_groups", False),
             regroup=not getattr(args, "no_regroup", False),
             grad_exchange=getattr(args, "grad_exchange", "all_reduce"),
             no_overlap=bool(getattr(args, "no_overlap", False)),
@@ -47,7 +48,7 @@ class TrainStep:
         return (f"full optimisation step, {o.backbone} {o.width}x{o.height} 3-frame, batch "
                 f"{o.batch_size}/GPU, use_affine, {o.fuse_model_type}, IFRNet-L teacher, 9 fused "
                 f"hot-path units (forward+backward tile kernel, "
-                f"{'3 launches of 3 units' if o.batch_units else '9 launches'}), "
+                f"{('2 launches of 6 + 3 units' if o.merge_unit_groups else '3 launches of 3 units') if o.batch_units else '9 launches'}), "
                 f"{'grouped' if o.group_calls else 'one-at-a-time'} network calls with per-call "
                 f"BatchNorm statistics, AdamW, random-init weights, device-resident synthetic batch "
                 f"(data loading excluded), nets {'bf16 autocast' if o.amp_bf16 else 'fp32'}"

@@ -323,6 +323,80 @@ __global__ void __launch_bounds__(NT) k_disp_head_bwd(const float *__restrict__ 
     }
 }
 
+// The same adjoint with the hot-path units' disparity gradients taken RAW, as the unit kernel left them (upstream
+// gradient 1, without the per-image shift of the mean-normalised smoothness term): (raw - shift_b) * g is applied on
+// load -- the pass k_fb_scale makes over every unit's gradient for a consumer that needs a tensor -- and the units' images
+// are read where the unit launch wrote them: no scaled copy, no re-interleaving `stack` of the group gradients.
+// grid (chunks, images of the head's batch); a unit covers the images first, first + step, ... (count of them).
+struct HeadUnit {
+    const float *g_raw, *stats, *g_loss, *g_sum;
+    size_t raw_stride;
+    float smoothness;
+    int first, step, count;
+};
+struct HeadUnits {
+    HeadUnit u[MVF_MAX_UNITS];
+    int n;
+};
+__global__ void __launch_bounds__(NT) k_disp_head_bwd_units(const float *__restrict__ disp,
+                                                            const float *__restrict__ g_disp,
+                                                            const float *__restrict__ g_depth,
+                                                            float *__restrict__ g_logit, int N, int vec, float min_disp,
+                                                            float range, HeadUnits hu)
+{
+    const int img = blockIdx.y;
+    const size_t base = (size_t)img * N;
+    // the (at most a few) units that cover this image: block-uniform
+    const float *raw[MVF_MAX_UNITS];
+    float shift[MVF_MAX_UNITS], gs[MVF_MAX_UNITS];
+    int m = 0;
+    for (int e = 0; e < hu.n; ++e) {
+        const HeadUnit &u = hu.u[e];
+        const int rel = img - u.first;
+        if (rel < 0 || rel % u.step != 0 || rel / u.step >= u.count) continue;
+        const int b = rel / u.step;
+        // shift_b and g exactly as k_fb_scale forms them (mvf_unit_fb.hip)
+        const float den = u.stats[b * 4 + 1];
+        const float smooth_b = u.stats[b * 4 + 2] + u.stats[b * 4 + 3];
+        shift[m] = (u.smoothness * smooth_b / (float)N) / den;
+        gs[m] = (u.g_loss ? u.g_loss[0] : 0.0f) + (u.g_sum ? u.g_sum[0] : 0.0f);
+        raw[m] = u.g_raw + (size_t)b * u.raw_stride;
+        ++m;
+    }
+    auto one = [&](float d, float g, float gdep) {
+        if (g_depth) {
+            const float dep = 1.0f / (min_disp + range * d);
+            g -= gdep * range * dep * dep;
+        }
+        return g * d * (1.0f - d);
+    };
+    if (vec) {
+        const int i = blockIdx.x * NT + threadIdx.x;
+        if (i >= N / 4) return;
+        const float4 d = reinterpret_cast<const float4 *>(disp + base)[i];
+        float4 g = g_disp ? reinterpret_cast<const float4 *>(g_disp + base)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < m; ++k) {
+            const float4 r = reinterpret_cast<const float4 *>(raw[k])[i];
+            const float4 t = make_float4((r.x - shift[k]) * gs[k], (r.y - shift[k]) * gs[k], (r.z - shift[k]) * gs[k],
+                                         (r.w - shift[k]) * gs[k]);
+            if (k == 0 && !g_disp) g = t;          // (0 + t would turn a -0 into +0: keep the bits of the two-kernel path)
+            else { g.x += t.x; g.y += t.y; g.z += t.z; g.w += t.w; }
+        }
+        const float4 gd = g_depth ? reinterpret_cast<const float4 *>(g_depth + base)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float4 *>(g_logit + base)[i] =
+            make_float4(one(d.x, g.x, gd.x), one(d.y, g.y, gd.y), one(d.z, g.z, gd.z), one(d.w, g.w, gd.w));
+    } else {
+        for (int i = blockIdx.x * NT + threadIdx.x; i < N; i += gridDim.x * NT) {
+            float g = g_disp ? g_disp[base + i] : 0.0f;
+            for (int k = 0; k < m; ++k) {
+                const float t = (raw[k][i] - shift[k]) * gs[k];
+                g = (k == 0 && !g_disp) ? t : g + t;
+            }
+            g_logit[base + i] = one(disp[base + i], g, g_depth ? g_depth[base + i] : 0.0f);
+        }
+    }
+}
+
 // ---- convolution epilogue: bias + activation (+ residual) --------------------------------------
 // Every biased convolution of the step is `conv -> + bias[c] -> activation` (decoder ConvBlock:
 // layers.py:106-118 ELU; IFRNet convrelu / ResBlock: networks/IFRNet.py:128-157 PReLU, with the
@@ -1551,6 +1625,39 @@ int mvf_disp_head_bwd(const float *disp, const float *g_disp, const float *g_dep
     ProfScope ps(MVF_PROF_DISP_HEAD_BWD, stream, 4LL * n * (2 + (g_disp ? 1 : 0) + (g_depth ? 1 : 0)));
     hipLaunchKernelGGL(k_disp_head_bwd, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, disp, g_disp,
                        g_depth, g_logit, n, min_disp, range);
+    return hip_check_launch();
+}
+
+int mvf_disp_head_bwd_units(const float *disp, const float *g_disp, const float *g_depth, float *g_logit, int B,
+                            int N, float min_disp, float range, const mvf_head_unit_grad *units, int n_units,
+                            void *stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    if (!disp || !g_logit || B > 65535 || n_units < 0 || n_units > MVF_MAX_UNITS || (n_units && !units))
+        return (int)hipErrorInvalidValue;
+    HeadUnits hu = {};
+    hu.n = n_units;
+    bool vec = (N % 4 == 0) && ((((uintptr_t)disp | (uintptr_t)g_disp | (uintptr_t)g_depth | (uintptr_t)g_logit) & 15) == 0);
+    int64_t imgs = 0;
+    for (int i = 0; i < n_units; ++i) {
+        const mvf_head_unit_grad &d = units[i];
+        if (!d.g_disp_raw || !d.stats || (!d.g_loss && !d.g_sum) || d.first < 0 || d.step < 1 || d.count < 1 ||
+            d.first + (int64_t)(d.count - 1) * d.step >= B)
+            return (int)hipErrorInvalidValue;
+        HeadUnit &u = hu.u[i];
+        u.g_raw = d.g_disp_raw; u.stats = d.stats; u.g_loss = d.g_loss; u.g_sum = d.g_sum;
+        u.raw_stride = d.raw_stride ? (size_t)d.raw_stride : (size_t)N;
+        u.smoothness = d.smoothness; u.first = d.first; u.step = d.step; u.count = d.count;
+        vec = vec && ((((uintptr_t)d.g_disp_raw) & 15) == 0) && (u.raw_stride % 4 == 0);
+        imgs += d.count;
+    }
+    const int per = vec ? N / 4 : N;
+    int64_t gx = (per + NT - 1) / NT;
+    if (!vec && gx > 64) gx = 64;
+    // disp read, g_logit written, the optional planes, one raw gradient per covered image
+    ProfScope ps(MVF_PROF_DISP_HEAD_BWD, stream, 4LL * N * ((int64_t)B * (2 + (g_disp ? 1 : 0) + (g_depth ? 1 : 0)) + imgs));
+    hipLaunchKernelGGL(k_disp_head_bwd_units, dim3((unsigned)gx, (unsigned)B), dim3(NT), 0, (hipStream_t)stream, disp,
+                       g_disp, g_depth, g_logit, N, vec ? 1 : 0, min_disp, range, hu);
     return hip_check_launch();
 }
 

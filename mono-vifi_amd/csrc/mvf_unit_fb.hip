@@ -86,10 +86,26 @@ struct FbArgs {
     double *img_ws;       // [U][B][NIMG] per-image folded loss terms
     int *tickets;         // [U + 1] one per unit + one per launch (k_units_finish); zero on entry, zero on exit
     float *loss_sum;      // nullable: sum of the units' loss[0]
+    const float *loss_sum_in;   // nullable: running total the sum starts from
+    float *tab;           // [U][B] ImgTab: what a workgroup needs of its image besides the planes (k_units_prepare)
     int nunits, flags, B, H, W, tiles_x, tiles_y;
     int flags_int;        // bit 0: every image base / stride of the launch is 8-byte aligned (pair staging allowed)
+    uint32_t mg_tx, mg_ty;   // floor(2^32 / tiles_x) + 1, floor(2^32 / tiles_y) + 1 (0: divide): workgroup -> tile
     float smoothness, min_disp, range, eps;
+    float gpix, cxs, cys; // launch constants of the adjoint: 1 / (B N), smoothness / (B H (W-1)), smoothness / (B (H-1) W)
 };
+
+// Per-image constants of a launch, written ONCE per (unit, image) by k_units_prepare in front of the unit kernel:
+// rounds 2-4 had every one of the image's 308 workgroups rebuild them -- lane 0 folding the 32 mean partials
+// serially and dividing twice, 24 lanes re-multiplying K @ T -- behind a chain of five dependent memory round
+// trips (kernel arguments -> unit descriptor -> partials pointer -> partials -> ...) in front of its first barrier.
+struct ImgTab {
+    float P[2][12];       // (K @ T)[:3] per source (the second source's copy of the first when S == 1)
+    float mean, den, rden;   // mean disparity, mean + 1e-7, 1 / den
+    float pad[5];
+};
+static_assert(sizeof(ImgTab) == 128, "one 128-byte line per image");
+constexpr int TABF = sizeof(ImgTab) / sizeof(float);
 
 // LDS carve (floats): target 3 planes | pair 3 f2 planes | disparity | coefficient 3 f2 region
 // planes (A,B,G) | pose | scratch
@@ -99,7 +115,30 @@ static_assert((NT / 16) * NRED <= 6 * RPLANE, "the final reduction parks its row
 #ifndef MVF_FB_EXTRA_LDS
 #define MVF_FB_EXTRA_LDS 0     // occupancy experiments: pad the workgroup's LDS
 #endif
-inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(PoseLds) + MVF_FB_EXTRA_LDS; }
+inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(ImgTab) + MVF_FB_EXTRA_LDS; }
+MVF_DEV void load_pose_pair(const ImgTab &sh, int ka, int kb, f2 P2[12])
+{
+#pragma unroll
+    for (int i = 0; i < 12; ++i) P2[i] = mk2(sh.P[ka][i], sh.P[kb][i]);
+}
+// workgroup -> tile with the launcher's reciprocals (exact for n * d < 2^32, which the launcher checks; three
+// 32-bit integer divisions on the scalar unit -- a v_rcp round trip through a vector register each -- were the first
+// thing every wave of the launch did)
+MVF_DEV int div_magic(int n, int d, uint32_t mg) { return mg ? (int)__umulhi((uint32_t)n, mg) : n / d; }
+MVF_DEV TileId tile_of_block_mg(int tiles_x, int tiles_y, int B, uint32_t mg_tx, uint32_t mg_ty)
+{
+    const int total = tiles_x * tiles_y * B;
+    const int lin = blockIdx.x;
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int q = total >> 3, r = total & 7;
+    const int vid = xcd * q + min(xcd, r) + slot;
+    TileId t;
+    const int rest = div_magic(vid, tiles_x, mg_tx);
+    t.bx = vid - rest * tiles_x;
+    t.b = div_magic(rest, tiles_y, mg_ty);
+    t.by = rest - t.b * tiles_y;
+    return t;
+}
 
 // ---- counter-based tie-break noise ------------------------------------------------------
 // train.py:1023-1024 draws torch.randn(identity_reprojection_loss.shape) * 1e-5 per call.  With
@@ -533,11 +572,13 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     f2 *pairP = reinterpret_cast<f2 *>(smem + FB_PAIR);
     float *dispP = smem + FB_DISP;
     f2 *coefP = reinterpret_cast<f2 *>(smem + FB_COEF);
-    PoseLds &sh = *reinterpret_cast<PoseLds *>(smem + FB_POSE);
+    ImgTab &sh = *reinterpret_cast<ImgTab *>(smem + FB_POSE);
+#if !MVF_FB_LDS_REDUCE
     float *scratch = smem + FB_COEF;       // the coefficient planes are free when the final reduction runs
+#endif
 
     // workgroup -> (unit, image, tile): the images of all units form one batch of nunits * B
-    const TileId tid = tile_of_block(a.tiles_x, a.tiles_y, a.B * a.nunits);
+    const TileId tid = tile_of_block_mg(a.tiles_x, a.tiles_y, a.B * a.nunits, a.mg_tx, a.mg_ty);
     const int H = a.H, W = a.W;
     const int unit = __builtin_amdgcn_readfirstlane(tid.b / a.B);
     const int b = __builtin_amdgcn_readfirstlane(tid.b - unit * a.B);
@@ -569,17 +610,9 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     const bool ident_given = automask && (u.ident_in != nullptr);
 #endif
 
-    if (threadIdx.x == 0) {
-        float m = 0.0f;
-        for (int i = 0; i < NMEAN; ++i) m += u.mean_ws[b * NMEAN + i];
-        sh.den = m / (float)N + 1e-7f;
-        sh.rden = 1.0f / sh.den;          // reciprocal of the mean-normalisation constant (phase 8), once per workgroup
-        sh.gpix = 1.0f / (float)((double)a.B * (double)N);
-    }
-    if (threadIdx.x < 12 * S) {
-        int k = threadIdx.x / 12, e = threadIdx.x - k * 12;
-        sh.P[k][e] = proj_entry(u.K + b * 16, u.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
-    }
+    // the image's constants: one 128-byte line of the table k_units_prepare wrote, in flight with the staging loads
+    if (threadIdx.x < TABF)
+        reinterpret_cast<float *>(&sh)[threadIdx.x] = a.tab[(size_t)ub * TABF + threadIdx.x];
     const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
     const int off = row * LDW + seg * PX;     // plane element of the window's top-left
     const int roff = off;                     // region-plane element of this lane's first pixel
@@ -774,7 +807,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         asm volatile("" :: "v"(vw[j]), "v"(vid[j]), "v"(nz[j]));
-        wk[j] = f2s(sh.gpix * mraw[j]);
+        wk[j] = f2s(a.gpix * mraw[j]);
     }
     if (false)
 #endif
@@ -831,7 +864,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         if (sel == 255) wa = wb = avg ? 1.0f / (float)S : 1.0f;        // single candidate
         else if (avg) wa = wb = (sel == n_id) ? 1.0f / (float)S : 0.0f;
         else { wa = (sel == n_id) ? 1.0f : 0.0f; wb = (sel == n_id + 1) ? 1.0f : 0.0f; }
-        const float wbase = sh.gpix * mraw[j];                         // 0 outside the image
+        const float wbase = a.gpix * mraw[j];                          // 0 outside the image
         wk[j] = mk2(wbase * wa, hasb ? wbase * wb : 0.0f);
     }
 
@@ -975,8 +1008,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     }
     float fb_sx = 0.0f, fb_sy = 0.0f;
     const float rden = sh.rden;
-    const float cxs = a.smoothness / (float)((double)a.B * H * (W - 1));
-    const float cys = a.smoothness / (float)((double)a.B * (H - 1) * W);
+    const float cxs = a.cxs, cys = a.cys;
 #ifndef MVF_FB_UNROLL7
 #define MVF_FB_UNROLL7 2
 #endif
@@ -1195,6 +1227,76 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     }
 }
 
+// ---- message passing between the blocks of the small kernels around the unit kernel -----------------------------
+// A block publishes a few values and takes a ticket; the block that draws the last ticket reads everybody's values.
+// __threadfence() on this chip is `buffer_wbl2 sc1` + wait: a write-back of the XCD's whole L2 (4 MiB, full of the unit
+// kernel's gradient planes) per call -- measured: 60 us for the 2,304 blocks of one preparing launch.  Instead every
+// published value is an agent-scope atomic store (sc1: written through to the device-coherent level), the ticket is
+// taken after `s_waitcnt vmcnt(0)` (the stores have completed), and the reader uses agent-scope atomic loads (sc1:
+// not served from a stale L2 line): the same ordering for exactly the values involved, no cache maintenance.
+template <typename Tv>
+MVF_DEV void publish(Tv *p, Tv v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename Tv>
+MVF_DEV Tv fetch_published(const Tv *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+MVF_DEV int take_ticket(int *tk)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // everything published before is complete
+    return __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- preparing kernel: ONE small launch in front of the unit kernel, blocks (chunk, image, unit).
+// For a unit whose disparity head supplied no mean partials (`mean_mask` bit set) the NMEAN blocks of an image first
+// sum their chunk of the disparity (k_disp_mean's partition and order) and the LAST of them to arrive (device-scope
+// ticket) writes the image's table line; for the others only block 0 of an image runs, straight to the table.
+// Table line: lanes 0 .. 23 form (K @ T)[:3] (proj_entry: ATen's small-matrix order, golden key "P*"); lane 32 folds
+// the NMEAN partials in index order -- whoever arrives last: the result does not depend on the arrival order -- and
+// divides (the compiler's correctly rounded IEEE divides, as the unit kernel's lane 0 did before round 5).
+__global__ void __launch_bounds__(256) k_units_prepare(FbArgs a, int S, unsigned mean_mask, int *tk)
+{
+    __shared__ float scratch[4];
+    __shared__ int s_last;
+    const int chunk = blockIdx.x, b = blockIdx.y, unit = blockIdx.z;
+    const UnitArgs &u = a.u[unit];
+    const int N = a.H * a.W;
+    const int t = threadIdx.x;
+    if ((mean_mask >> unit) & 1u) {
+        const int per = (N + NMEAN - 1) / NMEAN;
+        const int lo = chunk * per, hi = min(lo + per, N);
+        const float *d = u.disp + (size_t)b * u.disp_stride;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        int i = lo + t;
+        for (; i + 3 * 256 < hi; i += 4 * 256) {
+            s0 += d[i];
+            s1 += d[i + 256];
+            s2 += d[i + 512];
+            s3 += d[i + 768];
+        }
+        for (; i < hi; i += 256) s0 += d[i];
+        const float r = block_sum<256>((s0 + s1) + (s2 + s3), scratch);
+        if (t == 0) {
+            publish(const_cast<float *>(u.mean_ws) + b * NMEAN + chunk, r);
+            s_last = (take_ticket(tk + unit * a.B + b) == NMEAN - 1);
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (t == 0) publish(tk + unit * a.B + b, 0);    // leave the counter as it was found
+    } else if (chunk != 0) return;
+    ImgTab &tb = reinterpret_cast<ImgTab *>(a.tab)[(size_t)unit * a.B + b];
+    if (t < 24) {
+        const int k = (t < 12 || S < 2) ? 0 : 1, e = t < 12 ? t : t - 12;
+        tb.P[t < 12 ? 0 : 1][e] = proj_entry(u.K + b * 16, u.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
+    } else if (t == 32) {
+        float m = 0.0f;
+        for (int i = 0; i < NMEAN; ++i)
+            m += fetch_published(u.mean_ws + b * NMEAN + i);
+        const float mean = m / (float)((size_t)a.H * a.W);
+        const float den = mean + 1e-7f;
+        tb.mean = mean;
+        tb.den = den;
+        tb.rden = 1.0f / den;             // reciprocal of the mean-normalisation constant (phase 8)
+    }
+}
+
 // ---- finishing kernel: ONE launch for all units of a unit launch ------------------------------
 // block (unit, image): folds the image's tile partials (27 values x ntiles; tiles strided over 32
 // slices in fp64, then the slices in order) into grad_T of both sources (= K^T [grad_P ; 0]),
@@ -1259,44 +1361,37 @@ __global__ void __launch_bounds__(32 * FIN_SLICES) k_units_finish(FbArgs a, int 
     }
     if (threadIdx.x == 0) {
         const double sxb = red[25] / ((double)a.B * H * (W - 1)), syb = red[26] / ((double)a.B * (H - 1) * W);
-        float m = 0.0f;
-        for (int i = 0; i < NMEAN; ++i) m += u.mean_ws[b * NMEAN + i];
-        const float mean = m / (float)N;
-        u.stats[b * 4 + 0] = mean;
-        u.stats[b * 4 + 1] = mean + 1e-7f;
+        const ImgTab &tb = reinterpret_cast<const ImgTab *>(a.tab)[ub];
+        u.stats[b * 4 + 0] = tb.mean;
+        u.stats[b * 4 + 1] = tb.den;
         u.stats[b * 4 + 2] = (float)sxb;
         u.stats[b * 4 + 3] = (float)syb;
         double *iw = a.img_ws + (size_t)ub * NIMG;
-        iw[0] = red[24];
-        iw[1] = sxb + syb;
-        __threadfence();                       // the image's terms are visible before its ticket
-        s_last = (atomicAdd(a.tickets + unit, 1) == a.B - 1);
+        publish(iw, red[24]);
+        publish(iw + 1, sxb + syb);
+        s_last = (take_ticket(a.tickets + unit) == a.B - 1);       // the image's terms are complete before its ticket
         if (s_last) {
-            __threadfence();
             double photo = 0.0, smooth = 0.0;
             for (int i = 0; i < a.B; ++i) {
                 const double *jw = a.img_ws + ((size_t)unit * a.B + i) * NIMG;
-                photo += __builtin_nontemporal_load(jw);
-                smooth += __builtin_nontemporal_load(jw + 1);
+                photo += fetch_published(jw);
+                smooth += fetch_published(jw + 1);
             }
             const double pmn = photo / ((double)a.B * (double)N);
             const float l0 = (float)(pmn + (double)a.smoothness * smooth);
             u.loss[0] = l0;
             u.loss[1] = (float)pmn;
             u.loss[2] = (float)smooth;
-            a.tickets[unit] = 0;               // leave the counter as it was found
+            publish(a.tickets + unit, 0);      // leave the counter as it was found
             if (a.loss_sum) {
                 // the launch's last unit to finish adds the units' losses in UNIT order (whoever it is: the
                 // result does not depend on the arrival order); each finisher publishes its loss[0] first
-                __hip_atomic_store(u.loss, l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
-                if (atomicAdd(a.tickets + a.nunits, 1) == a.nunits - 1) {
-                    __threadfence();
-                    float tot = 0.0f;
-                    for (int i = 0; i < a.nunits; ++i)
-                        tot += __hip_atomic_load(a.u[i].loss, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                publish(u.loss, l0);
+                if (take_ticket(a.tickets + a.nunits) == a.nunits - 1) {
+                    float tot = a.loss_sum_in ? a.loss_sum_in[0] : 0.0f;
+                    for (int i = 0; i < a.nunits; ++i) tot += fetch_published(a.u[i].loss);
                     a.loss_sum[0] = tot;
-                    a.tickets[a.nunits] = 0;
+                    publish(a.tickets + a.nunits, 0);
                 }
             }
         }
@@ -1325,6 +1420,7 @@ __global__ void __launch_bounds__(256) k_fb_scale(ScaleArgs a)
         if (i < a.nT) u.gT[i] = u.gT_raw[i] * g;
         return;
     }
+    if (!u.g_disp) return;                        // the unit's disparity gradient is taken raw by its consumer
     const int b = blockIdx.y;
     const int N = a.N, N4 = a.N4;
     const float den = u.stats[b * 4 + 1];
@@ -1345,22 +1441,10 @@ __global__ void __launch_bounds__(256) k_fb_scale(ScaleArgs a)
 
 }  // namespace
 
-// per-image mean partials of the disparity (mvf_photo.hip)
-namespace mvf_photo {
-struct DispMeanJobs {
-    const float *disp[MVF_MAX_UNITS];
-    size_t stride[MVF_MAX_UNITS];
-    float *ws[MVF_MAX_UNITS];
-    int n;
-};
-void launch_disp_mean(const float *disp, size_t image_stride, float *ws, int B, int N, hipStream_t st);
-void launch_disp_mean_many(const DispMeanJobs &jobs, int B, int N, hipStream_t st);
-}
-
 namespace {
 // floats of workspace: mean partials | loss partials | grad_P partials | per-image folds (doubles)
 struct WsLayout {
-    size_t mean, part, gp, img, total;
+    size_t mean, part, gp, img, tab, total;
 };
 WsLayout ws_layout(int U, int B, int H, int W)
 {
@@ -1371,7 +1455,9 @@ WsLayout ws_layout(int U, int B, int H, int W)
     l.gp = l.part + (size_t)U * B * tiles * NPART;
     l.img = l.gp + (size_t)2 * U * B * tiles * 12;
     l.img = (l.img + 1) & ~(size_t)1;                   // doubles: 8-byte aligned
-    l.total = l.img + (size_t)U * B * NIMG * 2;
+    l.tab = l.img + (size_t)U * B * NIMG * 2;
+    l.tab = (l.tab + 31) & ~(size_t)31;                 // the per-image table: 128-byte lines (workspace itself: see the launcher)
+    l.total = l.tab + (size_t)U * B * TABF;
     return l;
 }
 }  // namespace
@@ -1383,7 +1469,9 @@ size_t mvf_units_workspace_floats(int n_units, int B, int H, int W)
     return ws_layout(n_units, B, H, W).total + 2;
 }
 
-size_t mvf_units_ticket_ints(int n_units, int B) { (void)B; return (size_t)n_units + 1; }
+
+// one per unit + one per launch (finishing kernel), then one per (unit, image) (preparing kernel)
+size_t mvf_units_ticket_ints(int n_units, int B) { return (size_t)n_units + 1 + (size_t)n_units * (B > 0 ? B : 0); }
 
 int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, float smoothness,
                      float min_disp, float range, float eps, float *workspace, int32_t *tickets, int B,
@@ -1408,10 +1496,22 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
     a.part = workspace + l.part;
     a.gp_ws = workspace + l.gp;
     a.img_ws = reinterpret_cast<double *>(workspace + l.img);
+    a.tab = workspace + l.tab;
     a.tickets = tickets;
+    {
+        // launch constants the adjoint used to derive per lane (two double multiplies and an IEEE divide each): the
+        // same expressions, evaluated here once -- host float / double arithmetic is IEEE, the bits are the same
+        a.gpix = 1.0f / (float)((double)B * (double)N);
+        a.cxs = smoothness / (float)((double)B * H * (W - 1));
+        a.cys = smoothness / (float)((double)B * (H - 1) * W);
+        const uint64_t nmax = (uint64_t)ntiles * B * n_units;          // largest dividend of the tile decode
+        a.mg_tx = (nmax * (uint64_t)a.tiles_x < (1ull << 32) && a.tiles_x > 1) ? (uint32_t)((1ull << 32) / a.tiles_x) + 1u : 0u;
+        a.mg_ty = (nmax * (uint64_t)a.tiles_y < (1ull << 32) && a.tiles_y > 1) ? (uint32_t)((1ull << 32) / a.tiles_y) + 1u : 0u;
+    }
     a.loss_sum = units[0].loss_sum;
-    // units without disparity-mean partials of their own: ONE launch computes them for all of them
-    mvf_photo::DispMeanJobs mean_jobs = {};
+    a.loss_sum_in = units[0].loss_sum ? units[0].loss_sum_in : nullptr;
+    // units without disparity-mean partials of their own: the preparing launch computes them
+    unsigned mean_mask = 0;
     bool pair_ok = (W % 2) == 0;
     for (int i = 0; i < n_units; ++i) {
         const mvf_unit_desc &d = units[i];
@@ -1436,21 +1536,27 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
         u.seed0 = (uint32_t)d.noise_seed; u.seed1 = (uint32_t)(d.noise_seed >> 32);
         if (d.disp_mean_partials) u.mean_ws = d.disp_mean_partials;
         else {
-            float *mw = workspace + l.mean + (size_t)i * B * NMEAN;
-            u.mean_ws = mw;
-            mean_jobs.disp[mean_jobs.n] = d.disp; mean_jobs.stride[mean_jobs.n] = u.disp_stride; mean_jobs.ws[mean_jobs.n] = mw;
-            ++mean_jobs.n;
+            u.mean_ws = workspace + l.mean + (size_t)i * B * NMEAN;
+            mean_mask |= 1u << i;
         }
     }
-    if (mean_jobs.n) mvf_photo::launch_disp_mean_many(mean_jobs, B, N, st);
     a.flags_int = pair_ok ? 1 : 0;
     {
+        // (the disparity planes are read once when a unit brings no mean partials)
+        int nm = 0;
+        for (int i = 0; i < n_units; ++i) nm += (mean_mask >> i) & 1;
+        ProfScope ps(MVF_PROF_DISP_MEAN, st, 4LL * nm * B * N + (int64_t)sizeof(ImgTab) * n_units * B);
+        hipLaunchKernelGGL(k_units_prepare, dim3(mean_mask ? NMEAN : 1, (unsigned)B, (unsigned)n_units), dim3(256), 0, st,
+                           a, S, mean_mask, tickets + n_units + 1);
+    }
+    {
         // launch kind for the per-type medians of bench.py: identity maps taken over / mask supplied / neither
-        int tag = MVF_TAG_SINGLE_FRAME;
+        int tag = MVF_TAG_SINGLE_FRAME, nmask = 0;
         for (int i = 0; i < n_units; ++i) {
             if (a.u[i].ident_in) tag = MVF_TAG_MULTI_FRAME;
-            else if (a.u[i].mask && tag != MVF_TAG_MULTI_FRAME) tag = MVF_TAG_AFFINE;
+            nmask += a.u[i].mask != nullptr;
         }
+        if (tag != MVF_TAG_MULTI_FRAME && nmask) tag = (nmask == n_units) ? MVF_TAG_AFFINE : MVF_TAG_MIXED;
         ProfScope ps(MVF_PROF_UNIT_FWDBWD, st, (int64_t)n_units * B * N, tag);
         const dim3 grid((unsigned)(ntiles * B * n_units));
         const bool avg = flags & MVF_AVG_REPROJ;
@@ -1475,10 +1581,13 @@ int mvf_units_fwdbwd_scale(const mvf_unit_scale_desc *units, int n_units, float 
     const int N = H * W;
     ScaleArgs a = {};
     bool vec = (N % 4 == 0);
+    bool any_disp = false;
     for (int i = 0; i < n_units; ++i) {
         const mvf_unit_scale_desc &d = units[i];
-        if (!d.g_disp_raw || !d.g_T_raw || !d.stats || (!d.g_loss && !d.g_sum) || !d.g_disp || !d.g_T)
+        // g_disp == NULL: only grad_T of that unit (its disparity gradient goes raw to mvf_disp_head_bwd_units)
+        if (!d.g_T_raw || !d.stats || (!d.g_loss && !d.g_sum) || !d.g_T || (d.g_disp && !d.g_disp_raw))
             return (int)hipErrorInvalidValue;
+        any_disp = any_disp || d.g_disp;
         ScaleUnit &u = a.u[i];
         u.g_raw = d.g_disp_raw; u.gT_raw = d.g_T_raw; u.stats = d.stats; u.g_loss = d.g_loss; u.g_sum = d.g_sum;
         u.g_disp = d.g_disp; u.gT = d.g_T;
@@ -1492,10 +1601,12 @@ int mvf_units_fwdbwd_scale(const mvf_unit_scale_desc *units, int n_units, float 
     a.N = N;
     a.N4 = vec ? N / 4 : 0;
     a.nT = S * B * 16;
-    const int per = vec ? a.N4 : (N + 3) / 4;
+    const int per = any_disp ? (vec ? a.N4 : (N + 3) / 4) : 0;
     const unsigned gx = (unsigned)((max(per, a.nT) + 255) / 256);
-    ProfScope ps(MVF_PROF_FB_SCALE, stream, 8LL * n_units * B * N);       // raw gradient read, scaled gradient written
-    hipLaunchKernelGGL(k_fb_scale, dim3(gx, (unsigned)B + 1, (unsigned)n_units), dim3(256), 0,
+    int nd = 0;
+    for (int i = 0; i < n_units; ++i) nd += units[i].g_disp != nullptr;
+    ProfScope ps(MVF_PROF_FB_SCALE, stream, 8LL * nd * B * N);            // raw gradient read, scaled gradient written
+    hipLaunchKernelGGL(k_fb_scale, dim3(gx, (unsigned)(any_disp ? B : 0) + 1, (unsigned)n_units), dim3(256), 0,
                        (hipStream_t)stream, a);
     return hip_check_launch();
 }

@@ -94,7 +94,7 @@ class HotPathLosses:
                                                   *imgs_src)
         return loss, (auto_mask if want_auto_mask and not o.disable_automasking else None)
 
-    def compute_units(self, units, want_ident=False, want_auto_mask=False, want_sum=False):
+    def compute_units(self, units, want_ident=False, want_auto_mask=False, want_sum=False, sum_in=None):
         """Several mutually independent units of one shape as ONE launch (reference: the three
         calls of each group in process_batch, train.py:747-760 / 795-810 / 837-882).
 
@@ -103,7 +103,9 @@ class HotPathLosses:
         sources returned).  Returns (losses [n], idents list | None, auto_masks list | None); with
         ``want_sum`` the first element is the 0-dim SUM of the n losses instead (what process_batch adds to
         loss_base per group, train.py:760 / 812 / 882), written by the launch itself -- no reduction launch
-        forward, no expand + copy of its gradient backward.
+        forward, no expand + copy of its gradient backward; ``sum_in`` (0-dim fp32 tensor on the device, with
+        ``want_sum``): the running total the sum is added to, inside the same finishing kernel.  ``want_ident``:
+        one flag for all units or one per unit.
         Falls back to one `compute_unit` per entry -- and then returns `idents = None`: no identity
         maps are handed over, the partner units re-evaluate them -- when the forward+backward kernel
         cannot take the group as one launch: `--batch_units False`, more than MAX_UNITS entries, S > 2,
@@ -125,20 +127,40 @@ class HotPathLosses:
             out = [self.compute_unit(un["disp_tgt"], un["img_tgt"], un["poses"], un["imgs_src"], un["K"],
                                      un["inv_K"], un.get("mask_rec"), want_auto_mask) for un in units]
             per_unit = torch.stack([l for l, _ in out])
-            return (per_unit.sum() if want_sum else per_unit), None, ([m for _, m in out] if want_auto_mask else None)
+            if want_sum:
+                per_unit = per_unit.sum() if sum_in is None else sum_in + per_unit.sum()
+            return per_unit, None, ([m for _, m in out] if want_auto_mask else None)
         in_kernel = getattr(o, "inkernel_noise", True) and getattr(self, "tie_break_noise", None) is None
-        flat, mean_parts = [], []
+        flat, mean_parts, sinks, tokens = [], [], [], []
+        defer = bool(getattr(o, "defer_unit_grads", True))
         for un, (disp, T) in zip(units, prepared):
             noise = None if in_kernel else self._tie_break_noise(disp, S)
+            # a disparity that is a view of its head's output (ops.disp_head): the unit reads it in place and leaves
+            # its raw gradient to the head's adjoint kernel (ops.HeadSink) -- no scaled copy, no re-interleaving stack
+            sink = un["disp_tgt"].get(("disp_head_sink", 0)) if defer else None
+            where = sink.covers(disp) if (sink is not None and disp.requires_grad) else None
+            if where is not None:
+                sinks.append((sink, where[0], where[1]))
+                if not any(t is sink.token for t in tokens):
+                    tokens.append(sink.token)
+                disp = disp.detach()
+            else:
+                sinks.append(None)
             flat += [disp, un["img_tgt"], T, un["K"], un["inv_K"], un.get("mask_rec"), noise,
                      un.get("ident"), *un["imgs_src"]]
             mean_parts.append(un["disp_tgt"].get(("disp_mean_partials", 0)))
+        wid = list(want_ident) if isinstance(want_ident, (list, tuple)) else [bool(want_ident)] * n
+        use_sum_in = bool(want_sum) and sum_in is not None
+        if use_sum_in:
+            flat.append(sum_in.float().reshape(()))
         cfg = dict(n=n, S=S, flags=self._loss_flags(), smoothness=float(o.disparity_smoothness),
                    min_depth=o.min_depth, max_depth=o.max_depth, eps=1e-7,
-                   want_mask=bool(want_auto_mask), want_idx=False, want_ident=bool(want_ident), want_sum=bool(want_sum),
+                   want_mask=bool(want_auto_mask), want_idx=False, want_ident=wid, want_sum=bool(want_sum),
+                   sum_in=use_sum_in, sinks=sinks if tokens else None, n_tokens=len(tokens),
                    mean_parts=mean_parts if any(m is not None for m in mean_parts) else None)
-        res = ops.Units.apply(cfg, *flat)
+        res = ops.Units.apply(cfg, *flat, *tokens)
         losses, per = (res[-1] if want_sum else res[0]), res[2:]
-        idents = [per[4 * u + 3] for u in range(n)] if want_ident and not o.disable_automasking else None
+        idents = [per[4 * u + 3] if wid[u] else None for u in range(n)] \
+            if any(wid) and not o.disable_automasking else None
         masks = [per[4 * u + 0] for u in range(n)] if want_auto_mask and not o.disable_automasking else None
         return losses, idents, masks

@@ -83,9 +83,11 @@ class DepthDecoder(nn.Module):
                 and not torch.is_autocast_enabled():
             # sigmoid + disp_to_depth + the unit kernel's mean partials in one pass (ops.disp_head)
             from .. import ops
-            disp, depth, part = ops.disp_head(logit, min_depth, max_depth)
+            disp, depth, part, sink = ops.disp_head(logit, min_depth, max_depth, want_sink=True)
             self.outputs[("disp", 0)], self.outputs[("depth", 0)] = disp, depth
             self.outputs[("disp_mean_partials", 0)] = part
+            if sink is not None:
+                self.outputs[("disp_head_sink", 0)] = sink        # ops.HeadSink (not a tensor)
         else:
             self.outputs[("disp", 0)] = self.sigmoid(logit)
         return self.outputs

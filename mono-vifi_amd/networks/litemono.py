@@ -412,9 +412,11 @@ class DepthDecoder(nn.Module):
                 if i == 0 and f.is_cuda and f.dtype == torch.float32 and self.num_output_channels == 1 \
                         and not torch.is_autocast_enabled():
                     from .. import ops
-                    disp, depth, part = ops.disp_head(f, min_depth, max_depth)
+                    disp, depth, part, sink = ops.disp_head(f, min_depth, max_depth, want_sink=True)
                     self.outputs[("disp", 0)], self.outputs[("depth", 0)] = disp, depth
                     self.outputs[("disp_mean_partials", 0)] = part
+                    if sink is not None:
+                        self.outputs[("disp_head_sink", 0)] = sink        # ops.HeadSink (not a tensor)
                 else:
                     self.outputs[("disp", i)] = self.sigmoid(f)
         return self.outputs

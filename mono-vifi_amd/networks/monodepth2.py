@@ -82,11 +82,15 @@ class DepthDecoder(nn.Module):
             if i in self.scales:
                 logit = self._blk("dispconv", i)(x)
                 if fused and self.num_output_channels == 1:
-                    disp, depth, part = ops.disp_head(logit, min_depth, max_depth, want_depth=(i == 0))
+                    disp, depth, part, sink = ops.disp_head(logit, min_depth, max_depth, want_depth=(i == 0),
+                                                            want_sink=True)
                     self.outputs[("disp", i)] = disp
                     if i == 0:
                         self.outputs[("depth", 0)] = depth
                         self.outputs[("disp_mean_partials", 0)] = part
+                        if sink is not None:
+                            # (not a tensor: where the hot-path units leave their raw disparity gradients, ops.HeadSink)
+                            self.outputs[("disp_head_sink", 0)] = sink
                 else:
                     self.outputs[("disp", i)] = self.sigmoid(logit)
         return self.outputs

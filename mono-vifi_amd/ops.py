@@ -440,22 +440,42 @@ class Units(torch.autograd.Function):
 
     apply(cfg, disp_0, tgt_0, T_0, K_0, inv_K_0, mask_0, noise_0, ident_in_0, *src_0 (S), disp_1, ...)
     cfg = dict(n, S, flags, smoothness, min_depth, max_depth, eps, want_mask, want_idx,
-               want_ident, want_sum, noise_out (list|None), mean_parts (list|None))
+               want_ident (bool | one bool per unit), want_sum, sum_in (bool), noise_out (list|None),
+               mean_parts (list|None))
     returns (losses [n], terms [n,2] (photo, smooth), then per unit: auto_mask, argmin, idx,
              ident) -- absent outputs are empty tensors -- and, LAST, with want_sum the 0-dim sum of the n
     losses (differentiable like `losses`; the finishing kernel writes it, the backward pass takes its upstream
-    gradient as one more device scalar: no reduce / expand / copy launches around a group of units)."""
+    gradient as one more device scalar: no reduce / expand / copy launches around a group of units).
+    With cfg["sum_in"] the input tensor after the units' is a 0-dim running total (fp32, on the device) the sum starts
+    from: `loss_base += group` of train.py:760 / 812 / 882 inside the finishing kernel; its gradient is the sum's.
+    cfg["sinks"] (list per unit of (HeadSink, first, step) | None) + cfg["n_tokens"] trailing token inputs: a unit with a
+    sink reads the disparity head's output in place (pass it DETACHED); its raw disparity gradient is deposited in the
+    sink during backward and scaled by the head's adjoint kernel on load (see `HeadSink`)."""
 
     @staticmethod
     def forward(ctx, cfg, *flat):
         n, S = cfg["n"], cfg["S"]
         flags, smoothness = cfg["flags"], cfg["smoothness"]
         per = UNIT_FIELDS + S
+        want_sum = bool(cfg.get("want_sum", False))
+        n_tok = int(cfg.get("n_tokens", 0))
+        if n_tok:
+            flat = flat[:-n_tok]       # the tokens only carry the autograd edge to their disparity heads
+        sinks = cfg.get("sinks") or [None] * n
+        sum_in = None
+        if cfg.get("sum_in", False):
+            if not want_sum:
+                raise RuntimeError("sum_in needs want_sum")
+            flat, sum_in = flat[:-1], flat[-1]
+            if sum_in.dtype != torch.float32 or sum_in.numel() != 1:
+                raise RuntimeError("sum_in must be one fp32 value")
+            nat.require_device(sum_in)
+            sum_in = _c(sum_in)
         assert len(flat) == n * per and 1 <= n <= nat.MAX_UNITS
         md, rg = depth_consts(cfg["min_depth"], cfg["max_depth"])
         want_mask, want_idx, want_ident = cfg.get("want_mask", False), cfg.get("want_idx", False), \
             cfg.get("want_ident", False)
-        want_sum = bool(cfg.get("want_sum", False))
+        want_ident = list(want_ident) if isinstance(want_ident, (list, tuple)) else [bool(want_ident)] * n
         noise_outs = cfg.get("noise_out") or [None] * n
         mean_parts = cfg.get("mean_parts") or [None] * n
         automask = not (flags & NO_AUTOMASK)
@@ -503,7 +523,7 @@ class Units(torch.autograd.Function):
             auto_mask = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if want_mask else None
             idx = torch.empty((S, B, H, W, 2), dtype=torch.int32, device=dev) if want_idx else None
             ident = torch.empty((B, H, W, 2), dtype=torch.float32, device=dev) \
-                if (want_ident and automask) else None
+                if (want_ident[u] and automask) else None
             seed = 0
             if noise is None and automask:
                 # tie-break draw of train.py:1023-1024 generated in the kernel: one 64-bit key per
@@ -536,6 +556,8 @@ class Units(torch.autograd.Function):
             needs.append((ctx.needs_input_grad[1 + u * per], ctx.needs_input_grad[1 + u * per + 2]))
         if want_sum:
             descs[0].loss_sum = loss_sum.data_ptr()
+            descs[0].loss_sum_in = sum_in.data_ptr() if sum_in is not None else None
+            keep.append(sum_in)
         ws = torch.empty(nat.lib().mvf_units_workspace_floats(n, B, H, W), dtype=torch.float32, device=dev)
         tk = _tickets(dev, nat.lib().mvf_units_ticket_ints(n, B))
         try:
@@ -547,6 +569,7 @@ class Units(torch.autograd.Function):
             raise
         ctx.save_for_backward(g_disp, g_T, stats)
         ctx.n, ctx.S, ctx.smoothness, ctx.per, ctx.needs, ctx.want_sum = n, S, smoothness, per, needs, want_sum
+        ctx.has_sum_in, ctx.n_tok, ctx.sinks = sum_in is not None, n_tok, sinks
         res = (loss3[:, 0], loss3[:, 1:], *outs)
         ctx.mark_non_differentiable(*res[1:])
         if want_sum:
@@ -562,8 +585,9 @@ class Units(torch.autograd.Function):
         # raw gradients for an upstream gradient of 1; one pass applies the per-image constant of
         # the mean-normalised smoothness term and each unit's upstream gradient (its own + the sum's)
         g_sum = rest[-1] if ctx.want_sum else None
+        tail = ((g_sum,) if ctx.has_sum_in else ()) + (None,) * ctx.n_tok          # d sum / d sum_in = 1
         if g_losses is None and g_sum is None:
-            return (None,) * (1 + ctx.n * ctx.per)
+            return (None,) * (1 + ctx.n * ctx.per) + tail
         g_raw, gT_raw, stats = ctx.saved_tensors
         n, S = ctx.n, ctx.S
         _, B, _, H, W = g_raw.shape
@@ -571,27 +595,36 @@ class Units(torch.autograd.Function):
             g_losses = _c(g_losses).reshape(n)
         if g_sum is not None:
             g_sum = _c(g_sum.float()).reshape(1)
-        g_disp, g_T = torch.empty_like(g_raw), torch.empty_like(gT_raw)
+        sinks = ctx.sinks
+        g_disp = torch.empty_like(g_raw) if any(s is None for s in sinks) else None
+        g_T = torch.empty_like(gT_raw)
         descs = (nat.UnitScaleDesc * n)()
         for u in range(n):
             d = descs[u]
-            d.g_disp_raw, d.in_stride = g_raw[u].data_ptr(), H * W
             d.g_T_raw, d.stats = gT_raw[u].data_ptr(), stats[u].data_ptr()
             d.g_loss = (g_losses.data_ptr() + 4 * u) if g_losses is not None else None
             d.g_sum = g_sum.data_ptr() if g_sum is not None else None
-            d.g_disp, d.out_stride = g_disp[u].data_ptr(), H * W
             d.g_T = g_T[u].data_ptr()
+            if sinks[u] is None:
+                d.g_disp_raw, d.in_stride = g_raw[u].data_ptr(), H * W
+                d.g_disp, d.out_stride = g_disp[u].data_ptr(), H * W
+            else:
+                # the disparity head this unit read in place takes the raw gradient and scales it on load
+                sink, first, step = sinks[u]
+                sink.entries.append(dict(raw=g_raw[u], stats=stats[u], smoothness=float(ctx.smoothness),
+                                         g_loss=(g_losses, u) if g_losses is not None else None, g_sum=g_sum,
+                                         first=int(first), step=int(step)))
         nat.check(nat.lib().mvf_units_fwdbwd_scale(C.cast(descs, C.c_void_p), n, ctx.smoothness, B, S, H, W,
                                                    _stream()), "units_fwdbwd_scale")
         grads = [None]
         for u in range(n):
             gu = [None] * ctx.per
-            if ctx.needs[u][0]:
+            if ctx.needs[u][0] and sinks[u] is None:
                 gu[0] = g_disp[u]
             if ctx.needs[u][1]:
                 gu[2] = g_T[u]
             grads += gu
-        return tuple(grads)
+        return tuple(grads) + tail
 
 
 class Unit:
@@ -1038,13 +1071,46 @@ def up2cat_pad(x, skip=None):
     return Up2CatPad.apply(x, skip)
 
 
+class HeadSink:
+    """What a disparity head hands to the hot-path units that read its output in place: during backward a unit
+    deposits its RAW disparity gradient here (`Units.backward`) instead of returning a scaled tensor to autograd, and
+    the head's adjoint kernel applies `(raw - shift_b) * g` on load (`mvf_disp_head_bwd_units`) -- no k_fb_scale pass,
+    no `stack` of the group gradients.  `token` is an (empty) differentiable output of the head every such unit launch
+    takes as an input: the autograd edge that makes the engine run the head's backward AFTER those units' backward."""
+
+    def __init__(self, disp, token, entries):
+        # (no reference to `disp` or to the autograd node: the node holds `entries`, this object holds the token --
+        # a cycle through the node would keep the head's tensors alive until the garbage collector runs)
+        self.token, self.entries = token, entries
+        self.storage, self.offset, self.shape = disp.untyped_storage().data_ptr(), disp.storage_offset(), tuple(disp.shape)
+
+    def covers(self, view):
+        """(first image, image step) of `view` [B,1,H,W] inside the head's batch, or None if it is not such a view."""
+        if view is None or view.dtype != torch.float32 or view.dim() != 4 or tuple(view.shape[1:]) != self.shape[1:]:
+            return None
+        if view.untyped_storage().data_ptr() != self.storage:
+            return None
+        N = self.shape[1] * self.shape[2] * self.shape[3]
+        st = view.stride()
+        if st[3] != 1 or st[2] != view.shape[3]:
+            return None
+        off = view.storage_offset() - self.offset
+        step = st[0] if view.shape[0] > 1 else N
+        if off < 0 or off % N or step % N or step < N:
+            return None
+        first, step = off // N, step // N
+        if first + (view.shape[0] - 1) * step >= self.shape[0]:
+            return None
+        return first, step
+
+
 class DispHead(torch.autograd.Function):
     """sigmoid (networks/monodepth2.py:93) fused with disp_to_depth (layers.py:16-25):
     logit [B,1,H,W] -> disp, depth (or None), per-image mean partials of disp [B,32] for the unit
-    kernel (not differentiable)."""
+    kernel (not differentiable), token (empty; see `HeadSink`)."""
 
     @staticmethod
-    def forward(ctx, logit, min_depth, max_depth, want_depth):
+    def forward(ctx, logit, min_depth, max_depth, want_depth, entries):
         nat.require_device(logit)
         logit = _c(logit)
         B = logit.shape[0]
@@ -1062,25 +1128,50 @@ class DispHead(torch.autograd.Function):
         # depth is unused would otherwise hand backward() a full-size zero g_depth (a fill launch, and a
         # plane the adjoint kernel then reads)
         ctx.set_materialize_grads(False)
-        return disp, (depth if want_depth else torch.empty(0, device=logit.device)), part
+        token = logit.new_empty(0)
+        ctx.entries = entries          # the list the units' backward fills (HeadSink.entries)
+        return disp, (depth if want_depth else torch.empty(0, device=logit.device)), part, token
 
     @staticmethod
-    def backward(ctx, g_disp, g_depth, _g_part):
+    def backward(ctx, g_disp, g_depth, _g_part, _g_token):
         (disp,) = ctx.saved_tensors
         md, rg = ctx.consts
-        if g_disp is None and g_depth is None:
-            return None, None, None, None
-        g_disp = _c(g_disp) if g_disp is not None else torch.zeros_like(disp)
+        entries = ctx.entries
+        if g_disp is None and g_depth is None and not entries:
+            return None, None, None, None, None
         g_depth = _c(g_depth) if (g_depth is not None and g_depth.numel() == disp.numel()) else None
         g = torch.empty_like(disp)
+        if entries:
+            # the units that read this head's output in place: their raw gradients, scaled on load
+            if len(entries) > nat.MAX_UNITS:
+                raise RuntimeError("more than MAX_UNITS deferred units on one disparity head")
+            g_disp = _c(g_disp) if g_disp is not None else None
+            B, N = disp.shape[0], disp[0].numel()
+            descs = (nat.HeadUnitGrad * len(entries))()
+            for d, e in zip(descs, entries):
+                d.g_disp_raw, d.raw_stride = e["raw"].data_ptr(), N
+                d.stats = e["stats"].data_ptr()
+                d.g_loss = (e["g_loss"][0].data_ptr() + 4 * e["g_loss"][1]) if e["g_loss"] is not None else None
+                d.g_sum = e["g_sum"].data_ptr() if e["g_sum"] is not None else None
+                d.smoothness, d.first, d.step, d.count = e["smoothness"], e["first"], e["step"], e["raw"].shape[0]
+            nat.check(nat.lib().mvf_disp_head_bwd_units(
+                nat.ptr(disp), nat.ptr(g_disp), nat.ptr(g_depth), nat.ptr(g), B, N, md, rg,
+                C.cast(descs, C.c_void_p), len(entries), _stream()), "disp_head_bwd_units")
+            del entries[:]
+            return g, None, None, None, None
+        g_disp = _c(g_disp) if g_disp is not None else torch.zeros_like(disp)
         nat.check(nat.lib().mvf_disp_head_bwd(nat.ptr(disp), nat.ptr(g_disp), nat.ptr(g_depth), nat.ptr(g),
                                               disp.numel(), md, rg, _stream()), "disp_head_bwd")
-        return g, None, None, None
+        return g, None, None, None, None
 
 
-def disp_head(logit, min_depth=0.1, max_depth=100.0, want_depth=True):
-    """-> (disp, depth | None, mean_partials)"""
-    disp, depth, part = DispHead.apply(logit, min_depth, max_depth, bool(want_depth))
+def disp_head(logit, min_depth=0.1, max_depth=100.0, want_depth=True, want_sink=False):
+    """-> (disp, depth | None, mean_partials) and, with `want_sink`, a `HeadSink` as fourth element"""
+    entries = []
+    disp, depth, part, token = DispHead.apply(logit, min_depth, max_depth, bool(want_depth), entries)
+    if want_sink:
+        sink = HeadSink(disp, token, entries) if (disp.requires_grad and torch.is_grad_enabled()) else None
+        return disp, (depth if want_depth else None), part, sink
     return disp, (depth if want_depth else None), part
 
 

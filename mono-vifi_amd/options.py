@@ -116,6 +116,14 @@ def build_parser():
     p.add_argument("--batch_units", type=_str2bool, default=True,
                    help="the three mutually independent hot-path units of each group of a step "
                         "(single-frame / multi-frame / affine) as ONE kernel launch instead of three")
+    p.add_argument("--merge_unit_groups", type=_str2bool, default=True,
+                   help="with --batch_units: the single-frame and the affine units of a step (mutually independent: "
+                        "train.py:747-760, 837-882) as ONE launch of six units, the multi-frame ones second -- two unit "
+                        "launches per step instead of three")
+    p.add_argument("--defer_unit_grads", type=_str2bool, default=True,
+                   help="a hot-path unit that reads a disparity head's output in place leaves its RAW disparity gradient "
+                        "to the head's adjoint kernel, which applies the per-image shift and the upstream gradient on load "
+                        "(no scaling pass, no re-interleaving copy of the group gradients)")
     p.add_argument("--share_identity", type=_str2bool, default=True,
                    help="the multi-frame unit of a target takes the identity-reprojection maps the "
                         "single-frame unit of the same target and sources computed (train.py:747-749 vs "

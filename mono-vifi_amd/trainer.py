@@ -35,6 +35,7 @@ from torch.utils.data import DataLoader
 from . import datasets, parallel
 from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth, transformation_from_parameters
 from .losses import HotPathLosses
+from ._native import MAX_UNITS
 from .networks import FusionModule, IFRNet, dhrnet, grouped, litemono, monodepth2, posenet
 
 
@@ -449,7 +450,8 @@ class Trainer(HotPathLosses):
             out = self._nets(lambda: m(feats, self.opt.min_depth, self.opt.max_depth))
         else:
             out = self._nets(lambda: m(feats))
-        return {k: v.float() for k, v in out.items()}
+        # (("disp_head_sink", 0) is not a tensor: ops.HeadSink, passed through)
+        return {k: (v.float() if torch.is_tensor(v) else v) for k, v in out.items()}
 
     def _encode(self, name, img):
         if self.opt.channels_last:
@@ -465,14 +467,15 @@ class Trainer(HotPathLosses):
         loss, _ = self.compute_losses_base(disp, tgt, warped, srcs, mask_rec)
         return loss
 
-    def _units(self, units, want_ident=False):
-        """Mutually independent hot-path units of one group (reference: e.g. train.py:747-760):
-        ONE launch of the forward+backward tile kernel for all of them.  units: dicts as for
-        `compute_units`.  Returns (sum of their losses, identity maps per unit | None)."""
+    def _units(self, units, want_ident=False, sum_in=None):
+        """Mutually independent hot-path units (reference: e.g. train.py:747-760): ONE launch of the
+        forward+backward tile kernel for all of them.  units: dicts as for `compute_units`; `want_ident`: one flag
+        or one per unit; `sum_in`: the running loss total the launch adds its units' losses to.
+        Returns (sum_in + sum of their losses, identity maps per unit | None)."""
         if self.opt.fused_units:
-            total, idents, _ = self.compute_units(units, want_ident=want_ident, want_sum=True)
+            total, idents, _ = self.compute_units(units, want_ident=want_ident, want_sum=True, sum_in=sum_in)
             return total, idents
-        total = None
+        total = sum_in
         for un in units:
             l = self._unit(un["disp_tgt"], un["img_tgt"], un["poses"], un["imgs_src"], un["K"], un["inv_K"],
                            un.get("mask_rec"))
@@ -535,7 +538,7 @@ class Trainer(HotPathLosses):
         # a no-op today (no decoder has BatchNorm); keeps per-call statistics if one ever does
         with grouped.grouped(self.models[decoder], G):
             out = self._depth(decoder, merged)
-        split = {k: grouped.split_groups(v, G) for k, v in out.items()}
+        split = {k: (grouped.split_groups(v, G) if torch.is_tensor(v) else [v] * G) for k, v in out.items()}
         return [{k: split[k][g] for k in out} for g in range(G)]
 
     def _fuse_many(self, jobs, merged_feats=None):
@@ -555,7 +558,7 @@ class Trainer(HotPathLosses):
         mask = grouped.merge_groups([j[2] for j in jobs])
         with grouped.grouped(self.models["fusion_module"], G), grouped.grouped(self.models["depth_mf"], G):
             out = one(feats, flows, mask)
-        split = {k: grouped.split_groups(v, G) for k, v in out.items()}
+        split = {k: (grouped.split_groups(v, G) if torch.is_tensor(v) else [v] * G) for k, v in out.items()}
         return [{k: split[k][g] for k in out} for g in range(G)]
 
     def predict_poses_many(self, pairs):
@@ -662,13 +665,38 @@ class Trainer(HotPathLosses):
 
         def unit(disp, tgt, poses, sources=srcs, **kw):
             return dict(disp_tgt=disp, img_tgt=tgt, poses=poses, imgs_src=sources, K=K, inv_K=inv_K, **kw)
-        # the three single-frame units (train.py:747-760): one launch.  Each also hands the identity
-        # maps of its (target, sources) to the multi-frame unit of the same target below
+        # ---- the affine-augmented views' units (train.py:837-882) need nothing the multi-frame branch produces: their
+        # disparities come out of the same decoder call as the single-frame ones
+        units_a, todo = [], ()
+        if o.use_affine:
+            Rc = inputs["Rc"]
+            # (the graph step inverts Rc before the replay: a solver call does not belong in a capture)
+            # inv_ex = torch.inverse (same LU, bit-identical result) WITHOUT its host-side singularity check: that check
+            # reads a device flag and so drained the stream in the middle of every step's forward pass (measured:
+            # 92 ms of the host's 120 ms forward enqueue spent waiting there; tools/host_audit.py, tools/inv_probe.py)
+            Rc_inv = inputs["Rc_inv"] if "Rc_inv" in inputs else torch.linalg.inv_ex(Rc).inverse
+            srcs_a = [inputs[("color_affine", -1, 0)], inputs[("color_affine", 1, 0)]]
+            mask_rec = inputs["valid_mask_rec"]
+            for (pa, pb), tgt, disp_a in zip(((pose_0_n1, pose_0_p1), (pose_nt_n1, pose_nt_p1), (pose_pt_n1, pose_pt_p1)),
+                                              tgts_a, dec[3:]):
+                poses_a = [self._affine_pose(pa, Rc, Rc_inv), self._affine_pose(pb, Rc, Rc_inv)]
+                units_a.append(unit(disp_a, tgt, poses_a, srcs_a, mask_rec=mask_rec))
+
+        # the three single-frame units (train.py:747-760) AND the three affine ones: mutually independent, ONE launch
+        # of six units (round 4: two launches of three).  Each single-frame unit also hands the identity maps of its
+        # (target, sources) to the multi-frame unit of the same target below
         share = bool(getattr(o, "share_identity", True)) and not o.disable_automasking
-        l_sf, idents = self._units([unit(disp_0, img_0, [pose_0_n1, pose_0_p1]),
-                                    unit(disp_pt, img_pt, [pose_pt_n1, pose_pt_p1]),
-                                    unit(disp_nt, img_nt, [pose_nt_n1, pose_nt_p1])], want_ident=share)
-        losses["loss_base"] = losses["loss_base"] + l_sf
+        units_sf = [unit(disp_0, img_0, [pose_0_n1, pose_0_p1]), unit(disp_pt, img_pt, [pose_pt_n1, pose_pt_p1]),
+                    unit(disp_nt, img_nt, [pose_nt_n1, pose_nt_p1])]
+        merged_launch = bool(units_a) and bool(getattr(o, "merge_unit_groups", True)) and o.fused_units \
+            and getattr(o, "batch_units", True) and len(units_sf) + len(units_a) <= MAX_UNITS
+        if merged_launch:
+            total, idents = self._units(units_sf + units_a, want_ident=[share] * 3 + [False] * len(units_a))
+            idents = idents[:3] if idents is not None else None
+        else:
+            total, idents = self._units(units_sf, want_ident=share)
+            if units_a:
+                total, _ = self._units(units_a, sum_in=total)
         if share and idents is None and not getattr(self, "_share_warned", False):
             # --share_identity only works through the batched forward+backward launch
             self._share_warned = True
@@ -691,35 +719,20 @@ class Trainer(HotPathLosses):
         disp_0_fuse, disp_nt_fuse, disp_pt_fuse = fused
         depth_0_fuse, depth_nt_fuse, depth_pt_fuse = (to_depth(d) for d in fused)
 
-        # the three multi-frame units (train.py:795-810): one launch, identity maps handed over
-        l_mf, _ = self._units([unit(disp_0_fuse, img_0, [pose_0_n1, pose_0_p1], ident=id_0),
-                               unit(disp_nt_fuse, img_nt, [pose_nt_n1, pose_nt_p1], ident=id_nt),
-                               unit(disp_pt_fuse, img_pt, [pose_pt_n1, pose_pt_p1], ident=id_pt)])
-        losses["loss_base"] = losses["loss_base"] + l_mf
+        # the three multi-frame units (train.py:795-810): one launch, identity maps handed over; its finishing kernel
+        # adds the first launch's total (loss_base of train.py:760 / 812 / 882 without an add launch)
+        total, _ = self._units([unit(disp_0_fuse, img_0, [pose_0_n1, pose_0_p1], ident=id_0),
+                                unit(disp_nt_fuse, img_nt, [pose_nt_n1, pose_nt_p1], ident=id_nt),
+                                unit(disp_pt_fuse, img_pt, [pose_pt_n1, pose_pt_p1], ident=id_pt)], sum_in=total)
+        losses["loss_base"] = total
         losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_0, depth_0_fuse)
         losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_nt, depth_nt_fuse)
         losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_pt, depth_pt_fuse)
 
-        # ---- affine-augmentation losses
+        # ---- affine-augmentation consistency losses (train.py:868-882)
         if o.use_affine:
-            Rc = inputs["Rc"]
-            # (the graph step inverts Rc before the replay: a solver call does not belong in a capture)
-            # inv_ex = torch.inverse (same LU, bit-identical result) WITHOUT its host-side singularity check: that check
-            # reads a device flag and so drained the stream in the middle of every step's forward pass (measured:
-            # 92 ms of the host's 120 ms forward enqueue spent waiting there; tools/host_audit.py, tools/inv_probe.py)
-            Rc_inv = inputs["Rc_inv"] if "Rc_inv" in inputs else torch.linalg.inv_ex(Rc).inverse
-            srcs_a = [inputs[("color_affine", -1, 0)], inputs[("color_affine", 1, 0)]]
-            mask_rec = inputs["valid_mask_rec"]
-            todo = ((pose_0_n1, pose_0_p1, depth_0, depth_0_fuse), (pose_nt_n1, pose_nt_p1, depth_nt, depth_nt_fuse),
-                    (pose_pt_n1, pose_pt_p1, depth_pt, depth_pt_fuse))
-            # the three affine units (train.py:837-882): one launch
-            units_a = []
-            for (pa, pb, depth_s, depth_f), tgt, disp_a in zip(todo, tgts_a, dec[3:]):
-                poses_a = [self._affine_pose(pa, Rc, Rc_inv), self._affine_pose(pb, Rc, Rc_inv)]
-                units_a.append(unit(disp_a, tgt, poses_a, srcs_a, mask_rec=mask_rec))
-            l_af, _ = self._units(units_a)
-            losses["loss_base"] = losses["loss_base"] + l_af
-            for (pa, pb, depth_s, depth_f), disp_a in zip(todo, dec[3:]):
+            todo = ((depth_0, depth_0_fuse), (depth_nt, depth_nt_fuse), (depth_pt, depth_pt_fuse))
+            for (depth_s, depth_f), disp_a in zip(todo, dec[3:]):
                 losses["loss_dc"] = losses["loss_dc"] + self.compute_depth_consistency_loss_affine(
                     to_depth(disp_a), depth_s, depth_f, inputs)
 

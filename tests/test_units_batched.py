@@ -297,3 +297,116 @@ def test_group_sum_written_by_the_launch(dev, shape, n):
     _, g_b = run("both")
     for (a, b), (c, d) in zip(g_b, g_l):                 # 0.5 + 1.5 == 2.0: the two upstream gradients add exactly
         assert np.array_equal(a, c) and np.array_equal(b, d)
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 70), (12, 192, 640)])
+def test_six_units_mixed_masks_and_chained_sum(dev, shape):
+    """Round 5: the single-frame and the affine units of a step as ONE launch of six (three without and three with
+    mask_rec, train.py:747-760 + 837-882), identity maps wanted for the first three only, and the launch's total
+    chained into the next launch's finishing kernel (`sum_in`): every unit == the same unit launched alone, bit for
+    bit; total == ((0 + l0) + l1 ...) in unit order with the running total in front."""
+    from mono_vifi_amd import ops
+    B, H, W = shape
+    inps = [_inputs(5100 + 17 * u + H, B, H, W, 0, with_mask=(u >= 3)) for u in range(6)]
+    flat, leaves = [], []
+    for inp in inps:
+        d, Tt, f = _flat(inp, dev, 0)
+        flat += f
+        leaves.append((d, Tt))
+    res = ops.Units.apply(_cfg(6, 0, want_ident=[True] * 3 + [False] * 3, want_sum=True), *flat)
+    losses, per, total = res[0], res[2:-1], res[-1]
+    for u in range(6):
+        assert (per[4 * u + 3].numel() > 0) == (u < 3), "identity maps only where they were asked for"
+    # second launch: two more units, the first launch's total as its running total
+    inps2 = [_inputs(5300 + 19 * u + H, B, H, W, 0, with_mask=False) for u in range(2)]
+    flat2, leaves2 = [], []
+    for inp in inps2:
+        d, Tt, f = _flat(inp, dev, 0)
+        flat2 += f
+        leaves2.append((d, Tt))
+    res2 = ops.Units.apply(_cfg(2, 0, want_sum=True, sum_in=True), *flat2, total)
+    total2 = res2[-1]
+    (total2 * 1.5).backward()
+
+    seq = np.float32(0.0)
+    for u in range(6):
+        seq = np.float32(seq + np.float32(float(losses[u].detach())))
+    assert np.float32(float(total.detach())) == seq
+    for u in range(2):
+        seq = np.float32(seq + np.float32(float(res2[0][u].detach())))
+    assert np.float32(float(total2.detach())) == seq
+
+    for u, inp in enumerate(inps + inps2):
+        d, Tt, f = _flat(inp, dev, 0)
+        r1 = ops.Units.apply(_cfg(1, 0), *f)
+        (r1[0].sum() * 1.5).backward()
+        many = (res if u < 6 else res2)
+        uu = u if u < 6 else u - 6
+        lv = leaves[u] if u < 6 else leaves2[uu]
+        assert float(many[0][uu].detach()) == float(r1[0][0].detach()), f"unit {u}: loss"
+        assert np.array_equal(N(many[2 + 4 * uu + 1]), N(r1[2 + 1])), f"unit {u}: argmin"
+        assert np.array_equal(N(lv[0].grad), N(d.grad)), f"unit {u}: grad_disp"
+        assert np.array_equal(N(lv[1].grad), N(Tt.grad)), f"unit {u}: grad_T"
+
+
+@pytest.mark.parametrize("shape,G", [((2, 33, 70), 3), ((12, 192, 640), 6)])
+@pytest.mark.parametrize("with_depth_grad", [False, True])
+def test_deferred_unit_gradients_through_the_disparity_head(dev, shape, G, with_depth_grad):
+    """Round 5: units that read a disparity head's output in place leave their RAW gradients to the head's adjoint
+    kernel (ops.HeadSink, mvf_disp_head_bwd_units: (raw - shift_b) * g applied on load).  Against the round-4 route
+    -- k_fb_scale writes scaled gradients, autograd stacks the groups, mvf_disp_head_bwd reads the stack -- the logit
+    gradient and grad_T are identical bit for bit, with and without a second consumer of the head (depth)."""
+    from types import SimpleNamespace
+    from mono_vifi_amd import ops
+    from mono_vifi_amd.losses import HotPathLosses
+    B, H, W = shape
+    n = min(G, 3)
+    inps = [_inputs(6100 + 23 * u + H, B, H, W, 0, with_mask=(u == 1)) for u in range(G)]
+    logit0 = torch.empty((B * G, 1, H, W), device=dev)
+    for g in range(G):
+        dnp = np.clip(inps[g]["disp"], 1e-4, 1 - 1e-4)
+        logit0.view(B, G, 1, H, W)[:, g] = T(np.log(dnp / (1 - dnp)).astype(np.float32), dev)
+    wdep = torch.rand((B * G, 1, H, W), device=dev)
+
+    class L(HotPathLosses):
+        pass
+
+    def run(defer):
+        l = L()
+        l.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False, avg_reprojection=False,
+                                disable_automasking=False, disparity_smoothness=1e-3, inkernel_noise=False,
+                                batch_units=True, defer_unit_grads=defer)
+        logit = logit0.clone().requires_grad_(True)
+        disp, depth, part, sink = ops.disp_head(logit, 0.1, 100.0, want_depth=True, want_sink=True)
+        assert sink is not None
+        views = torch.unbind(disp.view(B, G, 1, H, W), 1)
+        parts = torch.unbind(part.view(B, G, 32), 1)
+        units, Ts = [], []
+        for u in range(n):
+            inp = inps[u]
+            Tt = T(inp["T"], dev, True)
+            Ts.append(Tt)
+            l.tie_break_noise = None
+            units.append(dict(disp_tgt={("disp", 0): views[u], ("disp_mean_partials", 0): parts[u].contiguous(),
+                                        ("disp_head_sink", 0): sink},
+                              img_tgt=T(inp["tgt"], dev), poses=Tt, imgs_src=[T(inp["src"][0], dev), T(inp["src"][1], dev)],
+                              K=T(inp["K"], dev), inv_K=T(inp["inv_K"], dev),
+                              mask_rec=T(inp["mask_rec"], dev) if inp["mask_rec"] is not None else None))
+        torch.manual_seed(7)          # the tie-break draw (a tensor here) is the same in both runs
+        total, _, _ = l.compute_units(units, want_sum=True)
+        loss = total * 0.75
+        if with_depth_grad:
+            loss = loss + (depth * wdep).mean()
+        loss.backward()
+        return float(total.detach()), N(logit.grad), [N(t.grad) for t in Ts], len(sink.entries)
+
+    a = run(False)
+    b = run(True)
+    assert b[3] == 0, "the head's backward consumed the deposited entries"
+    assert a[0] == b[0]
+    assert np.array_equal(a[1], b[1]), "logit gradient: deferred route != scaled-tensor route"
+    for x, y in zip(a[2], b[2]):
+        assert np.array_equal(x, y)
+    # the groups no unit read got no disparity gradient (only the depth term, if any)
+    if not with_depth_grad and G > n:
+        assert float(np.abs(b[1].reshape(B, G, -1)[:, n:]).max()) == 0.0
