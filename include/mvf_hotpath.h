@@ -320,6 +320,20 @@ MVF_API size_t mvf_fusion_bwd_workspace_ints(int B, int h, int w);
 MVF_API int mvf_fusion_level_bwd_gather(const float *g_out, const float *prep, const float *xs, const float *ys,
                                 float *g_feat_n1, float *g_feat_p1, int32_t *workspace, int B, int C, int h,
                                 int w, void *stream);
+/* Round 5: the deterministic adjoint through ANCHOR lists (an output pixel listed once, under the top-left cell of the
+ * 2x2 block it touches; its channel values fetched once instead of once per touched cell), the lists of ALL pyramid
+ * levels of a step built by one count / scan / fill / sort pass: they depend only on prep (the teacher's flows).
+ * lists[i]: mvf_fusion_lists_level_ints(B, hs[i], ws[i]) int32, 16-byte aligned, kept until the level's backward;
+ * scratch: mvf_fusion_lists_scratch_ints(...) int32, free after the call (stream order).
+ * mvf_fusion_level_bwd_lists == mvf_fusion_level_bwd_gather within rounding (another fixed order of the same
+ * additions), bit-reproducible from run to run. */
+MVF_API size_t mvf_fusion_lists_level_ints(int B, int h, int w);
+MVF_API size_t mvf_fusion_lists_scratch_ints(int B, int n_levels, const int32_t *hs, const int32_t *ws);
+MVF_API int mvf_fusion_lists_build(const float *const *preps, const float *const *xs, const float *const *ys,
+                           const int32_t *hs, const int32_t *ws, int n_levels, int B, int32_t *const *lists,
+                           int32_t *scratch, void *stream);
+MVF_API int mvf_fusion_level_bwd_lists(const float *g_out, const int32_t *lists, float *g_feat_n1, float *g_feat_p1,
+                               int B, int C, int h, int w, void *stream);
 
 /* ---- f2: Trainer.compute_SI_log_depth_loss (train.py:924-941) ----
  * pred, target [B,1,H,W] (N = H*W), mask nullable [B,1,H,W] (same shape; any batch size).
@@ -333,6 +347,25 @@ MVF_API int mvf_silog_bwd(const float *pred, const float *target, const float *m
                   const float *g_loss, float *g_pred, float *g_target, int B, int N, float beta,
                   void *stream);
 
+/* The SI-log losses of a step (train.py:813-815, 868-882: nine per step) as ONE forward and ONE backward launch.
+ * A job reads image b of pred / target / mask at base + b * stride (floats; 0 = N: contiguous), so the depth views of a
+ * grouped decoder call are read in place.  losses [n_jobs], total [1] = their sum in job order, sums [n_jobs,B,4];
+ * workspace: mvf_silog_many_workspace_floats(n_jobs, B) floats; tickets: n_jobs + 1 int32, ZERO on entry, left zero.
+ * Backward: upstream gradient of job j = *g_total (nullable) + g_losses[j] (nullable), g_pred / g_target [B,N]
+ * contiguous, nullable per job.  Same arithmetic per job as mvf_silog_fwd / mvf_silog_bwd. */
+#define MVF_MAX_SILOG_JOBS 16
+typedef struct mvf_silog_job {
+    const float *pred;   int64_t pred_stride;
+    const float *target; int64_t target_stride;
+    const float *mask;   int64_t mask_stride;         /* nullable */
+    float *g_pred, *g_target;                         /* backward only */
+} mvf_silog_job;
+MVF_API size_t mvf_silog_many_workspace_floats(int n_jobs, int B);
+MVF_API int mvf_silog_many_fwd(const mvf_silog_job *jobs, int n_jobs, float *losses, float *total, float *sums,
+                       float *workspace, int32_t *tickets, int B, int N, float beta, void *stream);
+MVF_API int mvf_silog_many_bwd(const mvf_silog_job *jobs, int n_jobs, const float *sums, const float *g_total,
+                       const float *g_losses, int B, int N, float beta, void *stream);
+
 /* ---- f2: the affine-augmentation glue ---------------------------
  * Trainer.affine_transform (train.py:888-902): per sample rotate(img, angle) (torchvision
  * functional.rotate, bilinear, zero fill), crop box = (x0, y0, w, h), F.interpolate back to
@@ -343,11 +376,21 @@ MVF_API int mvf_silog_bwd(const float *pred, const float *target, const float *m
  * inside the image (the reference's slicing / paste assume it too). */
 MVF_API int mvf_affine_transform_fwd(const float *img, const float *angle_deg, const int32_t *box,
                              float *out, int B, int C, int H, int W, void *stream);
+/* the same for B images that are views of B_meta samples (image b uses angle / box of sample b % B_meta): the frames
+ * train.py:832-833 transforms one call each, as one launch over their concatenation */
+MVF_API int mvf_affine_transform_views_fwd(const float *img, const float *angle_deg, const int32_t *box, float *out,
+                                   int B, int B_meta, int C, int H, int W, void *stream);
 /* depth_restore of Trainer.compute_depth_consistency_loss_affine (train.py:909-916):
  * out = ratio[b] * rotate( zeros(H,W) with F.interpolate(depth -> (h,w)) pasted at (x0,y0),
  * -angle[b] ).  depth/out [B,C,H,W]. */
 MVF_API int mvf_affine_restore_fwd(const float *depth, const float *angle_deg, const int32_t *box,
                            const float *ratio, float *out, int B, int C, int H, int W, void *stream);
+/* the same with the C planes of image b at depth + b * image_stride (floats; 0 = C*H*W): several depth maps that lie
+ * one plane apart -- consecutive groups of a grouped decoder call's interleaved output -- restored by ONE launch as the
+ * channels of one image (they share angle / box / ratio: train.py:868-882 restores three per step) */
+MVF_API int mvf_affine_restore_strided_fwd(const float *depth, int64_t image_stride, const float *angle_deg,
+                                   const int32_t *box, const float *ratio, float *out, int B, int C, int H,
+                                   int W, void *stream);
 /* g_depth = adjoint of the above applied to g_out; deterministic (two gather passes, no
  * atomics).  workspace: B*C*H*W floats. */
 MVF_API int mvf_affine_restore_bwd(const float *g_out, const float *angle_deg, const int32_t *box,

@@ -58,6 +58,16 @@ class HeadUnitGrad(C.Structure):
     ]
 
 
+class SilogJob(C.Structure):
+    """mvf_silog_job: one SI-log loss of an mvf_silog_many_fwd / _bwd launch."""
+    _fields_ = [
+        ("pred", _vp), ("pred_stride", _i64), ("target", _vp), ("target_stride", _i64),
+        ("mask", _vp), ("mask_stride", _i64), ("g_pred", _vp), ("g_target", _vp),
+    ]
+
+
+MAX_SILOG_JOBS = 16
+
 # name -> argument ctypes (return type is always int = hipError_t unless listed in _RESTYPE)
 _SIGNATURES = {
     "mvf_abi_version": [],
@@ -136,9 +146,18 @@ _SIGNATURES = {
     "mvf_fusion_level_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_fusion_bwd_workspace_ints": [_i, _i, _i],
     "mvf_fusion_level_bwd_gather": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_fusion_lists_level_ints": [_i, _i, _i],
+    "mvf_fusion_lists_scratch_ints": [_i, _i, _vp, _vp],
+    "mvf_fusion_lists_build": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp],
+    "mvf_fusion_level_bwd_lists": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_silog_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mvf_silog_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mvf_silog_many_workspace_floats": [_i, _i],
+    "mvf_silog_many_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp],
+    "mvf_silog_many_bwd": [_vp, _i, _vp, _vp, _vp, _i, _i, _f, _vp],
     "mvf_affine_transform_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_affine_transform_views_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvf_affine_restore_strided_fwd": [_vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "mvf_reflect_pad1_fwd": [_vp, _vp, _i, _i, _i, _vp],
     "mvf_reflect_pad1_bwd": [_vp, _vp, _i, _i, _i, _vp],
     "mvf_affine_restore_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -156,6 +175,7 @@ PROF_FIRST_GLUE, PROF_COUNT = 7, 36         # ids >= 7: glue kernels, profile le
 TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine", 3: "single_frame+affine"}
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_profile_name": C.c_char_p, "mvf_profile_read_launches": C.c_int64, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,
+            "mvf_silog_many_workspace_floats": C.c_size_t, "mvf_fusion_lists_level_ints": C.c_size_t, "mvf_fusion_lists_scratch_ints": C.c_size_t,
             "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t,
             "mvf_units_workspace_floats": C.c_size_t, "mvf_units_ticket_ints": C.c_size_t,
             "mvf_resize_bilinear_bwd_workspace_floats": C.c_size_t}

@@ -120,14 +120,14 @@ MVF_DEV Box box_of(const int32_t *__restrict__ box, int b, int H, int W)
 __global__ void __launch_bounds__(NT) k_affine_transform(const float *__restrict__ img,
                                                          const float *__restrict__ angle,
                                                          const int32_t *__restrict__ box,
-                                                         float *__restrict__ out, int C, int H, int W)
+                                                         float *__restrict__ out, int C, int H, int W, int Bm)
 {
     __shared__ Trig sh;
-    const int b = blockIdx.z;
-    const Trig t = block_trig(angle[b], &sh);
+    const int b = blockIdx.z, bm = b % Bm;       // image b takes angle / box of sample b % Bm (several views per sample)
+    const Trig t = block_trig(angle[bm], &sh);
     const int x = blockIdx.x * TX + (threadIdx.x & (TX - 1)), y = blockIdx.y * TY + threadIdx.x / TX;
     if (x >= W || y >= H) return;
-    const Box k = box_of(box, b, H, W);
+    const Box k = box_of(box, bm, H, W);
     const RTap ry = resize_src(y, k.h, H), rx = resize_src(x, k.w, W);
     ZTap z[4];
 #pragma unroll
@@ -162,7 +162,8 @@ __global__ void __launch_bounds__(NT) k_affine_restore_fwd(const float *__restri
                                                            const float *__restrict__ angle,
                                                            const int32_t *__restrict__ box,
                                                            const float *__restrict__ ratio,
-                                                           float *__restrict__ out, int C, int H, int W)
+                                                           float *__restrict__ out, int C, int H, int W,
+                                                           size_t in_stride)
 {
     __shared__ Trig sh;
     const int b = blockIdx.z;
@@ -178,7 +179,7 @@ __global__ void __launch_bounds__(NT) k_affine_restore_fwd(const float *__restri
     const float r = ratio[b];
     const size_t N = (size_t)H * W;
     for (int c = 0; c < C; ++c) {
-        const float *d = depth + ((size_t)b * C + c) * N;
+        const float *d = depth + (size_t)b * in_stride + (size_t)c * N;
         float v = 0.0f;
         if (ya && xa) v += canvas_at(d, H, W, k, z.y0, z.x0) * ((1.0f - z.lx) * (1.0f - z.ly));
         if (ya && xb) v += canvas_at(d, H, W, k, z.y0, z.x0 + 1) * (z.lx * (1.0f - z.ly));
@@ -303,22 +304,34 @@ extern "C" {
 int mvf_affine_transform_fwd(const float *img, const float *angle_deg, const int32_t *box, float *out,
                              int B, int C, int H, int W, void *stream)
 {
+    return mvf_affine_transform_views_fwd(img, angle_deg, box, out, B, B, C, H, W, stream);
+}
+
+int mvf_affine_transform_views_fwd(const float *img, const float *angle_deg, const int32_t *box, float *out,
+                                   int B, int B_meta, int C, int H, int W, void *stream)
+{
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-    if (!img || !angle_deg || !box || !out || B > 65535) return (int)hipErrorInvalidValue;
+    if (!img || !angle_deg || !box || !out || B > 65535 || B_meta < 1 || B % B_meta) return (int)hipErrorInvalidValue;
     ProfScope ps(MVF_PROF_AFFINE, stream, 8LL * B * C * H * W);
     hipLaunchKernelGGL(k_affine_transform, tile_grid(B, H, W), dim3(NT), 0, (hipStream_t)stream, img,
-                       angle_deg, box, out, C, H, W);
+                       angle_deg, box, out, C, H, W, B_meta);
     return hip_check_launch();
 }
 
 int mvf_affine_restore_fwd(const float *depth, const float *angle_deg, const int32_t *box,
                            const float *ratio, float *out, int B, int C, int H, int W, void *stream)
 {
+    return mvf_affine_restore_strided_fwd(depth, 0, angle_deg, box, ratio, out, B, C, H, W, stream);
+}
+
+int mvf_affine_restore_strided_fwd(const float *depth, int64_t image_stride, const float *angle_deg, const int32_t *box,
+                                   const float *ratio, float *out, int B, int C, int H, int W, void *stream)
+{
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
-    if (!depth || !angle_deg || !box || !ratio || !out || B > 65535) return (int)hipErrorInvalidValue;
+    if (!depth || !angle_deg || !box || !ratio || !out || B > 65535 || image_stride < 0) return (int)hipErrorInvalidValue;
     ProfScope ps(MVF_PROF_AFFINE, stream, 8LL * B * C * H * W);
     hipLaunchKernelGGL(k_affine_restore_fwd, tile_grid(B, H, W), dim3(NT), 0, (hipStream_t)stream, depth,
-                       angle_deg, box, ratio, out, C, H, W);
+                       angle_deg, box, ratio, out, C, H, W, image_stride ? (size_t)image_stride : (size_t)C * H * W);
     return hip_check_launch();
 }
 

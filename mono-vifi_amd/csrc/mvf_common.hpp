@@ -587,6 +587,23 @@ MVF_DEV float wave_sum(float v)      // result in lane 63
     return v;
 }
 
+// ---- message passing between the blocks of the small kernels (unit preparing / finishing, SI-log finishing) -----------------------------
+// A block publishes a few values and takes a ticket; the block that draws the last ticket reads everybody's values.
+// __threadfence() on this chip is `buffer_wbl2 sc1` + wait: a write-back of the XCD's whole L2 (4 MiB, full of the unit
+// kernel's gradient planes) per call -- measured: 60 us for the 2,304 blocks of one preparing launch.  Instead every
+// published value is an agent-scope atomic store (sc1: written through to the device-coherent level), the ticket is
+// taken after `s_waitcnt vmcnt(0)` (the stores have completed), and the reader uses agent-scope atomic loads (sc1:
+// not served from a stale L2 line): the same ordering for exactly the values involved, no cache maintenance.
+template <typename Tv>
+MVF_DEV void publish(Tv *p, Tv v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename Tv>
+MVF_DEV Tv fetch_published(const Tv *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+MVF_DEV int take_ticket(int *tk)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // everything published before is complete
+    return __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // sum over the workgroup; result valid in thread 0.  `scratch` holds >= nwaves floats.
 template <int NT>
 MVF_DEV float block_sum(float v, float *scratch)

@@ -421,6 +421,262 @@ __global__ void __launch_bounds__(NT) k_flow_warp_bwd_gather(const float *__rest
         if (k < nc) g_img[((size_t)b * C + c0 + k) * n + q] = acc[k];
 }
 
+// ---- round 5: ANCHOR lists -----------------------------------------------------------------------------------
+// The four cells an output pixel p touches are the 2x2 block at its top-left tap (y0, x0) -- its ANCHOR.  Listing p
+// once, under its anchor, instead of once under each of the four cells makes the integer work of the inverse map a
+// quarter (one counting atomic, one entry of 16 bytes per pixel and source instead of four of 8), the lists average
+// ONE entry instead of four (nothing to sort, no long serial tails where the flow converges), and -- the point -- the
+// channel values g[c][p] are fetched ONCE per pixel instead of once per touched cell:
+//   S_k[a] = sum over the (sorted) list of anchor a of  w_k(p) * sc(p) * g[p],  k = the four corners of the block
+//   grad[q] = ((S_0[q] + S_1[q - (0,1)]) + S_2[q - (1,0)]) + S_3[q - (1,1)]
+// Deterministic like the cell lists: every list is sorted by p, the four terms are added in a fixed order.  Zero-weight
+// corners are skipped exactly as dest_of skips them (a clamped tap carries weight 0: it would otherwise index a
+// neighbour that does not exist, and 0 x inf would poison the sum).
+// The lists of ALL pyramid levels of a step are built by one count / scan / fill / sort pass (they depend only on the
+// teacher's flows: known when the forward pass ends), not by six launches per level inside backward.
+#ifndef MVF_ANC_CH
+#define MVF_ANC_CH 8
+#endif
+constexpr int ACH = MVF_ANC_CH;            // channels per pass of a lane over its two anchor lists
+constexpr int MAXLV = 8;
+struct AncLevel {
+    const float *prep, *xs, *ys;
+    int *cnt, *cur, *off;                  // [2][B][n], [2][B][n], [2][B][n+1]
+    int4 *ent;                             // [2][B][n]: (p, wx bits, wy bits, merge weight bits)
+    int h, w, blk0;                        // blk0: first block of the level in the flattened pixel grid
+};
+struct AncLevels {
+    AncLevel l[MAXLV];
+    int n, B;
+};
+MVF_DEV int level_of_block(const AncLevels &L, int blk)
+{
+    int lv = 0;
+#pragma unroll
+    for (int k = 1; k < MAXLV; ++k)
+        if (k < L.n && blk >= L.l[k].blk0) lv = k;
+    return lv;
+}
+struct AncTap {
+    int anchor;
+    float wx, wy, sc;
+};
+MVF_DEV AncTap anchor_of(const AncLevel &v, int b, int s, int i)
+{
+    const int n = v.h * v.w, y = i / v.w, x = i - y * v.w;
+    const float *pp = v.prep + (size_t)b * PREP * n + i;
+    const Tap t = flow_tap_xy(pp[(size_t)(4 + 2 * s) * n], pp[(size_t)(5 + 2 * s) * n], v.xs, v.ys, x, y, v.h, v.w);
+    const float m = pp[8 * (size_t)n];
+    AncTap a;
+    a.anchor = t.y0 * v.w + t.x0;
+    a.wx = t.wx; a.wy = t.wy;
+    a.sc = (s == 0) ? m : 1.0f - m;
+    return a;
+}
+// grid (pixel blocks of all levels, B, 2 sources)
+__global__ void __launch_bounds__(NT) k_anc_count(AncLevels L)
+{
+    const int lv = level_of_block(L, blockIdx.x);
+    const AncLevel &v = L.l[lv];
+    const int n = v.h * v.w, i = (blockIdx.x - v.blk0) * NT + threadIdx.x, b = blockIdx.y, s = blockIdx.z;
+    if (i >= n) return;
+    const AncTap a = anchor_of(v, b, s, i);
+    atomicAdd(v.cnt + ((size_t)s * L.B + b) * n + a.anchor, 1);
+}
+// block = (source-image pair, level): exclusive scan of the counts (the cell-list scan above, per level)
+__global__ void __launch_bounds__(1024) k_anc_scan(AncLevels L)
+{
+    // chunks of 4,096 counts: a lane takes four consecutive ones (coalesced), the block scans the lane totals
+    // (shuffle scan inside a wave, the 16 wave totals through LDS), the running prefix carries over
+    __shared__ int wtot[16];
+    __shared__ int carry_s;
+    const AncLevel &v = L.l[blockIdx.y];
+    const int n = v.h * v.w;
+    const int *cnt = v.cnt + (size_t)blockIdx.x * n;
+    int *off = v.off + (size_t)blockIdx.x * (n + 1);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int carry = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int i0 = base + 4 * t;
+        int c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) c[k] = (i0 + k < n) ? cnt[i0 + k] : 0;
+        const int tot = (c[0] + c[1]) + (c[2] + c[3]);
+        int inc = tot;                                      // inclusive scan over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(inc, d);
+            if (lane >= d) inc += o;
+        }
+        if (lane == 63) wtot[wv] = inc;
+        __syncthreads();
+        int wpre = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wpre += (k < wv) ? wtot[k] : 0;
+        int run = carry + wpre + inc - tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (i0 + k < n) off[i0 + k] = run;
+            run += c[k];
+        }
+        if (t == 1023) carry_s = run;
+        __syncthreads();
+        carry = carry_s;
+    }
+    if (t == 0) off[n] = carry;
+}
+__global__ void __launch_bounds__(NT) k_anc_fill(AncLevels L)
+{
+    const int lv = level_of_block(L, blockIdx.x);
+    const AncLevel &v = L.l[lv];
+    const int n = v.h * v.w, i = (blockIdx.x - v.blk0) * NT + threadIdx.x, b = blockIdx.y, s = blockIdx.z;
+    if (i >= n) return;
+    const AncTap a = anchor_of(v, b, s, i);
+    const size_t sb = (size_t)s * L.B + b;
+    const int slot = v.off[sb * (n + 1) + a.anchor] + atomicAdd(v.cur + sb * n + a.anchor, 1);
+    v.ent[sb * n + slot] = make_int4(i, __float_as_int(a.wx), __float_as_int(a.wy), __float_as_int(a.sc));
+}
+// every anchor sorts its list by output pixel (lists average one entry: most lanes have nothing to do)
+__global__ void __launch_bounds__(NT) k_anc_sort(AncLevels L)
+{
+    const int lv = level_of_block(L, blockIdx.x);
+    const AncLevel &v = L.l[lv];
+    const int n = v.h * v.w, q = (blockIdx.x - v.blk0) * NT + threadIdx.x;
+    if (q >= n) return;
+    const size_t sb = (size_t)blockIdx.z * L.B + blockIdx.y;
+    const int *off = v.off + sb * (n + 1);
+    int4 *ent = v.ent + sb * n;
+    const int lo = off[q], hi = off[q + 1];
+    if (hi - lo < 3) return;            // a pair is put in order by its reader (k_fusion_level_bwd_anchor)
+    for (int a = lo + 1; a < hi; ++a) {
+        const int4 e = ent[a];
+        int c = a - 1;
+        while (c >= lo && ent[c].x > e.x) { ent[c + 1] = ent[c]; --c; }
+        ent[c + 1] = e;
+    }
+}
+
+// the four corner weights of an entry, as dest_of forms them (merge weight folded in), 0 where the corner is dropped
+MVF_DEV void corner_weights(const int4 &e, float wt[4])
+{
+    const float fw = __int_as_float(e.y), fe = 1.0f - fw, fn = __int_as_float(e.z), fs = 1.0f - fn;
+    const float sc = __int_as_float(e.w);
+    const float raw[4] = {fs * fe, fs * fw, fn * fe, fn * fw};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wt[k] = (raw[k] != 0.0f) ? raw[k] * sc : 0.0f;
+}
+// lane t-1's value (0 into lane 0 of the wave): DPP wave_shr:1
+MVF_DEV float from_prev_lane(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+// A workgroup owns a 32 x 8 region of anchors, one per lane, and emits the 31 x 7 cells whose four anchors lie inside
+// it.  Per round of ACH channels a lane forms the four corner sums of its anchor (stage A: the channel values of an
+// output pixel are fetched ONCE); its cell then needs S_0 (own), S_1 of the west anchor = lane t - 1 (one DPP wave
+// shift: a region row is half a wave, and the lane a shift would take across a row end never emits), and S_2, S_3 of
+// the row above: S_2 and the already west-shifted S_3 go through LDS (two planes, double buffered: ONE barrier per
+// round).  Measured against an LDS-free form in which a lane evaluates the anchor above its cell as well (every g
+// fetched by two lanes): equal at near-identity flows, 1.5 x faster at 6 px flows (that form's second readers sit on
+// other XCDs: L2 hit rate 30 %, twice the HBM reads; its two list walks per lane diverge twice).
+constexpr int ATW = 32, ATH = 8;           // anchors per region
+constexpr int AGRP = 64;                   // channels per block (the list entries are read once per group)
+#ifndef MVF_ANC_WAVES
+#define MVF_ANC_WAVES 4
+#endif
+// grid (region tiles, channel groups, B * 2 sources)
+__global__ void __launch_bounds__(NT, MVF_ANC_WAVES) k_fusion_level_bwd_anchor(const float *__restrict__ g_out,
+                                                                const int *__restrict__ off_all,
+                                                                const int4 *__restrict__ ent_all,
+                                                                float *__restrict__ g_fn1, float *__restrict__ g_fp1,
+                                                                int B, int C, int h, int w, int tiles_x)
+{
+    __shared__ float S[2][2][ACH][NT];
+    const int n = h * w;
+    const int s = blockIdx.z / B, b = blockIdx.z - s * B;
+    float *dst = (s == 0) ? g_fn1 : g_fp1;
+    if (!dst) return;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int t = threadIdx.x, lx = t & (ATW - 1), ly = t / ATW;
+    // region origin: one anchor row / column in front of the tile's cells
+    const int ay = ty * (ATH - 1) - 1 + ly, ax = tx * (ATW - 1) - 1 + lx;
+    const bool avalid = ay >= 0 && ay < h && ax >= 0 && ax < w;
+    const size_t sb = (size_t)s * B + b;
+    const int *off = off_all + sb * (n + 1);
+    const int4 *ent = ent_all + sb * n;
+    int lo = 0, hi = 0;
+    if (avalid) { lo = off[ay * w + ax]; hi = off[ay * w + ax + 1]; }
+    const int cnt = hi - lo;
+    // the first two entries of the list up front (lists average one entry); clamped index, predicated use
+    int4 e0 = ent[min(lo, n - 1)], e1 = ent[min(lo + 1, n - 1)];
+    if (cnt == 2 && e0.x > e1.x) { const int4 tmp = e0; e0 = e1; e1 = tmp; }     // (k_anc_sort leaves pairs to the reader)
+    float w0[4], w1[4];
+    corner_weights(e0, w0);
+    corner_weights(e1, w1);
+    // the cell this lane emits: its own anchor position, if the three other anchors are in the region
+    const bool emit = lx >= 1 && ly >= 1 && ay < h && ax < w;      // (ay, ax >= 0 follows)
+    const int CT = 2 * (C + EMB);
+    const int c_lo = blockIdx.y * AGRP, c_hi = min(c_lo + AGRP, C);
+    const float *gb = uniform_ptr(g_out + ((size_t)b * CT + C + EMB) * n);
+    float *db = uniform_ptr(dst + (size_t)b * C * n);
+    const unsigned q4 = (unsigned)(max(ay, 0) * w + max(ax, 0)) * 4u, o0 = (unsigned)e0.x * 4u, o1 = (unsigned)e1.x * 4u;
+    int buf = 0;
+    for (int c0 = c_lo; c0 < c_hi; c0 += ACH, buf ^= 1) {
+        const int nc = min(ACH, c_hi - c0);
+        const float *gc = gb + (size_t)c0 * n;
+        float acc[4][ACH];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) acc[k][j] = 0.0f;
+        if (cnt > 0) {
+            float v0[ACH], v1[ACH];
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) v0[j] = ldg_at(gc + (size_t)min(j, nc - 1) * n, o0);
+            if (cnt > 1) {
+#pragma unroll
+                for (int j = 0; j < ACH; ++j) v1[j] = ldg_at(gc + (size_t)min(j, nc - 1) * n, o1);
+            }
+#pragma unroll
+            for (int j = 0; j < ACH; ++j)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[k][j] += w0[k] * v0[j];
+            if (cnt > 1) {
+#pragma unroll
+                for (int j = 0; j < ACH; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k][j] += w1[k] * v1[j];
+            }
+            for (int q = lo + 2; q < hi; ++q) {
+                const int4 e = ent[q];
+                float wq[4];
+                corner_weights(e, wq);
+#pragma unroll
+                for (int j = 0; j < ACH; ++j) {
+                    const float v = ldg_at(gc + (size_t)min(j, nc - 1) * n, (unsigned)e.x * 4u);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[k][j] += wq[k] * v;
+                }
+            }
+        }
+        float west[ACH];
+#pragma unroll
+        for (int j = 0; j < ACH; ++j) {
+            west[j] = from_prev_lane(acc[1][j]);
+            S[buf][0][j][t] = acc[2][j];
+            S[buf][1][j][t] = from_prev_lane(acc[3][j]);
+        }
+        __syncthreads();        // (the buffer written two rounds ago was read before the previous round's barrier)
+        if (emit) {
+#pragma unroll
+            for (int j = 0; j < ACH; ++j) {
+                if (j >= nc) break;
+                const float r = ((acc[0][j] + west[j]) + S[buf][0][j][t - ATW]) + S[buf][1][j][t - ATW];
+                stg_at(db + (size_t)(c0 + j) * n, q4, r);
+            }
+        }
+    }
+}
+
 // count / scan / fill / sort of the inverse tap lists (see above); FLOW: one source
 template <bool FLOW>
 int build_inverse_lists(const float *field, const float *xs, const float *ys, int32_t *workspace, int B, int h, int w,
@@ -512,6 +768,73 @@ int mvf_fusion_level_bwd_gather(const float *g_out, const float *prep, const flo
     const int nchunk = (C + GCH - 1) / GCH;
     hipLaunchKernelGGL(k_fusion_level_bwd_gather, dim3((unsigned)((n + NT - 1) / NT), (unsigned)nchunk, (unsigned)B),
                        dim3(NT), 0, st, g_out, workspace, g_feat_n1, g_feat_p1, B, C, h, w);
+    return hip_check_launch();
+}
+
+// ints of one level's anchor lists: entries [2][B][n] x 4, offsets [2][B][n+1]
+size_t mvf_fusion_lists_level_ints(int B, int h, int w)
+{
+    const size_t n = (size_t)h * w;
+    return (((size_t)2 * B * n * 4 + (size_t)2 * B * (n + 1)) + 3) & ~(size_t)3;
+}
+// ints of the scratch the build needs (counters + cursors of every level)
+size_t mvf_fusion_lists_scratch_ints(int B, int n_levels, const int32_t *hs, const int32_t *ws)
+{
+    size_t t = 0;
+    for (int i = 0; i < n_levels; ++i) t += (size_t)2 * 2 * B * hs[i] * ws[i];
+    return t + 4;
+}
+
+int mvf_fusion_lists_build(const float *const *preps, const float *const *xs, const float *const *ys, const int32_t *hs,
+                           const int32_t *ws, int n_levels, int B, int32_t *const *lists, int32_t *scratch,
+                           void *stream)
+{
+    if (n_levels <= 0 || B <= 0) return 0;
+    if (n_levels > MAXLV || B > 32767 || !preps || !xs || !ys || !hs || !ws || !lists || !scratch)
+        return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    AncLevels L = {};
+    L.n = n_levels; L.B = B;
+    size_t so = 0;
+    int blk = 0;
+    for (int i = 0; i < n_levels; ++i) {
+        if (!preps[i] || !xs[i] || !ys[i] || !lists[i] || hs[i] < 2 || ws[i] < 2 || (((uintptr_t)lists[i]) & 15))
+            return (int)hipErrorInvalidValue;
+        const size_t n = (size_t)hs[i] * ws[i];
+        AncLevel &v = L.l[i];
+        v.prep = preps[i]; v.xs = xs[i]; v.ys = ys[i]; v.h = hs[i]; v.w = ws[i];
+        v.ent = reinterpret_cast<int4 *>(lists[i]);
+        v.off = lists[i] + (size_t)2 * B * n * 4;
+        v.cnt = scratch + so; so += (size_t)2 * B * n;
+        v.cur = scratch + so; so += (size_t)2 * B * n;
+        v.blk0 = blk;
+        blk += (int)((n + NT - 1) / NT);
+    }
+    hipError_t e = hipMemsetAsync(scratch, 0, so * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    const dim3 gp((unsigned)blk, (unsigned)B, 2);
+    hipLaunchKernelGGL(k_anc_count, gp, dim3(NT), 0, st, L);
+    hipLaunchKernelGGL(k_anc_scan, dim3((unsigned)(2 * B), (unsigned)n_levels), dim3(1024), 0, st, L);
+    hipLaunchKernelGGL(k_anc_fill, gp, dim3(NT), 0, st, L);
+    hipLaunchKernelGGL(k_anc_sort, gp, dim3(NT), 0, st, L);
+    return hip_check_launch();
+}
+
+int mvf_fusion_level_bwd_lists(const float *g_out, const int32_t *lists, float *g_feat_n1, float *g_feat_p1, int B,
+                               int C, int h, int w, void *stream)
+{
+    if (B <= 0 || C <= 0 || h <= 0 || w <= 0) return 0;
+    if (!g_out || !lists || B > 32767 || h < 2 || w < 2) return (int)hipErrorInvalidValue;
+    if (!g_feat_n1 && !g_feat_p1) return 0;
+    const int n = h * w;
+    if ((double)n * 4.0 * ACH >= 2147483648.0) return (int)hipErrorInvalidValue;    // 32-bit byte offsets inside a chunk of planes
+    // the merged half of g_out read once, two feature gradients written once (the lists are this build's own traffic)
+    ProfScope ps(MVF_PROF_FUSION_BWD_GATHER, stream, 4LL * B * n * C * (1 + (g_feat_n1 ? 1 : 0) + (g_feat_p1 ? 1 : 0)));
+    const int tiles_x = (w + ATW - 2) / (ATW - 1), tiles_y = (h + ATH - 2) / (ATH - 1);
+    hipLaunchKernelGGL(k_fusion_level_bwd_anchor, dim3((unsigned)(tiles_x * tiles_y), (unsigned)((C + AGRP - 1) / AGRP),
+                                                      (unsigned)(2 * B)),
+                       dim3(NT), 0, (hipStream_t)stream, g_out, lists + (size_t)2 * B * n * 4,
+                       reinterpret_cast<const int4 *>(lists), g_feat_n1, g_feat_p1, B, C, h, w, tiles_x);
     return hip_check_launch();
 }
 

@@ -502,6 +502,106 @@ __global__ void __launch_bounds__(NT) k_silog_bwd(const float *__restrict__ pred
     if (g_target) g_target[o] = -g * mk / lt;
 }
 
+// ---- the SI-log losses of a step as ONE forward and ONE backward launch (round 5) -----------------------------------
+// process_batch evaluates nine of them (train.py:813-815, 868-882), each on 12 images: nine partial + nine finishing
+// launches forward and nine backward, every one of them bound by its launch, not by its 6 MB.  Jobs: per-image base +
+// stride (the depth views of an interleaved decoder output are read where they lie).  Forward: blocks (chunk, image,
+// job) write partials, the last block of a job to arrive (ticket) folds its images in index order (fp64, the order of
+// k_silog_finish) into sums[job] and loss[job]; the last job adds the losses in job order into total[0].
+struct SilogJob {
+    const float *pred, *target, *mask;
+    size_t ps, ts, ms;                   // image strides (floats)
+    float *g_pred, *g_target;            // backward outputs [B,N] contiguous, nullable
+};
+struct SilogJobs {
+    SilogJob j[MVF_MAX_SILOG_JOBS];
+    int n;
+};
+__global__ void __launch_bounds__(NT) k_silog_many_fwd(SilogJobs J, float *__restrict__ ws, float *__restrict__ sums,
+                                                       float *__restrict__ losses, float *__restrict__ total,
+                                                       int *__restrict__ tickets, int B, int N, float beta)
+{
+    __shared__ float scratch[3 * (NT / 16)];
+    __shared__ int s_last;
+    __shared__ double acc[64];
+    const int b = blockIdx.y, jb = blockIdx.z;
+    const SilogJob &job = J.j[jb];
+    const float *p = job.pred + (size_t)b * job.ps, *t = job.target + (size_t)b * job.ts;
+    const float *m = job.mask ? job.mask + (size_t)b * job.ms : nullptr;
+    float v[3] = {0.0f, 0.0f, 0.0f};
+    for (int i = blockIdx.x * NT + threadIdx.x; i < N; i += SIL_NB * NT) {
+        float mk = m ? m[i] : 1.0f;
+        float ld = logf(p[i] + 1e-7f) * mk - logf(t[i] + 1e-7f) * mk;
+        v[0] += ld;
+        v[1] += ld * ld;
+        v[2] += mk;
+    }
+    const float tot = block_sum_many<NT, 3>(v, scratch);
+    float *wj = ws + (size_t)jb * B * SIL_NB * 4;
+    if (threadIdx.x < 3) publish(wj + ((size_t)b * SIL_NB + blockIdx.x) * 4 + threadIdx.x, tot);
+    __syncthreads();                      // (lanes 0 .. 2 have issued their stores: the ticket waits for them)
+    if (threadIdx.x == 0) {
+        // s_waitcnt inside take_ticket covers only this lane's stores: lanes 1, 2 sit in the same wave, and a wave's
+        // stores complete in order with its counter
+        s_last = (take_ticket(tickets + jb) == SIL_NB * B - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // the job's last block: images folded as k_silog_finish folds them
+    double lt = 0.0;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int bb = b0 + (int)threadIdx.x;
+        double lb = 0.0;
+        if (threadIdx.x < 64 && bb < B) {
+            double s1 = 0.0, s2 = 0.0, n = 0.0;
+            for (int k = 0; k < SIL_NB; ++k) {
+                const float *q = wj + ((size_t)bb * SIL_NB + k) * 4;
+                s1 += fetch_published(q); s2 += fetch_published(q + 1); n += fetch_published(q + 2);
+            }
+            n += 1e-8;
+            lb = s2 / n - (double)beta * s1 * s1 / (n * n);
+            float *sj = sums + ((size_t)jb * B + bb) * 4;
+            sj[0] = (float)s1; sj[1] = (float)s2; sj[2] = (float)n; sj[3] = 0.0f;
+        }
+        if (threadIdx.x < 64) acc[threadIdx.x] = lb;
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < 64; ++i) lt += acc[i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float lj = (float)(lt / (double)B);
+        publish(losses + jb, lj);
+        publish(tickets + jb, 0);
+        if (take_ticket(tickets + J.n) == J.n - 1) {
+            float tt = 0.0f;
+            for (int k = 0; k < J.n; ++k) tt += fetch_published(losses + k);
+            total[0] = tt;
+            publish(tickets + J.n, 0);
+        }
+    }
+}
+// element-wise adjoint of every job: upstream gradient = g_total[0] (nullable) + g_losses[job] (nullable)
+__global__ void __launch_bounds__(NT) k_silog_many_bwd(SilogJobs J, const float *__restrict__ sums,
+                                                       const float *__restrict__ g_total,
+                                                       const float *__restrict__ g_losses, int B, int N, float beta)
+{
+    const int b = blockIdx.y, jb = blockIdx.z;
+    const SilogJob &job = J.j[jb];
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= N) return;
+    const float mk = job.mask ? job.mask[(size_t)b * job.ms + i] : 1.0f;
+    const float lp = job.pred[(size_t)b * job.ps + i] + 1e-7f, lt = job.target[(size_t)b * job.ts + i] + 1e-7f;
+    const float ld = logf(lp) * mk - logf(lt) * mk;
+    const float *sj = sums + ((size_t)jb * B + b) * 4;
+    const float s1 = sj[0], n = sj[2];
+    const float gl = (g_total ? g_total[0] : 0.0f) + (g_losses ? g_losses[jb] : 0.0f);
+    const float g = gl / (float)B * (2.0f * ld / n - 2.0f * beta * s1 / (n * n));
+    const size_t o = (size_t)b * N + i;
+    if (job.g_pred) job.g_pred[o] = g * mk / lp;
+    if (job.g_target) job.g_target[o] = -g * mk / lt;
+}
+
 // ---------------------------------------------------------------- Conv3x3's ReflectionPad2d(1)
 // reference: layers.py:121-138 (every 3x3 convolution of the decoders pads by reflection
 // first; the tensors are the largest of the step, up to [72,16,192,640]).  Forward: one lane
@@ -1055,6 +1155,56 @@ int mvf_silog_bwd(const float *pred, const float *target, const float *mask, con
     ProfScope ps(MVF_PROF_SILOG_BWD, stream, 4LL * B * N * (2 + (mask ? 1 : 0) + (g_pred ? 1 : 0) + (g_target ? 1 : 0)));
     hipLaunchKernelGGL(k_silog_bwd, dim3((unsigned)((N + NT - 1) / NT), (unsigned)B), dim3(NT), 0,
                        (hipStream_t)stream, pred, target, mask, sums, g_loss, g_pred, g_target, B, N, beta);
+    return hip_check_launch();
+}
+
+size_t mvf_silog_many_workspace_floats(int n_jobs, int B) { return (size_t)n_jobs * B * SIL_NB * 4; }
+
+static int silog_jobs(const mvf_silog_job *jobs, int n_jobs, int N, bool bwd, SilogJobs &J)
+{
+    if (n_jobs < 1 || n_jobs > MVF_MAX_SILOG_JOBS || !jobs) return (int)hipErrorInvalidValue;
+    J.n = n_jobs;
+    for (int i = 0; i < n_jobs; ++i) {
+        const mvf_silog_job &d = jobs[i];
+        if (!d.pred || !d.target) return (int)hipErrorInvalidValue;
+        SilogJob &j = J.j[i];
+        j.pred = d.pred; j.target = d.target; j.mask = d.mask;
+        j.ps = d.pred_stride ? (size_t)d.pred_stride : (size_t)N;
+        j.ts = d.target_stride ? (size_t)d.target_stride : (size_t)N;
+        j.ms = d.mask_stride ? (size_t)d.mask_stride : (size_t)N;
+        j.g_pred = bwd ? d.g_pred : nullptr; j.g_target = bwd ? d.g_target : nullptr;
+    }
+    return 0;
+}
+
+int mvf_silog_many_fwd(const mvf_silog_job *jobs, int n_jobs, float *losses, float *total, float *sums,
+                       float *workspace, int32_t *tickets, int B, int N, float beta, void *stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    if (B > 65535 || !losses || !total || !sums || !workspace || !tickets) return (int)hipErrorInvalidValue;
+    SilogJobs J = {};
+    if (int e = silog_jobs(jobs, n_jobs, N, false, J)) return e;
+    int64_t bytes = 0;
+    for (int i = 0; i < n_jobs; ++i) bytes += 4LL * B * N * (2 + (jobs[i].mask ? 1 : 0));
+    ProfScope ps(MVF_PROF_SILOG_FWD, stream, bytes);
+    hipLaunchKernelGGL(k_silog_many_fwd, dim3(SIL_NB, (unsigned)B, (unsigned)n_jobs), dim3(NT), 0, (hipStream_t)stream, J,
+                       workspace, sums, losses, total, tickets, B, N, beta);
+    return hip_check_launch();
+}
+
+int mvf_silog_many_bwd(const mvf_silog_job *jobs, int n_jobs, const float *sums, const float *g_total,
+                       const float *g_losses, int B, int N, float beta, void *stream)
+{
+    if (B <= 0 || N <= 0) return 0;
+    if (B > 65535 || !sums || (!g_total && !g_losses)) return (int)hipErrorInvalidValue;
+    SilogJobs J = {};
+    if (int e = silog_jobs(jobs, n_jobs, N, true, J)) return e;
+    int64_t bytes = 0;
+    for (int i = 0; i < n_jobs; ++i)
+        bytes += 4LL * B * N * (2 + (jobs[i].mask ? 1 : 0) + (jobs[i].g_pred ? 1 : 0) + (jobs[i].g_target ? 1 : 0));
+    ProfScope ps(MVF_PROF_SILOG_BWD, stream, bytes);
+    hipLaunchKernelGGL(k_silog_many_bwd, dim3((unsigned)((N + NT - 1) / NT), (unsigned)B, (unsigned)n_jobs), dim3(NT), 0,
+                       (hipStream_t)stream, J, sums, g_total, g_losses, B, N, beta);
     return hip_check_launch();
 }
 

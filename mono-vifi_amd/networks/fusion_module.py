@@ -73,7 +73,8 @@ class FusionModule(nn.Module):
             sizes = [tuple(f.shape[-2:]) for f in feats_0]
             preps = ops.fusion_prep(flow_0_n1, flow_0_p1, merge_mask, sizes, self.backbone == "LiteMono")
             return [self.fusion_conv[self._slot[i]](
-                ops.fusion_level(feats_0[i].float(), feats_n1[i].float(), feats_p1[i].float(), preps[i]))
+                ops.fusion_level(feats_0[i].float(), feats_n1[i].float(), feats_p1[i].float(), preps[i],
+                                 lists=(preps.lists, i)))
                 for i in range(len(feats_0))]
         w_n1 = self.warp_features(feats_n1, flow_0_n1)
         w_p1 = self.warp_features(feats_p1, flow_0_p1)

@@ -818,6 +818,40 @@ def flow_warp_indices(img_shape, flow):
 # ------------------------------------------------------------------ f1 fusion module
 EMB_CH = 42     # Embedder: 2 * (1 + 2 * 10) channels (reference fusion_module.py:43-52)
 FUSION_BWD_GATHER = True     # False: the atomic scatter (mvf_fusion_level_bwd); tests compare both
+FUSION_BWD_ANCHOR = True     # deterministic route: anchor lists built once per step for all levels (round 5);
+                             # False: the round-4 per-level cell lists (mvf_fusion_level_bwd_gather)
+
+
+class PrepList(list):
+    """The per-level side tensors of `fusion_prep`, with `.lists`: the `FusionLists` of the same call (pass
+    `lists=(preps.lists, i)` to `fusion_level` and the backward pass builds the tap lists of all levels at once)."""
+    lists = None
+
+
+class FusionLists:
+    """The inverse (anchor) tap lists of every pyramid level of one FusionModule call, built by ONE count / scan /
+    fill / sort pass the first time a level's backward asks for them (they depend only on the teacher's flows)."""
+
+    def __init__(self, preps):
+        self.preps, self.lists = preps, None
+
+    def level(self, i):
+        if self.lists is None:
+            preps = self.preps
+            L, B, dev = len(preps), preps[0].shape[0], preps[0].device
+            hs = (C.c_int32 * L)(*[int(p.shape[2]) for p in preps])
+            ws = (C.c_int32 * L)(*[int(p.shape[3]) for p in preps])
+            lib = nat.lib()
+            lists = [torch.empty(lib.mvf_fusion_lists_level_ints(B, hs[k], ws[k]), dtype=torch.int32, device=dev)
+                     for k in range(L)]
+            scratch = torch.empty(lib.mvf_fusion_lists_scratch_ints(B, L, hs, ws), dtype=torch.int32, device=dev)
+            xs = [_linspace(int(ws[k]), dev) for k in range(L)]
+            ys = [_linspace(int(hs[k]), dev) for k in range(L)]
+            arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])  # noqa: E731
+            nat.check(lib.mvf_fusion_lists_build(arr(preps), arr(xs), arr(ys), hs, ws, L, B, arr(lists),
+                                                 nat.ptr(scratch), _stream()), "fusion_lists_build")
+            self.lists = lists
+        return self.lists[i]
 
 
 def fusion_prep(flow_n1, flow_p1, mask, sizes, litemono=False):
@@ -843,7 +877,9 @@ def fusion_prep(flow_n1, flow_p1, mask, sizes, litemono=False):
                   "fusion_prep")
         preps.append(prep)
         prev, ph, pw = prep, h, w
-    return preps
+    out = PrepList(preps)
+    out.lists = FusionLists(list(preps))    # (no reference back to `out`: nothing here forms a cycle)
+    return out
 
 
 class FusionLevel(torch.autograd.Function):
@@ -851,7 +887,7 @@ class FusionLevel(torch.autograd.Function):
     (reference: networks/fusion_module.py:105-127)."""
 
     @staticmethod
-    def forward(ctx, feat_0, feat_n1, feat_p1, prep):
+    def forward(ctx, feat_0, feat_n1, feat_p1, prep, plan=None):
         nat.require_device(feat_0, feat_n1, feat_p1, prep)
         feat_0, feat_n1, feat_p1, prep = _c(feat_0), _c(feat_n1), _c(feat_p1), _c(prep)
         B, Cc, h, w = feat_0.shape
@@ -864,6 +900,7 @@ class FusionLevel(torch.autograd.Function):
                                                  w, _stream()), "fusion_level_fwd")
         ctx.save_for_backward(prep, xs, ys)
         ctx.dims = (B, Cc, h, w)
+        ctx.plan = plan
         return out
 
     @staticmethod
@@ -876,21 +913,29 @@ class FusionLevel(torch.autograd.Function):
             # deterministic: inverse tap lists (integer work) + a gather per channel, no float atomics
             gn = torch.empty((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
             gp = torch.empty((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
+            if FUSION_BWD_ANCHOR and (gn is not None or gp is not None):
+                plan, lvl = ctx.plan if ctx.plan is not None else (FusionLists([prep]), 0)
+                lists = plan.level(lvl)
+                nat.check(nat.lib().mvf_fusion_level_bwd_lists(nat.ptr(g), nat.ptr(lists), nat.ptr(gn), nat.ptr(gp),
+                                                               B, Cc, h, w, _stream()), "fusion_level_bwd_lists")
+                return g0, gn, gp, None, None
             ws = torch.empty(nat.lib().mvf_fusion_bwd_workspace_ints(B, h, w), dtype=torch.int32, device=g.device)
             nat.check(nat.lib().mvf_fusion_level_bwd_gather(nat.ptr(g), nat.ptr(prep), nat.ptr(xs), nat.ptr(ys),
                                                             nat.ptr(gn), nat.ptr(gp), nat.ptr(ws), B, Cc, h, w,
                                                             _stream()), "fusion_level_bwd_gather")
-            return g0, gn, gp, None
+            return g0, gn, gp, None, None
         gn = torch.zeros((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[1] else None
         gp = torch.zeros((B, Cc, h, w), dtype=torch.float32, device=g.device) if ctx.needs_input_grad[2] else None
         nat.check(nat.lib().mvf_fusion_level_bwd(nat.ptr(g), nat.ptr(prep), nat.ptr(xs), nat.ptr(ys),
                                                  nat.ptr(gn), nat.ptr(gp), B, Cc, h, w, _stream()),
                   "fusion_level_bwd")
-        return g0, gn, gp, None
+        return g0, gn, gp, None, None
 
 
-def fusion_level(feat_0, feat_n1, feat_p1, prep):
-    return FusionLevel.apply(feat_0, feat_n1, feat_p1, prep)
+def fusion_level(feat_0, feat_n1, feat_p1, prep, lists=None):
+    """`lists`: (FusionLists, level index) of the `fusion_prep` call `prep` came from (`preps.lists`), so that the
+    backward pass builds the inverse tap lists of all levels in one pass; without it each level builds its own."""
+    return FusionLevel.apply(feat_0, feat_n1, feat_p1, prep, lists)
 
 
 # ------------------------------------------------------------------ f2 SI-log depth loss
@@ -938,6 +983,95 @@ def silog_loss(pred, target, mask=None, beta=0.5):
     return SILog.apply(pred, target, mask, beta)
 
 
+def _img1(t):
+    """[B,1,H,W] fp32 whose images are contiguous planes -> (tensor, image stride in floats): a view that strides over
+    the batch only (one group of a grouped decoder call's interleaved output) is read in place."""
+    t, st = _img(t)
+    return t, st
+
+
+class SILogMany(torch.autograd.Function):
+    """Several Trainer.compute_SI_log_depth_loss evaluations (reference: train.py:924-941; process_batch adds nine of
+    them into loss_dc, train.py:813-815, 868-882) as ONE forward and ONE backward launch.
+    apply(beta, n, pred_0, target_0, mask_0 | None, pred_1, ...) -> (total (0-dim: the sum in job order), losses [n])."""
+
+    @staticmethod
+    def forward(ctx, beta, n, *flat):
+        assert len(flat) == 3 * n and 1 <= n <= nat.MAX_SILOG_JOBS
+        B, _, H, W = flat[0].shape
+        N = H * W
+        dev = flat[0].device
+        jobs = (nat.SilogJob * n)()
+        keep = []
+        for j in range(n):
+            pred, target, mask = flat[3 * j:3 * j + 3]
+            nat.require_device(pred, target, mask)
+            if pred.shape[1] != 1 or target.shape != pred.shape or tuple(pred.shape) != (B, 1, H, W):
+                raise RuntimeError("compute_SI_log_depth_loss expects pred/target [B,1,H,W], one shape per launch")
+            if mask is not None and mask.shape != pred.shape:
+                mask = mask.expand(pred.shape).contiguous()      # the reference multiplies: anything broadcastable
+            (pred, ps), (target, ts) = _img1(pred), _img1(target)
+            mask, ms = _img1(mask) if mask is not None else (None, 0)
+            d = jobs[j]
+            d.pred, d.pred_stride, d.target, d.target_stride = pred.data_ptr(), ps, target.data_ptr(), ts
+            d.mask, d.mask_stride = (mask.data_ptr(), ms) if mask is not None else (None, 0)
+            keep += [pred, target, mask]
+        losses = torch.empty(n, dtype=torch.float32, device=dev)
+        total = torch.empty((), dtype=torch.float32, device=dev)
+        sums = torch.empty((n, B, 4), dtype=torch.float32, device=dev)
+        ws = torch.empty(nat.lib().mvf_silog_many_workspace_floats(n, B), dtype=torch.float32, device=dev)
+        tk = _tickets(dev, n + 1)
+        try:
+            nat.check(nat.lib().mvf_silog_many_fwd(C.cast(jobs, C.c_void_p), n, nat.ptr(losses), nat.ptr(total),
+                                                   nat.ptr(sums), nat.ptr(ws), nat.ptr(tk), B, N, float(beta),
+                                                   _stream()), "silog_many_fwd")
+        except Exception:
+            _drop_tickets(dev)
+            raise
+        ctx.save_for_backward(sums, *[t for t in keep if t is not None])
+        ctx.layout = [(keep[3 * j + 2] is not None) for j in range(n)]
+        ctx.strides = [(jobs[j].pred_stride, jobs[j].target_stride, jobs[j].mask_stride) for j in range(n)]
+        ctx.beta, ctx.n, ctx.dims = float(beta), n, (B, H, W)
+        ctx.set_materialize_grads(False)
+        return total, losses
+
+    @staticmethod
+    def backward(ctx, g_total, g_losses):
+        n, (B, H, W) = ctx.n, ctx.dims
+        if g_total is None and g_losses is None:
+            return (None,) * (2 + 3 * n)
+        sums, *rest = ctx.saved_tensors
+        dev = sums.device
+        g_total = _c(g_total.float()).reshape(1) if g_total is not None else None
+        g_losses = _c(g_losses.float()).reshape(n) if g_losses is not None else None
+        jobs = (nat.SilogJob * n)()
+        grads = [None, None]
+        it = iter(rest)
+        outs = []
+        for j in range(n):
+            pred, target = next(it), next(it)
+            mask = next(it) if ctx.layout[j] else None
+            d = jobs[j]
+            ps, ts, ms = ctx.strides[j]
+            d.pred, d.pred_stride, d.target, d.target_stride = pred.data_ptr(), ps, target.data_ptr(), ts
+            d.mask, d.mask_stride = (mask.data_ptr(), ms) if mask is not None else (None, 0)
+            gp = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if ctx.needs_input_grad[2 + 3 * j] else None
+            gt = torch.empty((B, 1, H, W), dtype=torch.float32, device=dev) if ctx.needs_input_grad[3 + 3 * j] else None
+            d.g_pred, d.g_target = nat.ptr(gp), nat.ptr(gt)
+            grads += [gp, gt, None]
+        nat.check(nat.lib().mvf_silog_many_bwd(C.cast(jobs, C.c_void_p), n, nat.ptr(sums), nat.ptr(g_total),
+                                               nat.ptr(g_losses), B, H * W, ctx.beta, _stream()), "silog_many_bwd")
+        return tuple(grads)
+
+
+def silog_many(jobs, beta=0.5):
+    """jobs: [(pred, target, mask | None), ...] of one shape [B,1,H,W] -> (sum of the losses, losses [n])."""
+    flat = []
+    for pred, target, mask in jobs:
+        flat += [pred, target, mask]
+    return SILogMany.apply(float(beta), len(jobs), *flat)
+
+
 # --------------------------------------------------------------------------- f2 affine glue
 def _affine_meta(angle, box, ratio, B, dev):
     """angle [B] or [B,1] degrees fp32, box [B,4] (x0,y0,w,h) int32, ratio [B] or [B,1] fp32 --
@@ -962,10 +1096,15 @@ def affine_transform(img, angle, box):
         raise RuntimeError("affine_transform has no backward (inputs are teacher frames)")
     img = _c(img)
     B, C, H, W = img.shape
-    angle, box, _ = _affine_meta(angle, box, None, B, img.device)
+    # `img` may hold several views per sample, concatenated along the batch ([V*B_meta, ...], image i uses the
+    # parameters of sample i % B_meta): the two teacher frames of a step in one launch
+    Bm = angle.numel()
+    if Bm < 1 or B % Bm:
+        raise RuntimeError("angle must hold B values (or B / V for V concatenated views per sample)")
+    angle, box, _ = _affine_meta(angle, box, None, Bm, img.device)
     out = torch.empty_like(img)
-    nat.check(nat.lib().mvf_affine_transform_fwd(nat.ptr(img), nat.ptr(angle), nat.ptr(box), nat.ptr(out),
-                                                 B, C, H, W, _stream()), "affine_transform_fwd")
+    nat.check(nat.lib().mvf_affine_transform_views_fwd(nat.ptr(img), nat.ptr(angle), nat.ptr(box), nat.ptr(out),
+                                                       B, Bm, C, H, W, _stream()), "affine_transform_fwd")
     return out
 
 
@@ -1000,6 +1139,61 @@ class AffineRestore(torch.autograd.Function):
 
 def affine_restore(depth, angle, box, ratio):
     return AffineRestore.apply(depth, angle, box, ratio)
+
+
+class AffineRestoreMany(torch.autograd.Function):
+    """depth_restore (train.py:909-916) of G depth maps [B,1,H,W] that share angle / box / ratio -- the three affine
+    views of a step (train.py:868-882) -- as ONE launch forward and one rotate + one resize adjoint launch backward:
+    the maps are the channels of one image.  Maps that lie one plane apart in memory (consecutive groups of a grouped
+    decoder call's interleaved output) are read in place.  Returns G tensors [B,1,H,W]."""
+
+    @staticmethod
+    def forward(ctx, angle, box, ratio, *depths):
+        nat.require_device(*depths)
+        G = len(depths)
+        B, C1, H, W = depths[0].shape
+        N = H * W
+        if C1 != 1 or any(tuple(d.shape) != (B, 1, H, W) or d.dtype != torch.float32 for d in depths):
+            raise RuntimeError("affine_restore_many expects fp32 depth maps of one shape [B,1,H,W]")
+        angle, box, ratio = _affine_meta(angle, box, ratio, B, depths[0].device)
+        d0 = depths[0]
+        st0 = d0.stride(0) if B > 1 else G * N
+        in_place = all(d.untyped_storage().data_ptr() == d0.untyped_storage().data_ptr() and
+                       d.storage_offset() == d0.storage_offset() + g * N and
+                       (d.stride(0) if B > 1 else st0) == st0 and d.stride(2) == W and d.stride(3) == 1
+                       for g, d in enumerate(depths)) and st0 >= G * N
+        if in_place:
+            src, stride = d0, st0
+        else:
+            src, stride = torch.cat([_c(d) for d in depths], 1), G * N
+        out = torch.empty((B, G, H, W), dtype=torch.float32, device=d0.device)
+        nat.check(nat.lib().mvf_affine_restore_strided_fwd(src.data_ptr(), stride, nat.ptr(angle), nat.ptr(box),
+                                                           nat.ptr(ratio), nat.ptr(out), B, G, H, W, _stream()),
+                  "affine_restore_fwd")
+        ctx.save_for_backward(angle, box, ratio)
+        ctx.G = G
+        ctx.set_materialize_grads(False)
+        return tuple(out[:, g:g + 1] for g in range(G))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        angle, box, ratio = ctx.saved_tensors
+        G = ctx.G
+        if all(g is None for g in gs):
+            return (None,) * (3 + G)
+        ref = next(g for g in gs if g is not None)
+        B, _, H, W = ref.shape
+        g = torch.cat([_c(x) if x is not None else torch.zeros_like(ref) for x in gs], 1)
+        ws = torch.empty_like(g)
+        gd = torch.empty_like(g)
+        nat.check(nat.lib().mvf_affine_restore_bwd(nat.ptr(g), nat.ptr(angle), nat.ptr(box), nat.ptr(ratio),
+                                                   nat.ptr(ws), nat.ptr(gd), B, G, H, W, _stream()),
+                  "affine_restore_bwd")
+        return (None, None, None) + tuple(gd[:, k:k + 1] for k in range(G))
+
+
+def affine_restore_many(depths, angle, box, ratio):
+    return AffineRestoreMany.apply(angle, box, ratio, *depths)
 
 
 # --------------------------------------------------------------------------- Conv3x3 glue

@@ -120,6 +120,8 @@ def build_parser():
                    help="with --batch_units: the single-frame and the affine units of a step (mutually independent: "
                         "train.py:747-760, 837-882) as ONE launch of six units, the multi-frame ones second -- two unit "
                         "launches per step instead of three")
+    p.add_argument("--batch_silog", type=_str2bool, default=True,
+                   help="the nine SI-log depth-consistency losses of a step as one launch forward and one backward")
     p.add_argument("--defer_unit_grads", type=_str2bool, default=True,
                    help="a hot-path unit that reads a disparity head's output in place leaves its RAW disparity gradient "
                         "to the head's adjoint kernel, which applies the per-image shift and the upstream gradient on load "

@@ -632,8 +632,12 @@ class Trainer(HotPathLosses):
         if o.fuse_model_type != "separate_all":
             enc_in += [aug(-1), aug(1)]
         if o.use_affine:
-            tgts_a = [inputs[("color_affine", 0, 0)], self.affine_transform(img_nt, inputs),
-                      self.affine_transform(img_pt, inputs)]
+            if o.group_calls and img_nt.is_cuda and img_nt.dtype == torch.float32:
+                # the two synthesised frames are the first two chunks of the teacher's batched output: ONE launch
+                t_nt, t_pt = self.affine_transform(im[:2 * B].float(), inputs).chunk(2)
+            else:
+                t_nt, t_pt = self.affine_transform(img_nt, inputs), self.affine_transform(img_pt, inputs)
+            tgts_a = [inputs[("color_affine", 0, 0)], t_nt, t_pt]
             enc_in += [inputs[("color_affine_aug", 0, 0)], tgts_a[1], tgts_a[2]]
         enc = self._encode_many("encoder", enc_in)
         feats_0, feats_nt, feats_pt = enc[0], enc[1], enc[2]
@@ -725,16 +729,21 @@ class Trainer(HotPathLosses):
                                 unit(disp_nt_fuse, img_nt, [pose_nt_n1, pose_nt_p1], ident=id_nt),
                                 unit(disp_pt_fuse, img_pt, [pose_pt_n1, pose_pt_p1], ident=id_pt)], sum_in=total)
         losses["loss_base"] = total
-        losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_0, depth_0_fuse)
-        losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_nt, depth_nt_fuse)
-        losses["loss_dc"] = losses["loss_dc"] + self.compute_SI_log_depth_loss(depth_pt, depth_pt_fuse)
-
-        # ---- affine-augmentation consistency losses (train.py:868-882)
+        # ---- depth-consistency losses: the three multi-frame / single-frame pairs (train.py:813-815) and, per affine
+        # view, the restored depth against both (train.py:868-882) -- nine SI-log evaluations, ONE launch each way
+        dc_jobs = [(depth_0, depth_0_fuse, None), (depth_nt, depth_nt_fuse, None), (depth_pt, depth_pt_fuse, None)]
         if o.use_affine:
+            from . import ops
+            mask_c = inputs["valid_mask_cons"]
             todo = ((depth_0, depth_0_fuse), (depth_nt, depth_nt_fuse), (depth_pt, depth_pt_fuse))
-            for (depth_s, depth_f), disp_a in zip(todo, dec[3:]):
-                losses["loss_dc"] = losses["loss_dc"] + self.compute_depth_consistency_loss_affine(
-                    to_depth(disp_a), depth_s, depth_f, inputs)
+            aff = [to_depth(d) for d in dec[3:]]
+            if getattr(o, "batch_silog", True) and all(t.is_cuda and t.dtype == torch.float32 for t in aff):
+                rest = ops.affine_restore_many(aff, inputs["angle"], inputs["box"], inputs["ratio_local"])
+            else:
+                rest = [ops.affine_restore(t, inputs["angle"], inputs["box"], inputs["ratio_local"]) for t in aff]
+            for (depth_s, depth_f), restored in zip(todo, rest):
+                dc_jobs += [(restored, depth_f, mask_c), (restored, depth_s, mask_c)]
+        losses["loss_dc"] = self._silog_sum(dc_jobs)
 
         losses["loss"] = losses["loss_base"] + o.lamda * losses["loss_dc"]
         return None, losses
@@ -755,6 +764,21 @@ class Trainer(HotPathLosses):
         mask = inputs["valid_mask_cons"]
         return self.compute_SI_log_depth_loss(restored, depth_fuse, mask) + \
             self.compute_SI_log_depth_loss(restored, depth, mask)
+
+    def _silog_sum(self, jobs, beta=0.5):
+        """Sum of compute_SI_log_depth_loss over `jobs` = [(pred, target, mask | None), ...] in list order
+        (reference: the `loss_dc +=` lines of train.py:813-815, 868-882): one launch forward, one backward
+        (`ops.silog_many`) when every tensor is fp32 on the device, else one call per job."""
+        from . import ops
+        ok = getattr(self.opt, "batch_silog", True) and 1 <= len(jobs) <= ops.nat.MAX_SILOG_JOBS and all(
+            t is None or (t.is_cuda and t.dtype == torch.float32 and t.shape == jobs[0][0].shape and t.dim() == 4
+                          and t.shape[1] == 1) for j in jobs for t in j)
+        if ok:
+            return ops.silog_many(jobs, beta)[0]
+        total = torch.zeros((), device=self.device)
+        for pred, target, mask in jobs:
+            total = total + self.compute_SI_log_depth_loss(pred, target, mask, beta)
+        return total
 
     def compute_SI_log_depth_loss(self, pred, target, mask=None, beta=0.5):
         """Scale-invariant log loss (reference: train.py:924-941): one reduction kernel + one

@@ -620,6 +620,71 @@ def test_silog(dev):
     assert rel_err(N(p.grad), gp) <= 1e-4 and rel_err(N(t.grad), gt) <= 1e-4
 
 
+def test_silog_many_equals_single_calls(dev):
+    """Round 5: the nine SI-log losses of a step (train.py:813-815, 868-882) as one launch each way
+    (mvf_silog_many_fwd / _bwd): per job the bits of mvf_silog_fwd / _bwd, the total = the sum in job order;
+    predictions that are strided views of one interleaved tensor are read in place; a tensor used by two jobs gets
+    the sum of its two gradients."""
+    from mono_vifi_amd import ops
+    rng = np.random.default_rng(83)
+    B, H, W, G = 3, 40, 72, 4
+    base = T((0.1 + 50 * rng.random((B * G, 1, H, W))).astype(np.float32), dev, True)
+    views = torch.unbind(base.view(B, G, 1, H, W), 1)                     # strided: image stride G*H*W
+    tgt = [T((0.1 + 50 * rng.random((B, 1, H, W))).astype(np.float32), dev, True) for _ in range(2)]
+    mask = T((rng.random((B, 1, H, W)) > 0.3).astype(np.float32), dev)
+    jobs = [(views[0], tgt[0], None), (views[2], tgt[0], mask), (views[2], tgt[1], mask), (tgt[1], views[3], None)]
+    total, losses = ops.silog_many(jobs, 0.5)
+    (total * 1.25).backward()
+    got = (float(total.detach()), N(losses), N(base.grad), [N(t.grad) for t in tgt])
+    base2 = base.detach().clone().requires_grad_(True)
+    views2 = torch.unbind(base2.view(B, G, 1, H, W), 1)
+    tgt2 = [t.detach().clone().requires_grad_(True) for t in tgt]
+    sub = {id(views[k]): views2[k] for k in range(G)}
+    sub.update({id(tgt[k]): tgt2[k] for k in range(2)})
+    singles = [ops.silog_loss(sub[id(p)], sub[id(t)], m, 0.5) for p, t, m in jobs]
+    seq = np.float32(0.0)
+    for l in singles:
+        seq = np.float32(seq + np.float32(float(l.detach())))
+    (sum(singles) * 1.25).backward()
+    assert np.array_equal(got[1], np.array([float(l.detach()) for l in singles], np.float32))
+    assert np.float32(got[0]) == seq
+    assert rel_err(got[2], N(base2.grad)) <= 1e-6            # (two-job tensors: the order of the two adds may differ)
+    for a, b in zip(got[3], tgt2):
+        assert rel_err(a, N(b.grad)) <= 1e-6
+    # group 1 of the interleaved tensor is read by no job
+    assert float(base.grad.view(B, G, -1)[:, 1].abs().max()) == 0.0
+
+
+def test_affine_batched_forms_equal_single_calls(dev):
+    """Round 5: the two teacher frames of a step transformed by one launch (views per sample, train.py:832-833), the
+    three affine depth maps restored by one launch as the channels of one image (train.py:868-882), read in place out
+    of an interleaved decoder output: bit-identical to one call each, forward and adjoint."""
+    from mono_vifi_amd import ops
+    B, H, W, G = 4, 48, 80, 6
+    x, angle, box, ratio = affine_case(25, B, 3, H, W)
+    a, b, r = T(angle, dev), T(box, dev), T(ratio, dev)
+    x2 = T(np.random.default_rng(26).random((B, 3, H, W)).astype(np.float32), dev)
+    both = ops.affine_transform(torch.cat([T(x, dev), x2], 0), a, b)
+    assert torch.equal(both[:B], ops.affine_transform(T(x, dev), a, b))
+    assert torch.equal(both[B:], ops.affine_transform(x2, a, b))
+    rng = np.random.default_rng(27)
+    inter = T((0.1 + 20 * rng.random((B * G, 1, H, W))).astype(np.float32), dev, True)
+    views = torch.unbind(inter.view(B, G, 1, H, W), 1)
+    outs = ops.affine_restore_many(list(views[3:6]), a, b, r)
+    wts = [torch.randn(B, 1, H, W, device=dev) for _ in range(3)]
+    sum((o * w).sum() for o, w in zip(outs, wts)).backward()
+    inter2 = inter.detach().clone().requires_grad_(True)
+    views2 = torch.unbind(inter2.view(B, G, 1, H, W), 1)
+    outs2 = [ops.affine_restore(v, a, b, r) for v in views2[3:6]]
+    sum((o * w).sum() for o, w in zip(outs2, wts)).backward()
+    for o, o2 in zip(outs, outs2):
+        assert torch.equal(o, o2)
+    assert torch.equal(inter.grad, inter2.grad)
+    # maps that do not lie one plane apart are gathered first: same result
+    outs3 = ops.affine_restore_many([views[5].detach(), views[3].detach(), views[4].detach()], a, b, r)
+    assert torch.equal(outs3[0], outs2[2]) and torch.equal(outs3[1], outs2[0])
+
+
 # ------------------------------------------------------------------ f2: affine glue
 AFFINE_SHAPES = [(2, 3, 32, 64), (3, 1, 37, 101), (2, 2, 5, 7), (12, 3, 192, 640), (8, 1, 320, 1024)]
 
@@ -768,13 +833,14 @@ def fusion_bwd(request):
     """Backward route of the fused fusion levels: "gather" (deterministic inverse-tap-list gather,
     the default) or "scatter" (float atomics)."""
     from mono_vifi_amd import ops
-    old = ops.FUSION_BWD_GATHER
-    ops.FUSION_BWD_GATHER = request.param == "gather"
-    yield request.param
-    ops.FUSION_BWD_GATHER = old
+    old = ops.FUSION_BWD_GATHER, ops.FUSION_BWD_ANCHOR
+    ops.FUSION_BWD_GATHER = request.param != "scatter"
+    ops.FUSION_BWD_ANCHOR = request.param == "gather"       # "cells": the round-4 per-level cell lists
+    yield "gather" if request.param == "cells" else request.param
+    ops.FUSION_BWD_GATHER, ops.FUSION_BWD_ANCHOR = old
 
 
-BOTH_FUSION_BWD = pytest.mark.parametrize("fusion_bwd", ["gather", "scatter"], indirect=True)
+BOTH_FUSION_BWD = pytest.mark.parametrize("fusion_bwd", ["gather", "cells", "scatter"], indirect=True)
 
 
 @BOTH_FUSION_BWD
@@ -790,7 +856,7 @@ def test_fusion_levels_vs_golden(dev, case, fusion_bwd):
     tf = [[T(f, dev, True) for f in lvl] for lvl in feats]
     sizes = [tuple(f.shape[-2:]) for f in feats[1]]
     preps = ops.fusion_prep(T(flows[0], dev), T(flows[1], dev), T(mask, dev), sizes, lite)
-    outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i]) for i in range(L)]
+    outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i], lists=(preps.lists, i)) for i in range(L)]
     sum((o * T(g[f"weight_{i}"], dev)).sum() for i, o in enumerate(outs)).backward()
     en = O.embedding_flows(flows[0], L, lite)
     for i in range(L):
@@ -829,7 +895,7 @@ def test_fusion_levels_full_pyramids_vs_oracle(dev, pyr, fusion_bwd):
     tf = [[T(f, dev, True) for f in lvl] for lvl in feats]
     sizes = [tuple(f.shape[-2:]) for f in feats[1]]
     preps = ops.fusion_prep(T(flows[0], dev), T(flows[1], dev), T(mask, dev), sizes, lite)
-    outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i]) for i in range(len(chans))]
+    outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i], lists=(preps.lists, i)) for i in range(len(chans))]
     sum((o * T(wts[i], dev)).sum() for i, o in enumerate(outs)).backward()
     if fusion_bwd == "gather":       # bit-reproducible: a second backward gives the same bits
         tf2 = [[T(f, dev, True) for f in lvl] for lvl in feats]
