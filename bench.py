@@ -573,8 +573,9 @@ def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n, fb_pixels=
     if r_fb:
         px_launch = (fb_pixels / fb_n) if fb_pixels else px
         avg_s = fb_ms / fb_n / 1e3
-        survey = (FWD_BYTES_PER_PX + BWD_BYTES_PER_PX) * px_launch / avg_s / 1e9
-        r_fb["frac_survey_8d"] = round(survey / HBM_PEAK_GBS, 4)
+        # what bounds this kernel is VALU pipe time, not bandwidth: `frac` stays the fraction of the HBM
+        # peak on the algorithmic bytes (the contract's figure); valu_pipe_frac (below, flat) is the bound's own fraction
+        r_fb["bound"] = "valu"
         # this build's own extra traffic, NOT in `achieved`: the identity maps handed from the single-frame to
         # the multi-frame units (what the PMC traffic holds beyond the algorithmic bytes)
         r_fb["handover_bytes_per_px"] = round(hand_px, 2)
@@ -586,9 +587,7 @@ def kernel_rooflines(args, fwd_ms, fwd_n, bwd_ms, bwd_n, fb_ms, fb_n, fb_pixels=
             f"tie-break noise is a tensor, + {MASK_BYTES_PER_PX} B mask_rec on the affine units; a launch carries "
             "images_per_launch images (several units).  The 8 B/px identity maps a single-frame unit writes and "
             "its multi-frame partner reads are this build's own traffic (handover_bytes_*): in the PMC traffic, "
-            "not in `achieved` / `frac` (frac_incl_handover_bytes prices them too); frac_survey_8d prices the "
-            "same launch at SURVEY 8d's forward 44 + backward 45 B/px (the two kernels it replaces) for "
-            "comparison with round 1")
+            "not in `achieved` / `frac` (frac_incl_handover_bytes prices them too)")
     cands = [(ms, r) for ms, r in ((fwd_ms, r_fwd), (bwd_ms, r_bwd), (fb_ms, r_fb)) if r]
     dominant = max(cands, key=lambda t: t[0])[1] if cands else None
     return {"unit_fwd": r_fwd, "unit_bwd": r_bwd, "unit_fwdbwd": r_fb}, dominant
@@ -617,8 +616,37 @@ def unit_launch_types(args, nat, fb_bytes_px_base, noise_tensor):
                      "min_us": round(min(ms for ms, _ in sel) * 1e3, 2), "max_us": round(max(ms for ms, _ in sel) * 1e3, 2),
                      "bytes": int(round(bpp * px)), "bytes_per_px": bpp,
                      "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 4)}
-    return {"by_launch": out, "median_us": round(statistics.median(ms for ms, _, _ in recs) * 1e3, 2),
-            "launches_recorded": len(recs)}
+    res = {"by_launch": out, "median_us": round(statistics.median(ms for ms, _, _ in recs) * 1e3, 2),
+           "launches_recorded": len(recs)}
+    # flat scalars (the driver's parser keeps scalars only): per launch type the median, and the fraction of the VALU
+    # pipe -- sum over the executed instructions of their measured issue cost (tools/isa_cost.py on this kernel,
+    # profiles/r05_isa_cost.json) over the kernel's time: what a perfect schedule of this instruction stream could gain
+    cost = _isa_cost()
+    pipe_ns = tot_ns = 0.0
+    for name, v in out.items():
+        key = name.replace("+", "_")
+        res[f"median_us_{key}"] = v["median_us"]
+        if cost:
+            cpp = cost["cost_per_px"]
+            c = {"single_frame": cpp["single_frame"], "multi_frame": cpp["multi_frame"], "affine": cpp["affine"],
+                 "single_frame+affine": 0.5 * (cpp["single_frame"] + cpp["affine"])}[name]
+            px = v["bytes"] / v["bytes_per_px"]
+            ns = c * px / cost["wave"] / cost["simds"] * cost["plain_instruction_ns"]
+            res[f"valu_pipe_frac_{key}"] = round(ns / (v["median_us"] * 1e3), 3)
+            pipe_ns += ns * v["launches"]
+            tot_ns += v["median_us"] * 1e3 * v["launches"]
+    if tot_ns:
+        res["valu_pipe_frac"] = round(pipe_ns / tot_ns, 3)
+        res["valu_pipe_source"] = "profiles/r05_isa_cost.json (static, cost-weighted ISA of this kernel) / median launch time of this run"
+    return res
+
+
+def _isa_cost():
+    try:
+        with open(os.path.join(ROOT, "profiles", "r05_isa_cost.json")) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def glue_kernel_leg(step, nat, steps=3):
@@ -934,7 +962,12 @@ def pmc_leg(args, timeout_s=120):
             return None
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    px_launch = 3.0 * args.batch * args.height * args.width        # three units per launch
+    # the child hot-path run issues the step's nine units as two launches (six + three units): mean units per launch
+    per_launch = UNITS_PER_STEP / (3.0 if getattr(args, "no_merge_unit_groups", False) or getattr(args, "no_batch_units", False)
+                                   else 2.0)
+    if getattr(args, "no_batch_units", False):
+        per_launch = 1.0
+    px_launch = per_launch * args.batch * args.height * args.width
     quad = got["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0            # SQ counters tick in quad-cycles over 1,024 SIMDs
     return {"traffic": int(round(got["FETCH_SIZE"] * 1024 * 2 + got["WRITE_SIZE"] * 1024)),
             "valu": {"valu_busy": round(got["SQ_ACTIVE_INST_VALU"] / quad, 3),
@@ -1145,6 +1178,26 @@ def main():
             last = max([v.get("leg_seconds", 0) for v in other.values()] + [20.0])
             other[n] = other_config_leg(args, n, rank, world, dev, nat) if not over_budget(args, 1.2 * last) \
                 else {"skipped": "time budget"}
+        # the same configurations pinned to the CPUs one of eight ranks would get: BASELINE's
+        # 8-GPU configurations are exactly these, and their steps cost the host 1.6-1.8 CPUs unpinned
+        if rank == 0 and world == 1 and args.host_leg:
+            import copy
+            torch.cuda.empty_cache()
+            for n in names:
+                if n not in OTHER_CONFIGS or "ms_per_step" not in other.get(n, {}):
+                    continue
+                if over_budget(args, 40):
+                    other[n]["host_pinned"] = {"skipped": "time budget"}
+                    continue
+                a = copy.copy(args)
+                for k, v in OTHER_CONFIGS[n].items():
+                    setattr(a, k, v)
+                hp = host_leg(a, steps=args.also_steps)
+                other[n]["host_pinned"] = hp
+                e_ = (hp or {}).get("eager", {})
+                if e_.get("ms_per_step"):
+                    other[n]["pinned_eager_over_unpinned"] = round(e_["ms_per_step"] / other[n]["ms_per_step"], 3)
+                    other[n]["host_bound_with_8_ranks"] = bool(e_["ms_per_step"] > 1.05 * other[n]["ms_per_step"])
 
         class _Done:        # the headline's description outlives its trainer
             images_per_step = images_headline
@@ -1178,6 +1231,9 @@ def main():
             dominant["traffic"], dominant["valu"] = live["traffic"], live["valu"]
             dominant["static_source"] = None
             dominant["pmc_source"] = live["source"]
+            for k in ("valu_busy", "valu_instr_per_px", "wave_active", "wave_wait_memory_or_barrier", "wave_wait_issue"):
+                if isinstance(live.get("valu"), dict) and k in live["valu"]:
+                    dominant[k] = live["valu"][k]
             dominant["traffic_over_algorithmic"] = round(live["traffic"] / dominant["algorithmic_bytes_per_launch"], 3)
             dominant["traffic_over_algorithmic_plus_handover"] = round(
                 live["traffic"] / (dominant["algorithmic_bytes_per_launch"] + dominant.get("handover_bytes_per_launch", 0)), 3)
@@ -1197,7 +1253,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{workload}: " + (getattr(step, "describe", lambda: None)() or (
-                f"{UNITS_PER_STEP} units fwd+bwd (3 launches of 3 units, identity maps handed from the "
+                f"{UNITS_PER_STEP} units fwd+bwd ({'2 launches of 6 + 3 units' if not getattr(args, 'no_merge_unit_groups', False) else '3 launches of 3 units'}, identity maps handed from the "
                 f"single-frame to the multi-frame units), batch {args.batch}/GPU, "
                 f"{args.width}x{args.height}, 2 sources/unit, exact mode, {args.disp} disparity")),
                 "global_batch": args.batch * world, "parallelism": f"dp{world}"},
@@ -1229,6 +1285,18 @@ def main():
             out["comm"] = comm
         if hotpath_only:
             out["hotpath_only"] = hotpath_only
+            # driver-visible scalars of the hot path alone: ms per step of the 9 units forward +
+            # backward, eager, and its ratio to the sum of the unit launches inside it
+            if hotpath_only.get("ms_per_step"):
+                out["hotpath_ms_per_step"] = hotpath_only["ms_per_step"]
+                rf = hotpath_only.get("roofline") or {}
+                if rf.get("avg_us") and rf.get("launches") and hotpath_only.get("steps"):
+                    unit_ms = rf["avg_us"] * rf["launches"] / hotpath_only["steps"] / 1e3
+                    out["hotpath_unit_launches_ms_per_step"] = round(unit_ms, 4)
+                    out["hotpath_over_unit_launches"] = round(hotpath_only["ms_per_step"] / unit_ms, 3)
+                gr_ = hotpath_only.get("hip_graph_replay") or {}
+                if gr_.get("ms_per_step"):
+                    out["hotpath_graph_replay_ms_per_step"] = gr_["ms_per_step"]
         if graph_leg:
             out["hip_graph_step"] = graph_leg
         if other:

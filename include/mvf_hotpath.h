@@ -347,10 +347,10 @@ MVF_API int mvf_silog_bwd(const float *pred, const float *target, const float *m
                   const float *g_loss, float *g_pred, float *g_target, int B, int N, float beta,
                   void *stream);
 
-/* The SI-log losses of a step (train.py:813-815, 868-882: nine per step) as ONE forward and ONE backward launch.
+/* The SI-log losses of a step (train.py:813-815, 868-882: nine per step) as one partial + one finishing launch forward and ONE launch backward.
  * A job reads image b of pred / target / mask at base + b * stride (floats; 0 = N: contiguous), so the depth views of a
  * grouped decoder call are read in place.  losses [n_jobs], total [1] = their sum in job order, sums [n_jobs,B,4];
- * workspace: mvf_silog_many_workspace_floats(n_jobs, B) floats; tickets: n_jobs + 1 int32, ZERO on entry, left zero.
+ * workspace: mvf_silog_many_workspace_floats(n_jobs, B) floats; tickets: 1 int32, ZERO on entry, left zero.
  * Backward: upstream gradient of job j = *g_total (nullable) + g_losses[j] (nullable), g_pred / g_target [B,N]
  * contiguous, nullable per job.  Same arithmetic per job as mvf_silog_fwd / mvf_silog_bwd. */
 #define MVF_MAX_SILOG_JOBS 16

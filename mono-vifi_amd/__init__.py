@@ -73,6 +73,9 @@ def use_shipped_miopen_db():
     return dst
 
 
+_FLAG_STATE = {"late": False}      # True: the flag was asked for when the GPU context already existed
+
+
 def ensure_graph_replay_env(strict=False):
     """HIP graphs of a whole optimisation step: switch the HIP runtime's graph *packet capture* off.
 
@@ -87,13 +90,32 @@ def ensure_graph_replay_env(strict=False):
     undocumented debug switch of this ROCm release and changes how EVERY graph of the process replays,
     so it is set only where a whole-step graph was asked for: `bench.py --hip-graph`, `Trainer` with
     `--hip_graph` (`strict`: raise if the GPU context already exists without the flag)."""
+    import sys as _sys
+    torch = _sys.modules.get("torch")
+    gpu_up = torch is not None and torch.cuda.is_initialized()
     if _os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0":
+        # "0" only counts if the runtime can have READ it: inherited from the parent process, or written here before
+        # the GPU context existed (ADVICE r04: a late non-strict call used to write it after the first HIP call, and
+        # the strict check then trusted the environment)
+        if _FLAG_STATE["late"]:
+            if strict:
+                raise RuntimeError(
+                    "--hip_graph: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 was requested after this process had already "
+                    "touched the GPU, so the HIP runtime never read it (DESIGN.md section 7): ask for the graph step "
+                    "before the first HIP call, or export the variable")
+            return False
         return True
     if "DEBUG_CLR_GRAPH_PACKET_CAPTURE" in _os.environ and not strict:
         return False            # an explicit user setting wins
-    import sys as _sys
-    torch = _sys.modules.get("torch")
-    if strict and torch is not None and torch.cuda.is_initialized():
+    if gpu_up and not strict:
+        # too late for the runtime to see it: do not pretend.  Remember, so that a later strict call fails loudly
+        # instead of trusting a value written now.
+        _FLAG_STATE["late"] = True
+        import warnings
+        warnings.warn("hip_graph requested after the first HIP call: DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 cannot take "
+                      "effect in this process (the whole-step graph will refuse to run)")
+        return False
+    if strict and gpu_up:
         raise RuntimeError(
             "--hip_graph needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the first HIP call "
             "(the replay of a captured optimisation step faults with the HIP runtime's graph packet capture "

@@ -810,6 +810,8 @@ int mvf_fusion_lists_build(const float *const *preps, const float *const *xs, co
         v.blk0 = blk;
         blk += (int)((n + NT - 1) / NT);
     }
+    // (this build's own integer work: no algorithmic bytes, its time counts for the adjoint it serves)
+    ProfScope ps(MVF_PROF_FUSION_BWD_GATHER, stream, 0);
     hipError_t e = hipMemsetAsync(scratch, 0, so * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     const dim3 gp((unsigned)blk, (unsigned)B, 2);

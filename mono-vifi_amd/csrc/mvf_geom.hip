@@ -506,8 +506,8 @@ __global__ void __launch_bounds__(NT) k_silog_bwd(const float *__restrict__ pred
 // process_batch evaluates nine of them (train.py:813-815, 868-882), each on 12 images: nine partial + nine finishing
 // launches forward and nine backward, every one of them bound by its launch, not by its 6 MB.  Jobs: per-image base +
 // stride (the depth views of an interleaved decoder output are read where they lie).  Forward: blocks (chunk, image,
-// job) write partials, the last block of a job to arrive (ticket) folds its images in index order (fp64, the order of
-// k_silog_finish) into sums[job] and loss[job]; the last job adds the losses in job order into total[0].
+// job) write partials; one finishing block per job folds its images in index order (fp64, the order of
+// k_silog_finish) into sums[job] and loss[job]; the last job to finish adds the losses in job order into total[0].
 struct SilogJob {
     const float *pred, *target, *mask;
     size_t ps, ts, ms;                   // image strides (floats)
@@ -517,13 +517,9 @@ struct SilogJobs {
     SilogJob j[MVF_MAX_SILOG_JOBS];
     int n;
 };
-__global__ void __launch_bounds__(NT) k_silog_many_fwd(SilogJobs J, float *__restrict__ ws, float *__restrict__ sums,
-                                                       float *__restrict__ losses, float *__restrict__ total,
-                                                       int *__restrict__ tickets, int B, int N, float beta)
+__global__ void __launch_bounds__(NT) k_silog_many_partial(SilogJobs J, float *__restrict__ ws, int B, int N)
 {
     __shared__ float scratch[3 * (NT / 16)];
-    __shared__ int s_last;
-    __shared__ double acc[64];
     const int b = blockIdx.y, jb = blockIdx.z;
     const SilogJob &job = J.j[jb];
     const float *p = job.pred + (size_t)b * job.ps, *t = job.target + (size_t)b * job.ts;
@@ -537,47 +533,46 @@ __global__ void __launch_bounds__(NT) k_silog_many_fwd(SilogJobs J, float *__res
         v[2] += mk;
     }
     const float tot = block_sum_many<NT, 3>(v, scratch);
-    float *wj = ws + (size_t)jb * B * SIL_NB * 4;
-    if (threadIdx.x < 3) publish(wj + ((size_t)b * SIL_NB + blockIdx.x) * 4 + threadIdx.x, tot);
-    __syncthreads();                      // (lanes 0 .. 2 have issued their stores: the ticket waits for them)
-    if (threadIdx.x == 0) {
-        // s_waitcnt inside take_ticket covers only this lane's stores: lanes 1, 2 sit in the same wave, and a wave's
-        // stores complete in order with its counter
-        s_last = (take_ticket(tickets + jb) == SIL_NB * B - 1);
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // the job's last block: images folded as k_silog_finish folds them
+    if (threadIdx.x < 3) ws[(((size_t)jb * B + b) * SIL_NB + blockIdx.x) * 4 + threadIdx.x] = tot;
+}
+// block = job: its images folded as k_silog_finish folds them; the last job to arrive (n_jobs tickets in all) adds the
+// losses in job order.  (Folding by the last partial block of a job instead -- one launch -- was measured: 108 us, its
+// 768 tickets per job serialise on one address; two launches: 20 us.)
+__global__ void __launch_bounds__(64) k_silog_many_finish(const float *__restrict__ ws, float *__restrict__ sums,
+                                                          float *__restrict__ losses, float *__restrict__ total,
+                                                          int *__restrict__ tickets, int n_jobs, int B, float beta)
+{
+    __shared__ double acc[64];
+    const int jb = blockIdx.x;
+    const float *wj = ws + (size_t)jb * B * SIL_NB * 4;
     double lt = 0.0;
     for (int b0 = 0; b0 < B; b0 += 64) {
         const int bb = b0 + (int)threadIdx.x;
         double lb = 0.0;
-        if (threadIdx.x < 64 && bb < B) {
+        if (bb < B) {
             double s1 = 0.0, s2 = 0.0, n = 0.0;
             for (int k = 0; k < SIL_NB; ++k) {
                 const float *q = wj + ((size_t)bb * SIL_NB + k) * 4;
-                s1 += fetch_published(q); s2 += fetch_published(q + 1); n += fetch_published(q + 2);
+                s1 += q[0]; s2 += q[1]; n += q[2];
             }
             n += 1e-8;
             lb = s2 / n - (double)beta * s1 * s1 / (n * n);
             float *sj = sums + ((size_t)jb * B + bb) * 4;
             sj[0] = (float)s1; sj[1] = (float)s2; sj[2] = (float)n; sj[3] = 0.0f;
         }
-        if (threadIdx.x < 64) acc[threadIdx.x] = lb;
+        acc[threadIdx.x] = lb;
         __syncthreads();
         if (threadIdx.x == 0)
             for (int i = 0; i < 64; ++i) lt += acc[i];
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        const float lj = (float)(lt / (double)B);
-        publish(losses + jb, lj);
-        publish(tickets + jb, 0);
-        if (take_ticket(tickets + J.n) == J.n - 1) {
+        publish(losses + jb, (float)(lt / (double)B));
+        if (take_ticket(tickets) == n_jobs - 1) {
             float tt = 0.0f;
-            for (int k = 0; k < J.n; ++k) tt += fetch_published(losses + k);
+            for (int k = 0; k < n_jobs; ++k) tt += fetch_published(losses + k);
             total[0] = tt;
-            publish(tickets + J.n, 0);
+            publish(tickets, 0);
         }
     }
 }
@@ -1187,8 +1182,10 @@ int mvf_silog_many_fwd(const mvf_silog_job *jobs, int n_jobs, float *losses, flo
     int64_t bytes = 0;
     for (int i = 0; i < n_jobs; ++i) bytes += 4LL * B * N * (2 + (jobs[i].mask ? 1 : 0));
     ProfScope ps(MVF_PROF_SILOG_FWD, stream, bytes);
-    hipLaunchKernelGGL(k_silog_many_fwd, dim3(SIL_NB, (unsigned)B, (unsigned)n_jobs), dim3(NT), 0, (hipStream_t)stream, J,
-                       workspace, sums, losses, total, tickets, B, N, beta);
+    hipLaunchKernelGGL(k_silog_many_partial, dim3(SIL_NB, (unsigned)B, (unsigned)n_jobs), dim3(NT), 0, (hipStream_t)stream,
+                       J, workspace, B, N);
+    hipLaunchKernelGGL(k_silog_many_finish, dim3((unsigned)n_jobs), dim3(64), 0, (hipStream_t)stream, workspace, sums,
+                       losses, total, tickets, n_jobs, B, beta);
     return hip_check_launch();
 }
 

@@ -90,7 +90,7 @@ struct FbArgs {
     float *tab;           // [U][B] ImgTab: what a workgroup needs of its image besides the planes (k_units_prepare)
     int nunits, flags, B, H, W, tiles_x, tiles_y;
     int flags_int;        // bit 0: every image base / stride of the launch is 8-byte aligned (pair staging allowed)
-    uint32_t mg_tx, mg_ty;   // floor(2^32 / tiles_x) + 1, floor(2^32 / tiles_y) + 1 (0: divide): workgroup -> tile
+    uint32_t mg_tx, mg_ty;   // floor(2^32 / tiles_x) + 1, floor(2^32 / tiles_y) + 1 (0: one tile that way): workgroup -> tile
     float smoothness, min_disp, range, eps;
     float gpix, cxs, cys; // launch constants of the adjoint: 1 / (B N), smoothness / (B H (W-1)), smoothness / (B (H-1) W)
 };
@@ -121,10 +121,10 @@ MVF_DEV void load_pose_pair(const ImgTab &sh, int ka, int kb, f2 P2[12])
 #pragma unroll
     for (int i = 0; i < 12; ++i) P2[i] = mk2(sh.P[ka][i], sh.P[kb][i]);
 }
-// workgroup -> tile with the launcher's reciprocals (exact for n * d < 2^32, which the launcher checks; three
-// 32-bit integer divisions on the scalar unit -- a v_rcp round trip through a vector register each -- were the first
-// thing every wave of the launch did)
-MVF_DEV int div_magic(int n, int d, uint32_t mg) { return mg ? (int)__umulhi((uint32_t)n, mg) : n / d; }
+// workgroup -> tile with the launcher's reciprocals (mg = floor(2^32 / d) + 1: exact for n * d < 2^32, which the
+// launcher checks; mg == 0 stands for d == 1).  Three 32-bit integer divisions on the scalar unit -- a v_rcp round trip
+// through a vector register each -- were the first thing every wave of the launch did.
+MVF_DEV int div_magic(int n, uint32_t mg) { return mg ? (int)__umulhi((uint32_t)n, mg) : n; }
 MVF_DEV TileId tile_of_block_mg(int tiles_x, int tiles_y, int B, uint32_t mg_tx, uint32_t mg_ty)
 {
     const int total = tiles_x * tiles_y * B;
@@ -133,9 +133,9 @@ MVF_DEV TileId tile_of_block_mg(int tiles_x, int tiles_y, int B, uint32_t mg_tx,
     const int q = total >> 3, r = total & 7;
     const int vid = xcd * q + min(xcd, r) + slot;
     TileId t;
-    const int rest = div_magic(vid, tiles_x, mg_tx);
+    const int rest = div_magic(vid, mg_tx);
     t.bx = vid - rest * tiles_x;
-    t.b = div_magic(rest, tiles_y, mg_ty);
+    t.b = div_magic(rest, mg_ty);
     t.by = rest - t.b * tiles_y;
     return t;
 }
@@ -1488,8 +1488,9 @@ int mvf_units_fwdbwd(const mvf_unit_desc *units, int n_units, int S, int flags, 
         a.cxs = smoothness / (float)((double)B * H * (W - 1));
         a.cys = smoothness / (float)((double)B * (H - 1) * W);
         const uint64_t nmax = (uint64_t)ntiles * B * n_units;          // largest dividend of the tile decode
-        a.mg_tx = (nmax * (uint64_t)a.tiles_x < (1ull << 32) && a.tiles_x > 1) ? (uint32_t)((1ull << 32) / a.tiles_x) + 1u : 0u;
-        a.mg_ty = (nmax * (uint64_t)a.tiles_y < (1ull << 32) && a.tiles_y > 1) ? (uint32_t)((1ull << 32) / a.tiles_y) + 1u : 0u;
+        if (nmax * (uint64_t)max(a.tiles_x, a.tiles_y) >= (1ull << 32)) return (int)hipErrorInvalidValue;
+        a.mg_tx = a.tiles_x > 1 ? (uint32_t)((1ull << 32) / a.tiles_x) + 1u : 0u;
+        a.mg_ty = a.tiles_y > 1 ? (uint32_t)((1ull << 32) / a.tiles_y) + 1u : 0u;
     }
     a.loss_sum = units[0].loss_sum;
     a.loss_sum_in = units[0].loss_sum ? units[0].loss_sum_in : nullptr;

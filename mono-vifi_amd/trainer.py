@@ -281,6 +281,13 @@ class Trainer(HotPathLosses):
                         g["capturable"] = bool(graph_opt)
                         g["fused"] = True if fused_opt else None
                         g["foreach"] = None if fused_opt else (True if graph_opt else None)
+                        if not graph_opt:
+                            # a --hip_graph run stores the rate as a device tensor (its scheduler updates it inside
+                            # the capture); the eager update wants plain floats (torch's foreach adam()
+                            # rejects a tensor rate, the fused one would read it back every step)
+                            for k in ("lr", "initial_lr"):
+                                if torch.is_tensor(g.get(k)):
+                                    g[k] = float(g[k])
                     for st in self.model_optimizer.state.values():
                         if "step" in st:
                             st["step"] = torch.as_tensor(st["step"], dtype=torch.float32).to(
@@ -678,7 +685,14 @@ class Trainer(HotPathLosses):
             # inv_ex = torch.inverse (same LU, bit-identical result) WITHOUT its host-side singularity check: that check
             # reads a device flag and so drained the stream in the middle of every step's forward pass (measured:
             # 92 ms of the host's 120 ms forward enqueue spent waiting there; tools/host_audit.py, tools/inv_probe.py)
-            Rc_inv = inputs["Rc_inv"] if "Rc_inv" in inputs else torch.linalg.inv_ex(Rc).inverse
+            if "Rc_inv" in inputs:
+                Rc_inv = inputs["Rc_inv"]
+            else:
+                Rc_inv, info = torch.linalg.inv_ex(Rc)
+                # torch.inverse would have raised on a singular Rc; here the LU's status stays on the device and is
+                # folded into a flag the logging step reads when it synchronises anyway
+                bad = (info != 0).any()
+                self._singular_rc = bad if getattr(self, "_singular_rc", None) is None else (self._singular_rc | bad)
             srcs_a = [inputs[("color_affine", -1, 0)], inputs[("color_affine", 1, 0)]]
             mask_rec = inputs["valid_mask_rec"]
             for (pa, pb), tgt, disp_a in zip(((pose_0_n1, pose_0_p1), (pose_nt_n1, pose_nt_p1), (pose_pt_n1, pose_pt_p1)),
@@ -797,6 +811,11 @@ class Trainer(HotPathLosses):
 
     # ------------------------------------------------------------------ logging / ckpt
     def log_time(self, batch_idx, data_time, batch_time, loss):
+        if getattr(self, "_singular_rc", None) is not None:
+            bad, self._singular_rc = bool(self._singular_rc), None
+            if bad:
+                raise RuntimeError("a singular affine matrix Rc reached the affine branch since the last log "
+                                   "(torch.inverse would have raised at that step; train.py:820)")
         left = (self.num_total_steps - self.step) * batch_time if self.step > 1 else 0
         lr = float(self.model_optimizer.param_groups[0]["lr"])
         logging.info("epoch: %2d/%d | batch: %4d/%d | data time: %.4f | batch time: %.3f | loss: %.4f | "

@@ -88,3 +88,22 @@ def test_graph_packet_capture_is_switched_off_only_for_hip_graph():
             "print(json.dumps({'r': r, 'e': os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE']}))",
             {"DEBUG_CLR_GRAPH_PACKET_CAPTURE": "1"})
     assert d["r"] is False and d["e"] == "1"
+
+
+def test_graph_flag_requested_after_the_gpu_context_exists_is_refused():
+    """a non-strict request that arrives after the first HIP call must not write the variable (the runtime
+    has already read its absence), and the strict call of `Trainer(--hip_graph)` must then fail loudly instead of
+    trusting the environment.  The GPU context is simulated (no GPU here)."""
+    d = _py("import os, json, warnings, torch, mono_vifi_amd as m\n"
+            "torch.cuda.is_initialized = lambda: True\n"
+            "with warnings.catch_warnings(record=True) as w:\n"
+            "    warnings.simplefilter('always')\n"
+            "    r = m.ensure_graph_replay_env()\n"
+            "env_after = os.environ.get('DEBUG_CLR_GRAPH_PACKET_CAPTURE')\n"
+            "os.environ['DEBUG_CLR_GRAPH_PACKET_CAPTURE'] = '0'     # what the old code had done at this point\n"
+            "try:\n"
+            "    m.ensure_graph_replay_env(strict=True); strict = 'passed'\n"
+            "except RuntimeError as e:\n"
+            "    strict = 'raised'\n"
+            "print(json.dumps({'r': r, 'env_after': env_after, 'warned': len(w) > 0, 'strict': strict}))")
+    assert d == {"r": False, "env_after": None, "warned": True, "strict": "raised"}

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import affine_case, assert_grad_close, load_golden, rel_err
+from conftest import affine_case, assert_grad_close, load_golden, rel_err, rel_l2
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -291,12 +291,23 @@ def test_fullsize_unit_flag_sets(dev, name, unit_kernel):
         assert np.array_equal(am[sidx], g["auto_mask_s"])
         assert abs(am.mean() - float(g["auto_mask_mean"])) <= 1e-6
     gd = N(disp.grad)
-    # 1e-4 on the tensor; per element 2e-4 of the tensor max: under these flag sets the REFERENCE's own fp32
-    # evaluation order sits 1.2-1.3e-4 from the fp64-folding oracle at its worst of the 4,096 samples (measured:
-    # no_ssim 1.30e-4, avg 1.24e-4, noauto 1.25e-4; relative L2 2.0-3.1e-5), the training kernel 1.44e-4 -- as close
-    # to the reference as a second legitimate evaluation order gets
-    assert_grad_close(gd.reshape(n)[sidx], g["grad_disp_s"], TOL, "grad_disp vs reference (sampled)",
-                      max_tol=2e-4 if unit_kernel == "fwdbwd" else None)
+    # 1e-4 on the tensor (relative L2) and, for the training kernel, 1e-4 PER ELEMENT of the tensor max -- against the
+    # reference's fp32 samples AND against the same reference code evaluated in float64 (g4_f64_C2_*, the arbiter).
+    # Round 4 held this at 2e-4 and blamed the SSIM adjoint; the cause was the metric: `assert_grad_close` on 4,096
+    # SAMPLES divides by the largest SAMPLE (2-2.6 x smaller than the tensor's largest element under these flag sets),
+    # not by the tensor max the bar is stated in.  With the right denominator: kernel vs reference fp32 <= 5.7e-5, vs
+    # float64 <= 4.4e-5; the reference's own fp32 run is 3.0-8.7e-5 from its float64 self (worst samples: far pixels,
+    # depth 36-92 m, where grad_disp = -range depth^2 dL/d depth amplifies the rounding of a cancelling parallax term):
+    # profiles/r05_grad_error_report.txt, tools/grad_error_report.py.
+    d64 = load_golden("g4_f64_C2_" + name)
+    assert np.array_equal(d64["sample_idx"], sidx)
+    gmax = float(d64["grad_disp_max64"])
+    got_s = gd.reshape(n)[sidx].astype(np.float64)
+    assert rel_l2(got_s, g["grad_disp_s"]) <= TOL
+    per_elem = TOL if unit_kernel == "fwdbwd" else 10 * TOL
+    assert np.abs(got_s - g["grad_disp_s"]).max() <= per_elem * gmax, "vs reference fp32 (sampled), of the tensor max"
+    same_fn = ~d64["selection_differs_near"].astype(bool)      # (a flipped argmin in the fp64 run: another function)
+    assert np.abs(got_s - d64["grad_disp_s64"])[same_fn].max() <= per_elem * gmax, "vs reference float64 (sampled)"
     assert abs(np.linalg.norm(gd.astype(np.float64)) - float(g["grad_disp_norm"])) <= TOL * float(g["grad_disp_norm"])
     ref = O.unit(inp["disp"], inp["tgt"], inp["src"], g["T"], inp["K"], inp["inv_K"], noise_np, mask_np, flags,
                  want_grads=True)

@@ -265,7 +265,11 @@ def test_regroup_equals_stack_and_autograd_accumulation(tmp_path, fuse):
     levels = 5
     n_enc = 2 if fuse == "separate_all" else 1
     assert out[True][3] == (levels * n_enc, levels * n_enc) and out[False][3] == (0, 0)
-    assert out[True][0] == out[False][0] and out[True][1] == out[False][1]
+    # (the values entering the losses are copies in both routes; the two forward passes themselves are not
+    # bit-reproducible on this stack -- the SAME route run twice gives per-job SI-log losses that differ in the last
+    # bit, measured in round 5 with a probe that re-ran process_batch six times: MIOpen's kernels, not this build's -- so the losses are held to 1e-6)
+    assert abs(out[True][0] - out[False][0]) <= 1e-6 * abs(out[False][0])
+    assert abs(out[True][1] - out[False][1]) <= 1e-6 * abs(out[False][1])
     # the gradient of a pyramid group read by up to four consumers is ONE four-term sum here and three pairwise
     # accumulations there: different fp32 rounding, carried back through the encoder (measured 4.8e-5 relative L2)
     assert float((out[True][2] - out[False][2]).norm() / out[False][2].norm()) <= 2e-4
