@@ -471,6 +471,25 @@ MVF_API int mvf_up2cat_pad_fwd(const float *x, const float *skip, float *out, in
 /* adjoint: g_x [B,C1,h,w] and g_skip [B,C2,2h,2w] (either nullable), deterministic gathers; h, w >= 2 */
 MVF_API int mvf_up2cat_pad_bwd(const float *g_out, float *g_x, float *g_skip, int B, int C1, int C2, int h,
                        int w, void *stream);
+/* Round 5: the same two pad kernels with the PRODUCER's epilogue applied on load -- the input is a raw convolution
+ * output y [B,C,...] and the padded tensor holds ELU(y + bias[c]) (ConvBlock, layers.py:106-118, followed by the next
+ * Conv3x3's pad, layers.py:121-138, or by upsample + cat + pad, networks/monodepth2.py:84-90): the activated tensor
+ * is written once, already padded.  Backward: g_in = pad_adjoint(g_padded) * ELU'(interior of padded), g_bias[c] = its
+ * sum over batch and pixels (deterministic fold); for up2cat only the x part is activated, g_skip as before.
+ * Wide shapes only: mvf_pad_act_supported(H, W) of the PADDED operation's unpadded size (2h, 2w for up2cat) and
+ * 16-byte aligned bases; anything else returns hipErrorInvalidValue (the caller keeps the separate kernels).
+ * workspace: mvf_pad_act_workspace_floats(B, C, H, W) / mvf_up2cat_pad_act_workspace_floats(B, C1, h, w) floats. */
+MVF_API int mvf_pad_act_supported(int H, int W);
+MVF_API size_t mvf_pad_act_workspace_floats(int B, int C, int H, int W);
+MVF_API int mvf_reflect_pad1_act_fwd(const float *in, const float *bias, float *out, int B, int C, int H, int W,
+                             void *stream);
+MVF_API int mvf_reflect_pad1_act_bwd(const float *g_padded, const float *padded, float *g_in, float *g_bias,
+                             float *workspace, int B, int C, int H, int W, void *stream);
+MVF_API int mvf_up2cat_pad_act_fwd(const float *x, const float *bias, const float *skip, float *out, int B, int C1,
+                           int C2, int h, int w, void *stream);
+MVF_API size_t mvf_up2cat_pad_act_workspace_floats(int B, int C1, int h, int w);
+MVF_API int mvf_up2cat_pad_act_bwd(const float *g_padded, const float *padded, float *g_x, float *g_bias, float *g_skip,
+                           float *workspace, int B, int C1, int C2, int h, int w, void *stream);
 /* Disparity head (networks/monodepth2.py:93 followed by layers.py:16-25): disp = sigmoid(logit),
  * depth = 1/(min_disp + range*disp) (nullable), mean_partials (nullable) [B,32] = the per-image
  * partial sums of disp that mvf_unit_fwdbwd otherwise computes itself.  logit [B,N]. */

@@ -106,6 +106,13 @@ _SIGNATURES = {
     "mvf_units_ticket_ints": [_i, _i],
     "mvf_up2cat_pad_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_up2cat_pad_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvf_pad_act_supported": [_i, _i],
+    "mvf_pad_act_workspace_floats": [_i, _i, _i, _i],
+    "mvf_reflect_pad1_act_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_reflect_pad1_act_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "mvf_up2cat_pad_act_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "mvf_up2cat_pad_act_workspace_floats": [_i, _i, _i, _i],
+    "mvf_up2cat_pad_act_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "mvf_disp_head_fwd": [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp],
     "mvf_disp_head_bwd": [_vp, _vp, _vp, _vp, _i64, _f, _f, _vp],
     "mvf_disp_head_bwd_units": [_vp, _vp, _vp, _vp, _i, _i, _f, _f, _vp, _i, _vp],
@@ -175,7 +182,8 @@ PROF_FIRST_GLUE, PROF_COUNT = 7, 36         # ids >= 7: glue kernels, profile le
 TAG_NAMES = {0: "single_frame", 1: "multi_frame", 2: "affine", 3: "single_frame+affine"}
 _RESTYPE = {"mvf_error_string": C.c_char_p, "mvf_profile_name": C.c_char_p, "mvf_profile_read_launches": C.c_int64, "mvf_workspace_floats": C.c_size_t,
             "mvf_flow_warp_workspace_floats": C.c_size_t, "mvf_fusion_prep_floats": C.c_size_t, "mvf_fusion_bwd_workspace_ints": C.c_size_t,
-            "mvf_silog_many_workspace_floats": C.c_size_t, "mvf_fusion_lists_level_ints": C.c_size_t, "mvf_fusion_lists_scratch_ints": C.c_size_t,
+            "mvf_silog_many_workspace_floats": C.c_size_t, "mvf_pad_act_workspace_floats": C.c_size_t,
+            "mvf_up2cat_pad_act_workspace_floats": C.c_size_t, "mvf_fusion_lists_level_ints": C.c_size_t, "mvf_fusion_lists_scratch_ints": C.c_size_t,
             "mvf_color_jitter_workspace_floats": C.c_size_t, "mvf_bias_act_workspace_floats": C.c_size_t,
             "mvf_units_workspace_floats": C.c_size_t, "mvf_units_ticket_ints": C.c_size_t,
             "mvf_resize_bilinear_bwd_workspace_floats": C.c_size_t}

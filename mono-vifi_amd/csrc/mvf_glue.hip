@@ -265,6 +265,130 @@ __global__ void __launch_bounds__(NT) k_up2cat_pad_fwd_w4(const float *__restric
         if (c0 + k < C) pad_put4(out + ((size_t)b * C + c0 + k) * PP, y, x0, v[k], H, W);
 }
 
+// ---- round 5: the convolution epilogue inside its consumer ---------------------------------
+// In the depth decoder every ConvBlock output (networks/monodepth2.py:84-93, layers.py:106-118: conv + bias + ELU) is
+// read next by exactly one pad kernel (the next Conv3x3's ReflectionPad2d(1), or upsample + cat + pad).  The pad kernels
+// can apply `ELU(y + bias[c])` on load: the activated tensor is then written ONCE, already padded, instead of written
+// by an epilogue pass, read back and written again padded (16 -> 8 bytes per element forward).  Backward: the padded
+// tensor (saved by the convolution that consumes it anyway) holds the activated values in its interior, so one kernel
+// gathers the pad adjoint, multiplies by ELU'(out) = out > 0 ? 1 : out + 1 and forms the bias gradient's partial
+// sums (20 -> 12 bytes per element).  Wide form only (W % 4 == 0 ...): other shapes keep the separate kernels.
+MVF_DEV float4 bias_elu4(float4 v, float bz)
+{
+    v.x += bz; v.y += bz; v.z += bz; v.w += bz;
+    v.x = (v.x > 0.0f) ? v.x : expm1f(v.x);
+    v.y = (v.y > 0.0f) ? v.y : expm1f(v.y);
+    v.z = (v.z > 0.0f) ? v.z : expm1f(v.z);
+    v.w = (v.w > 0.0f) ? v.w : expm1f(v.w);
+    return v;
+}
+__global__ void __launch_bounds__(NT) k_pad1_act_fwd_w4(const float *__restrict__ in, const float *__restrict__ bias,
+                                                        float *__restrict__ out, int planes, int C, int H, int W)
+{
+    const int W4 = W >> 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W4) return;
+    const int y = i / W4, x0 = (i - y * W4) * 4;
+    const size_t PP = (size_t)(H + 2) * (W + 2), n = (size_t)H * W;
+    const int p0 = blockIdx.y * PADW_PL;
+    float4 v[PADW_PL];
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k) {
+        const int p = min(p0 + k, planes - 1);
+        v[k] = bias_elu4(*reinterpret_cast<const float4 *>(in + (size_t)p * n + (size_t)y * W + x0), bias[p % C]);
+    }
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k)
+        if (p0 + k < planes) pad_put4(out + (size_t)(p0 + k) * PP, y, x0, v[k], H, W);
+}
+// (the x2-upsampled part gets bias + ELU, the skip feature is copied)
+__global__ void __launch_bounds__(NT) k_up2cat_pad_act_fwd_w4(const float *__restrict__ x, const float *__restrict__ bias,
+                                                              const float *__restrict__ skip, float *__restrict__ out,
+                                                              int C1, int C2, int h, int w)
+{
+    const int H = 2 * h, W = 2 * w, W4 = W >> 2;
+    const int i = blockIdx.x * NT + threadIdx.x;
+    if (i >= H * W4) return;
+    const int y = i / W4, j = i - y * W4, x0 = 4 * j;
+    const int b = blockIdx.z, C = C1 + C2, c0 = blockIdx.y * PADW_PL;
+    const size_t PP = (size_t)(H + 2) * (W + 2), n1 = (size_t)h * w, n2 = (size_t)H * W;
+    float4 v[PADW_PL];
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k) {
+        const int c = min(c0 + k, C - 1);
+        if (c < C1) {
+            const float2 t = *reinterpret_cast<const float2 *>(x + ((size_t)b * C1 + c) * n1 + (size_t)(y >> 1) * w + 2 * j);
+            const float4 a = bias_elu4(make_float4(t.x, t.y, 0.0f, 0.0f), bias[c]);
+            v[k] = make_float4(a.x, a.x, a.y, a.y);
+        } else {
+            v[k] = *reinterpret_cast<const float4 *>(skip + ((size_t)b * C2 + (c - C1)) * n2 + (size_t)y * W + x0);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PADW_PL; ++k)
+        if (c0 + k < C) pad_put4(out + ((size_t)b * C + c0 + k) * PP, y, x0, v[k], H, W);
+}
+MVF_DEV float elu_grad(float g, float o) { return (o > 0.0f) ? g : g * (o + 1.0f); }
+// block (chunk, plane): up to 4 x 256 column quads of one plane, one shot; part[(n * chunks + chunk) * C + c]
+constexpr int PADA_U = 4;
+__global__ void __launch_bounds__(NT) k_pad1_act_bwd_w4(const float *__restrict__ g, const float *__restrict__ padded,
+                                                        float *__restrict__ gx, float *__restrict__ part, int C, int H, int W)
+{
+    __shared__ float scratch[NT / kWave];
+    const int W4 = W >> 2, per = H * W4;
+    const int plane = blockIdx.y, n = plane / C, c = plane - n * C;
+    const size_t PP = (size_t)(H + 2) * (W + 2);
+    const float *gp = g + (size_t)plane * PP, *op = padded + (size_t)plane * PP;
+    float *dst = gx + (size_t)plane * H * W;
+    float4 gv[PADA_U], ov[PADA_U];
+    int yy[PADA_U], xx[PADA_U];
+#pragma unroll
+    for (int k = 0; k < PADA_U; ++k) {
+        const int i = min((int)blockIdx.x * (NT * PADA_U) + k * NT + (int)threadIdx.x, per - 1);
+        yy[k] = i / W4; xx[k] = (i - yy[k] * W4) * 4;
+        gv[k] = pad_adj4(gp, yy[k], xx[k], H, W);
+        ov[k] = ldg4u(op + (size_t)(yy[k] + 1) * (W + 2) + xx[k] + 1);
+    }
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PADA_U; ++k) {
+        if ((int)blockIdx.x * (NT * PADA_U) + k * NT + (int)threadIdx.x >= per) continue;
+        const float4 t = make_float4(elu_grad(gv[k].x, ov[k].x), elu_grad(gv[k].y, ov[k].y), elu_grad(gv[k].z, ov[k].z),
+                                     elu_grad(gv[k].w, ov[k].w));
+        *reinterpret_cast<float4 *>(dst + (size_t)yy[k] * W + xx[k]) = t;
+        acc += (t.x + t.y) + (t.z + t.w);
+    }
+    const float r = block_sum<NT>(acc, scratch);
+    if (threadIdx.x == 0) part[((size_t)n * gridDim.x + blockIdx.x) * C + c] = r;
+}
+// g_x of the x2-upsampled, activated part: (sum over the 2 x 2 children of the pad adjoint) * ELU'(x_act), x_act read
+// from the padded tensor's interior (a child of the pixel); block (chunk, plane of B * C1)
+__global__ void __launch_bounds__(NT) k_up2cat_pad_act_bwd_x_w4(const float *__restrict__ g, const float *__restrict__ padded,
+                                                                float *__restrict__ g_x, float *__restrict__ part, int C1,
+                                                                int C, int h, int w)
+{
+    __shared__ float scratch[NT / kWave];
+    const int H = 2 * h, W = 2 * w, w2 = w >> 1, per = h * w2;
+    const int plane = blockIdx.y, b = plane / C1, c = plane - b * C1;
+    const size_t PP = (size_t)(H + 2) * (W + 2);
+    const float *gp = g + ((size_t)b * C + c) * PP, *op = padded + ((size_t)b * C + c) * PP;
+    float *dst = g_x + (size_t)plane * h * w;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int i = (int)blockIdx.x * (NT * 2) + k * NT + (int)threadIdx.x;
+        if (i >= per) continue;
+        const int Y = i / w2, j = i - Y * w2;
+        const float4 a = pad_adj4(gp, 2 * Y, 4 * j, H, W), bq = pad_adj4(gp, 2 * Y + 1, 4 * j, H, W);
+        const float4 o = ldg4u(op + (size_t)(2 * Y + 1) * (W + 2) + 4 * j + 1);
+        const float2 t = make_float2(elu_grad((a.x + a.y) + (bq.x + bq.y), o.x), elu_grad((a.z + a.w) + (bq.z + bq.w), o.z));
+        *reinterpret_cast<float2 *>(dst + (size_t)Y * w + 2 * j) = t;
+        acc += t.x + t.y;
+    }
+    const float r = block_sum<NT>(acc, scratch);
+    if (threadIdx.x == 0) part[((size_t)b * gridDim.x + blockIdx.x) * C1 + c] = r;
+}
+
 static bool pad_wide_ok(const void *padded, const void *plain, int H, int W)
 {
     return (W & 3) == 0 && W >= 8 && H >= 4 && (((uintptr_t)plain) & 15) == 0 && (((uintptr_t)padded) & 3) == 0 &&
@@ -1600,6 +1724,93 @@ int mvf_up2cat_pad_bwd(const float *g_out, float *g_x, float *g_skip, int B, int
         else
         hipLaunchKernelGGL(k_up2cat_pad_bwd_skip, dim3((unsigned)((4 * h * w + NT - 1) / NT), (unsigned)((C2 + PL - 1) / PL), (unsigned)B),
                            dim3(NT), 0, (hipStream_t)stream, g_out, g_skip, C1, C2, h, w);
+    }
+    return hip_check_launch();
+}
+
+// ---- pad kernels with the producer's bias + ELU applied on load (see k_pad1_act_fwd_w4) ------------------------
+int mvf_pad_act_supported(int H, int W) { return ((W & 3) == 0 && W >= 8 && H >= 4 && !getenv("MVF_PAD_NARROW")) ? 1 : 0; }
+
+size_t mvf_pad_act_workspace_floats(int B, int C, int H, int W)
+{
+    const int chunks = (H * (W / 4) + NT * PADA_U - 1) / (NT * PADA_U);
+    return (size_t)B * (chunks > 0 ? chunks : 1) * C + 16;
+}
+
+int mvf_reflect_pad1_act_fwd(const float *in, const float *bias, float *out, int B, int C, int H, int W, void *stream)
+{
+    if (B <= 0 || C <= 0) return 0;
+    const int64_t planes = (int64_t)B * C;
+    if (!in || !bias || !out || !pad_wide_ok(out, in, H, W) || planes > 65535LL * PADW_PL) return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_REFLECT_PAD_FWD, stream, 4LL * planes * ((int64_t)H * W + (int64_t)(H + 2) * (W + 2)));
+    hipLaunchKernelGGL(k_pad1_act_fwd_w4, dim3((unsigned)((H * (W / 4) + NT - 1) / NT), (unsigned)((planes + PADW_PL - 1) / PADW_PL)),
+                       dim3(NT), 0, (hipStream_t)stream, in, bias, out, (int)planes, C, H, W);
+    return hip_check_launch();
+}
+
+int mvf_reflect_pad1_act_bwd(const float *g_padded, const float *padded, float *g_in, float *g_bias, float *workspace,
+                             int B, int C, int H, int W, void *stream)
+{
+    if (B <= 0 || C <= 0) return 0;
+    const int64_t planes = (int64_t)B * C;
+    if (!g_padded || !padded || !g_in || !g_bias || !workspace || !pad_wide_ok(g_padded, g_in, H, W) ||
+        (((uintptr_t)padded) & 3) || planes > 65535)
+        return (int)hipErrorInvalidValue;
+    const int chunks = (H * (W / 4) + NT * PADA_U - 1) / (NT * PADA_U);
+    // padded gradient and padded activations read once, the input gradient written once
+    ProfScope ps(MVF_PROF_REFLECT_PAD_BWD, stream, 4LL * planes * (2LL * (H + 2) * (W + 2) + (int64_t)H * W));
+    hipLaunchKernelGGL(k_pad1_act_bwd_w4, dim3((unsigned)chunks, (unsigned)planes), dim3(NT), 0, (hipStream_t)stream, g_padded,
+                       padded, g_in, workspace, C, H, W);
+    hipLaunchKernelGGL(k_bias_grad_finish_tree, dim3((unsigned)C), dim3(NT), 0, (hipStream_t)stream, workspace, g_bias, C,
+                       B * chunks);
+    return hip_check_launch();
+}
+
+int mvf_up2cat_pad_act_fwd(const float *x, const float *bias, const float *skip, float *out, int B, int C1, int C2, int h,
+                           int w, void *stream)
+{
+    if (B <= 0 || C1 <= 0 || h <= 0 || w <= 0) return 0;
+    const int C = C1 + C2, n = (2 * h + 2) * (2 * w + 2);
+    if (!x || !bias || !out || C2 < 0 || (C2 > 0 && !skip) || !pad_wide_ok(out, C2 > 0 ? skip : x, 2 * h, 2 * w) ||
+        (((uintptr_t)x) & 7) || (C + PADW_PL - 1) / PADW_PL > 65535 || B > 65535)
+        return (int)hipErrorInvalidValue;
+    ProfScope ps(MVF_PROF_UP2CAT_FWD, stream, 4LL * B * ((int64_t)C1 * h * w + (int64_t)C2 * 4 * h * w + (int64_t)C * n));
+    hipLaunchKernelGGL(k_up2cat_pad_act_fwd_w4, dim3((unsigned)((2 * h * (2 * w / 4) + NT - 1) / NT), (unsigned)((C + PADW_PL - 1) / PADW_PL), (unsigned)B),
+                       dim3(NT), 0, (hipStream_t)stream, x, bias, skip, out, C1, C2, h, w);
+    return hip_check_launch();
+}
+
+size_t mvf_up2cat_pad_act_workspace_floats(int B, int C1, int h, int w)
+{
+    const int chunks = (h * (w / 2) + NT * 2 - 1) / (NT * 2);
+    return (size_t)B * (chunks > 0 ? chunks : 1) * C1 + 16;
+}
+
+int mvf_up2cat_pad_act_bwd(const float *g_padded, const float *padded, float *g_x, float *g_bias, float *g_skip,
+                           float *workspace, int B, int C1, int C2, int h, int w, void *stream)
+{
+    if (B <= 0 || C1 <= 0 || h <= 0 || w <= 0) return 0;
+    if (!g_padded || !padded || !g_x || !g_bias || !workspace || C2 < 0 || h < 2 || w < 2 ||
+        !pad_wide_ok(g_padded, g_x, 2 * h, 2 * w) || (((uintptr_t)g_x) & 7) || (((uintptr_t)padded) & 3) ||
+        (int64_t)B * C1 > 65535)
+        return (int)hipErrorInvalidValue;
+    const int64_t PPb = (int64_t)(2 * h + 2) * (2 * w + 2);
+    {
+        const int chunks = (h * (w / 2) + NT * 2 - 1) / (NT * 2);
+        ProfScope ps(MVF_PROF_UP2CAT_BWD_X, stream, 4LL * B * C1 * (PPb + (int64_t)h * w + (int64_t)h * w));
+        hipLaunchKernelGGL(k_up2cat_pad_act_bwd_x_w4, dim3((unsigned)chunks, (unsigned)(B * C1)), dim3(NT), 0, (hipStream_t)stream,
+                           g_padded, padded, g_x, workspace, C1, C1 + C2, h, w);
+        hipLaunchKernelGGL(k_bias_grad_finish_tree, dim3((unsigned)C1), dim3(NT), 0, (hipStream_t)stream, workspace, g_bias,
+                           C1, B * chunks);
+    }
+    if (g_skip && C2 > 0) {
+        ProfScope ps(MVF_PROF_UP2CAT_BWD_SKIP, stream, 4LL * B * C2 * (PPb + 4LL * h * w));
+        if (pad_wide_ok(g_padded, g_skip, 2 * h, 2 * w) && (int64_t)B * C2 <= 65535LL * PADW_PL)
+            hipLaunchKernelGGL(k_pad1_bwd_w4, dim3((unsigned)((2 * h * (2 * w / 4) + NT - 1) / NT), (unsigned)((B * C2 + PADW_PL - 1) / PADW_PL)),
+                               dim3(NT), 0, (hipStream_t)stream, g_padded, g_skip, B * C2, C2, C1 + C2, C1, 2 * h, 2 * w);
+        else
+            hipLaunchKernelGGL(k_up2cat_pad_bwd_skip, dim3((unsigned)((4 * h * w + NT - 1) / NT), (unsigned)((C2 + PL - 1) / PL), (unsigned)B),
+                               dim3(NT), 0, (hipStream_t)stream, g_padded, g_skip, C1, C2, h, w);
     }
     return hip_check_launch();
 }

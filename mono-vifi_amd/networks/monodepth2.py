@@ -6,9 +6,12 @@ API and state-dict keys follow reference networks/monodepth2.py (``DepthEncoder`
 dispconv(s).  Plain PyTorch-ROCm modules: the convolutions are MIOpen / hipBLASLt GEMMs
 (MFMA for the genuine dense contractions); nothing here is hand-written.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ..layers import Conv3x3, ConvBlock, conv_bias_act, upsample
 from .resnet import ResNetTrunk, pyramid_features
@@ -17,6 +20,9 @@ from .resnet import ResNetTrunk, pyramid_features
 # decoder stage is one kernel (ops.up2cat_pad) and sigmoid + disp_to_depth one epilogue
 # (ops.disp_head); False = the stock op-by-op form (also what CPU tensors take).
 FUSED_GLUE = True
+# the ConvBlocks' bias + ELU applied by the pad kernel of their consumer (ops.reflect_pad1_act / up2cat_pad_act) instead of
+# by an epilogue pass of their own; "0" = the round-4 form (developer knob for the same-box A/B)
+FUSE_EPILOGUE_INTO_PAD = os.environ.get("MVF_PAD_EPILOGUE", "1") != "0"
 
 
 class DepthEncoder(nn.Module):
@@ -68,19 +74,70 @@ class DepthDecoder(nn.Module):
         fused = FUSED_GLUE and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()
         if fused:
             from .. import ops
+        # Round 5: a ConvBlock's bias + ELU is applied by the pad kernel of its (single) consumer: `pend` = (raw
+        # convolution output, bias) of the block whose epilogue is still owed.  Shapes the fused pad kernels do not
+        # take (W % 4, tiny planes) and every other consumer get the materialised tensor (`settle`).
+        from .. import layers as _layers
+        defer = fused and FUSE_EPILOGUE_INTO_PAD and _layers.FUSED_EPILOGUE and x.is_contiguous() and \
+            all(f.is_contiguous() for f in input_features)
+        pend = None
+
+        def settle(p):
+            return ops.bias_act(p[0], p[1], "elu", None, None, inplace=True)
+
+        def raw_conv(conv, xp):
+            return F.conv2d(xp, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
         for i in range(4, -1, -1):
-            x = self._blk("upconv", i, 0)(x)
+            blk0 = self._blk("upconv", i, 0)
+            if defer:
+                # ---- upconv(i, 0): pad (+ the previous block's epilogue) -> conv, epilogue deferred
+                c0 = blk0.conv.conv
+                if pend is not None and ops.pad_act_ok(pend[0], *pend[0].shape[-2:]):
+                    xp = ops.reflect_pad1_act(pend[0], pend[1])
+                else:
+                    xp = ops.reflect_pad1(settle(pend) if pend is not None else x)
+                pend = (raw_conv(c0, xp), c0.bias)
+            else:
+                x = blk0(x)
             skip = input_features[i - 1] if (self.use_skips and i > 0) else None
             blk = self._blk("upconv", i, 1)
-            if fused and x.shape[-1] >= 2 and x.shape[-2] >= 2:
+            if defer:
+                y, b = pend
+                if y.shape[-1] >= 2 and y.shape[-2] >= 2 and ops.pad_act_ok(y, 2 * y.shape[-2], 2 * y.shape[-1]) and \
+                        (skip is None or (skip.is_contiguous() and skip.data_ptr() % 16 == 0)):
+                    xp = ops.up2cat_pad_act(y, b, skip)
+                elif y.shape[-1] >= 2 and y.shape[-2] >= 2:
+                    xp = ops.up2cat_pad(settle(pend), skip)
+                else:
+                    xp = None
+                if xp is not None:
+                    pend = (raw_conv(blk.conv.conv, xp), blk.conv.conv.bias)
+                else:
+                    x = upsample(settle(pend))
+                    if skip is not None:
+                        x = torch.cat([x, skip], 1)
+                    c1 = blk.conv.conv
+                    pend = (raw_conv(c1, ops.reflect_pad1(x)), c1.bias)
+            elif fused and x.shape[-1] >= 2 and x.shape[-2] >= 2:
                 x = conv_bias_act(blk.conv.conv, ops.up2cat_pad(x, skip), "elu")
             else:
                 x = upsample(x)
                 if skip is not None:
                     x = torch.cat([x, skip], 1)
                 x = blk(x)
+            if defer and i in self.scales:
+                # the disparity convolution's pad takes the epilogue too (the block has a second consumer, the next
+                # level, only for i > 0: it re-applies the epilogue on its own load)
+                dc = self._blk("dispconv", i).conv
+                if ops.pad_act_ok(pend[0], *pend[0].shape[-2:]):
+                    xp = ops.reflect_pad1_act(pend[0], pend[1])
+                else:
+                    if i > 0:
+                        pend = (pend[0].clone(), pend[1])      # (settle works in place; the next level still needs y)
+                    xp = ops.reflect_pad1(settle(pend))
+                x_logit = ops.bias_act(raw_conv(dc, xp), dc.bias, "none", None, None, inplace=True)
             if i in self.scales:
-                logit = self._blk("dispconv", i)(x)
+                logit = x_logit if defer else self._blk("dispconv", i)(x)
                 if fused and self.num_output_channels == 1:
                     disp, depth, part, sink = ops.disp_head(logit, min_depth, max_depth, want_depth=(i == 0),
                                                             want_sink=True)

@@ -1298,6 +1298,84 @@ class HeadSink:
         return first, step
 
 
+def pad_act_ok(x_like, H, W):
+    """The fused pad + bias + ELU kernels take wide shapes only (W % 4 == 0, W >= 8, H >= 4, 16-byte aligned)."""
+    return bool(x_like.is_cuda and x_like.dtype == torch.float32 and x_like.is_contiguous() and
+                x_like.data_ptr() % 16 == 0 and nat.lib().mvf_pad_act_supported(int(H), int(W)))
+
+
+class ReflectPad1Act(torch.autograd.Function):
+    """ReflectionPad2d(1)(ELU(y + bias)) for a raw convolution output y: the ConvBlock epilogue (layers.py:106-118)
+    applied inside the next Conv3x3's pad kernel (layers.py:121-138).  Backward: pad adjoint, ELU' from the padded
+    tensor's interior and the bias gradient in one kernel."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        nat.require_device(y, bias)
+        y, bias = _c(y), _c(bias)
+        B, C, H, W = y.shape
+        out = torch.empty((B, C, H + 2, W + 2), dtype=torch.float32, device=y.device)
+        nat.check(nat.lib().mvf_reflect_pad1_act_fwd(nat.ptr(y), nat.ptr(bias), nat.ptr(out), B, C, H, W, _stream()),
+                  "reflect_pad1_act_fwd")
+        ctx.save_for_backward(out)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (padded,) = ctx.saved_tensors
+        g = _c(g)
+        B, C, Hp, Wp = g.shape
+        H, W = Hp - 2, Wp - 2
+        gy = torch.empty((B, C, H, W), dtype=torch.float32, device=g.device)
+        gb = torch.empty(C, dtype=torch.float32, device=g.device)
+        ws = torch.empty(nat.lib().mvf_pad_act_workspace_floats(B, C, H, W), dtype=torch.float32, device=g.device)
+        nat.check(nat.lib().mvf_reflect_pad1_act_bwd(nat.ptr(g), nat.ptr(padded), nat.ptr(gy), nat.ptr(gb), nat.ptr(ws),
+                                                     B, C, H, W, _stream()), "reflect_pad1_act_bwd")
+        return gy, gb
+
+
+class Up2CatPadAct(torch.autograd.Function):
+    """ReflectionPad2d(1)(cat([upsample_nearest_x2(ELU(y + bias)), skip], 1)) for a raw convolution output y
+    (networks/monodepth2.py:84-90 after the ConvBlock of layers.py:106-118)."""
+
+    @staticmethod
+    def forward(ctx, y, bias, skip):
+        nat.require_device(y, bias, skip)
+        y, bias, skip = _c(y), _c(bias), _c(skip)
+        B, C1, h, w = y.shape
+        C2 = skip.shape[1] if skip is not None else 0
+        if skip is not None and tuple(skip.shape) != (B, C2, 2 * h, 2 * w):
+            raise RuntimeError("up2cat_pad: skip must be [B,C2,2h,2w]")
+        out = torch.empty((B, C1 + C2, 2 * h + 2, 2 * w + 2), dtype=torch.float32, device=y.device)
+        nat.check(nat.lib().mvf_up2cat_pad_act_fwd(nat.ptr(y), nat.ptr(bias), nat.ptr(skip), nat.ptr(out), B, C1, C2, h, w,
+                                                   _stream()), "up2cat_pad_act_fwd")
+        ctx.save_for_backward(out)
+        ctx.dims = (B, C1, C2, h, w)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (padded,) = ctx.saved_tensors
+        B, C1, C2, h, w = ctx.dims
+        g = _c(g)
+        dev = g.device
+        gy = torch.empty((B, C1, h, w), dtype=torch.float32, device=dev)
+        gb = torch.empty(C1, dtype=torch.float32, device=dev)
+        gs = torch.empty((B, C2, 2 * h, 2 * w), dtype=torch.float32, device=dev) if (C2 and ctx.needs_input_grad[2]) else None
+        ws = torch.empty(nat.lib().mvf_up2cat_pad_act_workspace_floats(B, C1, h, w), dtype=torch.float32, device=dev)
+        nat.check(nat.lib().mvf_up2cat_pad_act_bwd(nat.ptr(g), nat.ptr(padded), nat.ptr(gy), nat.ptr(gb), nat.ptr(gs),
+                                                   nat.ptr(ws), B, C1, C2, h, w, _stream()), "up2cat_pad_act_bwd")
+        return gy, gb, gs
+
+
+def reflect_pad1_act(y, bias):
+    return ReflectPad1Act.apply(y, bias)
+
+
+def up2cat_pad_act(y, bias, skip=None):
+    return Up2CatPadAct.apply(y, bias, skip)
+
+
 class DispHead(torch.autograd.Function):
     """sigmoid (networks/monodepth2.py:93) fused with disp_to_depth (layers.py:16-25):
     logit [B,1,H,W] -> disp, depth (or None), per-image mean partials of disp [B,32] for the unit

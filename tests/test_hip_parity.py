@@ -1499,3 +1499,57 @@ def test_sum_act_equals_term_at_a_time(shape, n):
     for t in (ts[1:] or [ts[0]]):
         acc = t if acc is None else acc + t
     assert torch.equal(torch.nan_to_num(lin, nan=7.0), torch.nan_to_num(acc, nan=7.0))
+
+
+def test_decoder_epilogue_inside_the_pad_kernels(dev):
+    """Round 5: a ConvBlock's bias + ELU applied by the pad kernel of its consumer
+    (mvf_reflect_pad1_act_*, mvf_up2cat_pad_act_*; networks/monodepth2.py:84-93, layers.py:106-138) against the round-4
+    form (epilogue pass, then pad): identical forward bits (same operations), input / weight gradients within the
+    rounding of the bias-gradient folds; the ops alone against stock torch ops."""
+    import torch.nn.functional as F
+    from mono_vifi_amd import ops
+    from mono_vifi_amd.networks import monodepth2
+    torch.manual_seed(5)
+    # the ops alone
+    y = torch.randn(3, 6, 12, 20, device=dev, requires_grad=True)
+    b = torch.randn(6, device=dev, requires_grad=True)
+    skip = torch.randn(3, 5, 24, 40, device=dev, requires_grad=True)
+    y2, b2, s2 = (t.detach().clone().requires_grad_(True) for t in (y, b, skip))
+    got = ops.reflect_pad1_act(y, b)
+    want = F.pad(F.elu(y2 + b2.view(1, -1, 1, 1)), (1, 1, 1, 1), mode="reflect")
+    assert torch.equal(got, want)
+    w = torch.randn_like(got)
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    assert float((y.grad - y2.grad).abs().max()) <= 1e-6 * float(y2.grad.abs().max())
+    assert float((b.grad - b2.grad).abs().max()) <= 1e-5 * float(b2.grad.abs().max())
+    for t in (y, b, y2, b2):
+        t.grad = None
+    got = ops.up2cat_pad_act(y, b, skip)
+    want = F.pad(torch.cat([F.interpolate(F.elu(y2 + b2.view(1, -1, 1, 1)), scale_factor=2, mode="nearest"), s2], 1),
+                 (1, 1, 1, 1), mode="reflect")
+    assert torch.equal(got, want)
+    w = torch.randn_like(got)
+    (got * w).sum().backward()
+    (want * w).sum().backward()
+    assert float((y.grad - y2.grad).abs().max()) <= 1e-6 * float(y2.grad.abs().max())
+    assert float((b.grad - b2.grad).abs().max()) <= 1e-5 * float(b2.grad.abs().max())
+    assert float((skip.grad - s2.grad).abs().max()) <= 1e-6 * float(s2.grad.abs().max())    # (ATen's pad adjoint adds in another order)
+    # the decoder, both forms
+    dec = monodepth2.DepthDecoder([64, 64, 128, 256, 512], range(1)).to(dev)
+    feats = [torch.randn(2, c, 96 >> i, 160 >> i, device=dev) for i, c in enumerate([64, 64, 128, 256, 512])]
+    res = {}
+    for flag in (True, False):
+        monodepth2.FUSE_EPILOGUE_INTO_PAD = flag
+        try:
+            fs = [f.clone().requires_grad_(True) for f in feats]
+            dec.zero_grad()
+            out = dec(fs, 0.1, 100.0)
+            (out[("disp", 0)] * torch.linspace(0, 1, 192 * 320, device=dev).view(1, 1, 192, 320)).sum().backward()
+            res[flag] = (out[("disp", 0)].detach().clone(), [f.grad.clone() for f in fs],
+                         [p.grad.clone() for p in dec.parameters()])
+        finally:
+            monodepth2.FUSE_EPILOGUE_INTO_PAD = True
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b_ in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+        assert float((a - b_).norm()) <= 1e-5 * float(b_.norm())
