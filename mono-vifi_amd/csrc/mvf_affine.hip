@@ -137,6 +137,42 @@ __global__ void __launch_bounds__(NT) k_affine_transform(const float *__restrict
         z[q] = ztap_of(px, py);
     }
     const size_t N = (size_t)H * W;
+    // Round 5: a pixel whose four rotate-tap sets all lie inside the image (everywhere but a thin border for the
+    // +-5 degree rotations of the augmentation) takes its 16 taps as eight unconditional 8-byte row pairs per channel,
+    // weights formed once -- sample_zeros' sixteen predicated 4-byte loads per channel were the kernel's cost
+    // (50 us for 17.7 MB).  Same products, same left-to-right sums (0 + a == a): the same bits.
+    bool inner = true;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) inner = inner && z[q].x0 >= 0 && z[q].x0 + 1 < W && z[q].y0 >= 0 && z[q].y0 + 1 < H;
+    if (inner) {
+        float w4[4][4];
+        unsigned o0[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w4[q][0] = (1.0f - z[q].lx) * (1.0f - z[q].ly);
+            w4[q][1] = z[q].lx * (1.0f - z[q].ly);
+            w4[q][2] = (1.0f - z[q].lx) * z[q].ly;
+            w4[q][3] = z[q].lx * z[q].ly;
+            o0[q] = (unsigned)(z[q].y0 * W + z[q].x0) * 4u;
+        }
+        const unsigned W4b = (unsigned)W * 4u;
+        for (int c = 0; c < C; ++c) {
+            const float *im = img + ((size_t)b * C + c) * N;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float2 r0 = ldg2_at(im, o0[q]), r1 = ldg2_at(im, o0[q] + W4b);
+                float a = r0.x * w4[q][0];
+                a += r0.y * w4[q][1];
+                a += r1.x * w4[q][2];
+                a += r1.y * w4[q][3];
+                v[q] = a;
+            }
+            out[((size_t)b * C + c) * N + (size_t)y * W + x] =
+                (1.0f - ry.l) * ((1.0f - rx.l) * v[0] + rx.l * v[1]) + ry.l * ((1.0f - rx.l) * v[2] + rx.l * v[3]);
+        }
+        return;
+    }
     for (int c = 0; c < C; ++c) {
         const float *im = img + ((size_t)b * C + c) * N;
         float v00 = sample_zeros(im, H, W, z[0]), v01 = sample_zeros(im, H, W, z[1]);

@@ -39,10 +39,10 @@ else
     n=$(basename $d | sed s/var_//); export MVF_HOTPATH_LIB=$d/libmvf_hotpath.so
     par=""
     if [ -n "$3" ]; then par=$(cd $R && python -m pytest tests/test_hip_parity.py -q -x -k "$3" 2>&1 | tail -1 | tr ',' ';'); fi
-    us=$(python $R/bench.py --workload hotpath --steps 20 --warmup 5 --no-cpu-baseline --no-replay-leg 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['kernels']['unit_fwdbwd']['avg_us'])")
+    us=$(python $R/bench.py --workload hotpath --steps 20 --warmup 5 --no-cpu-baseline --no-replay-leg $VBENCH 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['kernels']['unit_fwdbwd']['avg_us'])")
     rm -rf $O/pmc_$n
     rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-      --kernel-trace --output-format csv -d $O/pmc_$n -- python $R/bench.py --workload hotpath --steps 4 --warmup 2 --no-cpu-baseline --no-replay-leg > /dev/null 2>&1 || true
+      --kernel-trace --output-format csv -d $O/pmc_$n -- python $R/bench.py --workload hotpath --steps 4 --warmup 2 --no-cpu-baseline --no-replay-leg $VBENCH > /dev/null 2>&1 || true
     python - "$O/pmc_$n" "$n" "$(cat $d/flags.txt)" "$us" "$par" >> $O/variants.csv <<'PY'
 import csv, glob, sys
 d, name, flags, us, par = sys.argv[1:6]
@@ -52,7 +52,7 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         if "k_unit_fb" in row["Kernel_Name"]:
             a = acc.setdefault(row["Counter_Name"], [0.0, 0]); a[0] += float(row["Counter_Value"]); a[1] += 1
 g = {k: v[0] / v[1] for k, v in acc.items()}
-px = 3.0 * 12 * 192 * 640
+px = float(__import__('os').environ.get('VUNITS', '3')) * 12 * 192 * 640
 if g:
     quad = g["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
     print(f"{name},{flags},{us},{g['SQ_INSTS_VALU']*64/px:.0f},{g['SQ_ACTIVE_INST_VALU']/quad:.3f},{g['GRBM_GUI_ACTIVE']/8:.0f},"
@@ -62,5 +62,5 @@ else:
 PY
     rm -rf $O/pmc_$n
   done
-  column -s, -t $O/variants.csv | cut -c1-220
+  cut -c1-220 $O/variants.csv
 fi
