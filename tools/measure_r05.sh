@@ -3,7 +3,7 @@
 #   and of the training step, PMC passes (VALU / LDS, FETCH / WRITE), per-step kernel breakdown
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/r05m; mkdir -p $O; cd $R
 ulimit -c 0
-( time python -m pytest tests -m gpu -x -q ) > $O/r05_gputest.log 2>&1; tail -3 $O/r05_gputest.log
+if [ -z "$SKIP_TESTS" ]; then ( time python -m pytest tests -m gpu -x -q ) > $O/r05_gputest.log 2>&1; tail -3 $O/r05_gputest.log; fi
 s=$(date +%s); python bench.py > $O/r05_bench_train_resnet18.json 2> $O/bench_default.err; echo "default bench rc=$? $(( $(date +%s) - s )) s" | tee $O/bench_default.time
 for dm in smooth noise; do python bench.py --workload hotpath --disp $dm --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_hotpath_C2_$dm.json; done
 python bench.py --workload hotpath --batch 4 --steps 50 --warmup 5 --no-cpu-baseline 2>/dev/null | tail -1 > $O/r05_bench_hotpath_C1.json
