@@ -1279,6 +1279,18 @@ def main():
                 out["host"]["host_bound_with_8_ranks"] = bool(e_["ms_per_step"] > 1.05 * out["ms_per_step"])
         if own_kernels:
             out["own_kernels"] = own_kernels
+            # the hot path INSIDE the training step: its unit launches (HIP events of the timed region) plus the
+            # preparing / finishing / gradient-scale launches around them (own-kernel leg) -- in the trainer the
+            # disparity head supplies the mean partials and consumes the raw gradients, so this, not the stand-alone
+            # loop of `hotpath_only` (which computes the means and scales the gradients itself), is what a step pays
+            kk = own_kernels.get("kernels") or {}
+            rf = out.get("roofline") or {}
+            if rf.get("avg_us") and rf.get("launches") and out.get("steps"):
+                unit_ms = rf["avg_us"] * rf["launches"] / out["steps"] / 1e3
+                around = sum((kk.get(k) or {}).get("ms_per_step", 0.0) for k in ("k_units_finish", "k_fb_scale", "k_disp_mean"))
+                out["hotpath_in_step_unit_launches_ms"] = round(unit_ms, 4)
+                out["hotpath_in_step_ms"] = round(unit_ms + around, 4)
+                out["hotpath_in_step_over_unit_launches"] = round((unit_ms + around) / unit_ms, 3)
         if conv_mfma:
             out["conv_mfma"] = conv_mfma
         if comm:

@@ -223,6 +223,7 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         super().__init__(*args, **kwargs)
         self.groups = 1
         self._plan, self._tiled, self._called = None, None, False     # see _BnPlan
+        self._plan_off = False       # the layer ran twice inside one grouped() call once: it stays out of the plan
         self.sync = False            # synchronise statistics across ranks (SyncBatchNorm semantics)
         self.force_sync = False      # take the synchronised branch even in a group of one (tests)
         self.process_group = None
@@ -255,10 +256,14 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         tiled = None
         if plan is not None and plan.tiled_for(self, G):
             if self._called:
-                raise RuntimeError("a GroupedBatchNorm2d layer ran twice inside one grouped() call: its prepared "
-                                   "statistics buffer holds the first call's update (set MVF_BN_PLAN=0 for such a network)")
-            tiled = self._tiled
-            self._called = True
+                # second run inside one grouped() call (a block shared by two branches): the prepared buffer holds the
+                # first run's update.  Fold that update now, run this and every later call of the layer on the per-layer
+                # path, and keep the layer out of the network's plan from here on (no RuntimeError).
+                self._fold_running(self._tiled[2], self._tiled[3], G, C)
+                self._called, self._plan_off = False, True
+            else:
+                tiled = self._tiled
+                self._called = True
         if sync:
             xv = x.view(N // G, G * C, *x.shape[2:])
             # (weight and bias reach the synchronised function through autograd: their tiling stays a differentiable repeat)
@@ -344,6 +349,7 @@ class _BnPlan:
     @classmethod
     def of(cls, module, bns, groups):
         """The plan of (module, groups), or None where it does not apply (CPU, mixed momenta / devices, G > 32)."""
+        bns = [m for m in bns if not m._plan_off]
         if groups < 2 or groups > 32 or not bns or not _BN_PLAN:
             return None
         m0 = bns[0]
@@ -379,12 +385,16 @@ class _BnPlan:
         self._ensure_table()
         nat, st = _nat()
         nat.check(nat.lib().mvf_bn_tile_many(nat.ptr(self.table), len(self.bns), self.max_c, self.G, st), "bn_tile_many")
+        # the launch rewrote every layer's buffer through a raw pointer: tell autograd, so that a graph of an EARLIER
+        # grouped() call that still holds views of it (weights saved for backward) fails loudly instead of
+        # differentiating against the new values
+        torch.autograd.graph.increment_version([m._tiled for m in self.bns])
         for m in self.bns:
             m._plan, m._called = self, False
         self.live = True
 
     def tiled_for(self, m, G):
-        return self.live and G == self.G and m._tiled is not None
+        return self.live and G == self.G and m._tiled is not None and not m._plan_off
 
     def end(self):
         self.live = False

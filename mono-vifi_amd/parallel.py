@@ -136,12 +136,46 @@ def broadcast_module_states(modules, src=0):
 
 
 class _Bucket:
-    __slots__ = ("buf", "params", "views", "pending", "handle", "launched", "shard")
+    """One flat exchange buffer.  `buf` / `views` / `shard` are allocated the first time the bucket is exchanged (or its
+    views are asked for): a run that exchanges nothing (one process, no forced collectives) holds no copy of the
+    parameters' size."""
+    __slots__ = ("_buf", "params", "_views", "pending", "handle", "launched", "_shard", "numel", "unused", "_rank", "_world")
 
-    def __init__(self, buf, params, views):
-        self.buf, self.params, self.views = buf, params, views
+    def __init__(self, params, numel, rank, world):
+        self._buf, self.params, self._views = None, params, None
         self.pending, self.handle, self.launched = len(params), None, False
-        self.shard = None       # reduce_scatter exchange: this rank's 1/N-th of `buf` (a view)
+        self._shard = None      # reduce_scatter exchange: this rank's 1/N-th of `buf` (a view)
+        self.numel, self._rank, self._world = numel, rank, world
+        self.unused = []        # parameters that brought no gradient to the current step's exchange
+
+    def _materialise(self):
+        buf = torch.zeros(self.numel, dtype=torch.float32, device=self.params[0].device)
+        views, off = [], 0
+        for p in self.params:
+            views.append(buf[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        self._buf, self._views = buf, views
+        if self._world is not None:
+            per = self.numel // self._world
+            self._shard = buf[self._rank * per:(self._rank + 1) * per]
+
+    @property
+    def buf(self):
+        if self._buf is None:
+            self._materialise()
+        return self._buf
+
+    @property
+    def views(self):
+        if self._views is None:
+            self._materialise()
+        return self._views
+
+    @property
+    def shard(self):
+        if self._buf is None:
+            self._materialise()
+        return self._shard
 
 
 class BucketedGradReducer:
@@ -211,16 +245,9 @@ class BucketedGradReducer:
         # reduce_scatter exchange: every rank owns an equal slice, so the flat buffer is padded
         # to a multiple of the group size (the padding stays zero: nothing ever writes it)
         n_pad = -(-n // self.world) * self.world if self.exchange == "reduce_scatter" else n
-        buf = torch.zeros(n_pad, dtype=torch.float32, device=params[0].device)
-        views, off = [], 0
         for p in params:
-            views.append(buf[off:off + p.numel()].view_as(p))
-            off += p.numel()
             p.grad = None
-        b = _Bucket(buf, params, views)
-        if self.exchange == "reduce_scatter":
-            per = n_pad // self.world
-            b.shard = buf[self._rank * per:(self._rank + 1) * per]
+        b = _Bucket(params, n_pad, self._rank, self.world if self.exchange == "reduce_scatter" else None)
         for p in params:
             self._owner[id(p)] = b
         self.buckets.append(b)
@@ -233,6 +260,7 @@ class BucketedGradReducer:
         self._ev_issue, self._ev_end = [], None
         for b in self.buckets:
             b.pending, b.handle, b.launched = len(b.params), None, False
+            b.unused = []
             if _BUCKET_VIEWS:       # round-3 form, kept as a developer knob for same-box A/B timing
                 b.buf.zero_()
                 for p, v in zip(b.params, b.views):
@@ -244,12 +272,14 @@ class BucketedGradReducer:
     def _pack(self, b):
         """Gradients of a bucket -> its flat buffer (one multi-tensor copy; a parameter that got no gradient
         contributes zeros), and ``param.grad`` -> the view, so that what the collective averages in place is
-        what clipping and the optimiser read."""
+        what clipping and the optimiser read.  Parameters without a gradient are remembered: `finish()` hands
+        them back as ``grad = None`` (see there)."""
         src, dst = [], []
         for p, v in zip(b.params, b.views):
             g = p.grad
             if g is None:
                 v.zero_()
+                b.unused.append(p)
             elif g.data_ptr() != v.data_ptr():
                 src.append(g if g.dtype == v.dtype else g.to(v.dtype))
                 dst.append(v)
@@ -287,7 +317,7 @@ class BucketedGradReducer:
         b = self._owner[id(p)]
         b.pending -= 1
         if b.pending == 0 and not b.launched and self.overlap:
-            if self.timeline and b.buf.is_cuda:
+            if self.timeline and b.params[0].is_cuda:
                 ev = torch.cuda.Event(enable_timing=True)
                 ev.record()
                 self._ev_issue.append(ev)
@@ -296,8 +326,13 @@ class BucketedGradReducer:
 
     def finish(self):
         """Call after ``loss.backward()``: reduces the buckets that never filled (unused
-        parameters) and waits for every collective."""
-        if self.timeline and self.buckets and self.buckets[0].buf.is_cuda:
+        parameters) and waits for every collective.
+        A parameter that received no gradient in this step leaves with ``grad = None`` -- as it does in a run
+        without an exchange, and as the reference's ``DistributedDataParallel(find_unused_parameters=True)``
+        (train.py:208) leaves a globally unused one -- so AdamW neither decays it nor ages its moments at N = 8 while
+        it does not at N = 1.  Data-parallel ranks run the same graph, so the set is the same on every
+        rank; its zero slot still takes part in the collective (the bucket layout is static)."""
+        if self.timeline and self.buckets and self.buckets[0].params[0].is_cuda:
             self._ev_end = torch.cuda.Event(enable_timing=True)
             self._ev_end.record()
         for b in self.buckets:
@@ -313,6 +348,10 @@ class BucketedGradReducer:
                 if gather_late:
                     dist.all_gather_into_tensor(b.buf, b.shard, group=self.group)
                     count_collective("grad_all_gather")
+        for b in self.buckets:
+            for p in b.unused:
+                p.grad = None
+            b.unused = []
 
     def timeline_ms(self):
         """timeline=True: per exchange issued from a hook, the GPU time between its issue point and the end
@@ -333,7 +372,7 @@ class BucketedGradReducer:
 
     @property
     def total_bytes(self):
-        return sum(b.buf.numel() for b in self.buckets) * 4
+        return sum(b.numel for b in self.buckets) * 4
 
     def bucket_view(self, p):
         """The slice of its bucket a parameter's gradient is packed into (and, after the exchange, is)."""

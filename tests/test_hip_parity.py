@@ -1173,6 +1173,57 @@ def test_resnet_residual_epilogue_equals_stock_ops(dev):
         assert float((res[True][2] - res[False][2]).norm() / res[False][2].norm()) <= 1e-4
 
 
+def test_bn_plan_shared_layer_and_stale_graph(dev):
+    """The layer plan of a grouped call (one tiling launch when the call begins, one fold when it ends) against the
+    per-layer path: (a) a BatchNorm layer that runs TWICE inside one grouped() call -- a block shared by
+    two branches -- gives the sequential result (outputs, gradients, running statistics) instead of raising, and
+    stays out of the plan afterwards; (b) a graph of an earlier grouped() call that still holds the prepared buffer
+    fails loudly in backward once a later call has refilled it."""
+    import torch.nn as nn
+    from mono_vifi_amd.networks import grouped
+
+    class Shared(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1, self.c2 = nn.Conv2d(3, 8, 3, padding=1), nn.Conv2d(8, 8, 3, padding=1)
+            self.bn_a, self.bn_s = nn.BatchNorm2d(8), nn.BatchNorm2d(8)
+
+        def forward(self, x):
+            y = torch.relu(self.bn_a(self.c1(x)))
+            u = self.bn_s(self.c2(y))                 # the shared layer, first run
+            return self.bn_s(self.c2(torch.relu(u)))  # ... and second
+    torch.manual_seed(4)
+    G = 3
+    x = torch.rand(2 * G, 3, 16, 24, device=dev)
+    res = {}
+    for plan in (True, False):
+        torch.manual_seed(5)
+        net = grouped.convert_grouped_batchnorm(Shared()).to(dev).train()
+        grouped._BN_PLAN = plan
+        try:
+            for _ in range(2):                        # second step: the shared layer is out of the plan, the other in it
+                net.zero_grad()
+                with grouped.grouped(net, G):
+                    out = net(x)
+                (out ** 2).mean().backward()
+        finally:
+            grouped._BN_PLAN = True
+        res[plan] = (out.detach().clone(), torch.cat([p.grad.flatten() for p in net.parameters()]),
+                     torch.cat([b.flatten().float() for b in net.buffers()]))
+        if plan:
+            assert net.bn_s._plan_off and not net.bn_a._plan_off
+    for a, b in zip(res[True], res[False]):
+        assert float((a - b).abs().max()) <= 1e-5 * max(1.0, float(b.abs().max()))
+    # (b) stale graph
+    net = grouped.convert_grouped_batchnorm(nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8))).to(dev).train()
+    with grouped.grouped(net, G):
+        first = net(x)
+    with grouped.grouped(net, G):
+        net(x)
+    with pytest.raises(RuntimeError, match="modified by an inplace operation"):
+        first.sum().backward()
+
+
 def test_resize_bilinear_vs_oracle(dev):
     """mvf_resize_bilinear_fwd/bwd (HRNet fuse layers: align_corners=True up to 8x; Lite-Mono
     decoder: scale_factor=2) against the oracle (itself pinned to ATen's CPU kernels), forward

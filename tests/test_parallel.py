@@ -64,9 +64,11 @@ def _worker(rank, world, port, q, exchange="all_reduce", overlap=True):
                 assert red.issued_from_finish <= nb_unused
             else:
                 assert in_backward == 0 and red.issued_from_finish == red.num_buckets
-        # after the exchange every gradient IS its bucket slice (packed by one multi-tensor copy per bucket)
-        assert all(p.grad.data_ptr() == red.bucket_view(p).data_ptr() for p in params)
-        grads = [p.grad.clone() for p in params]
+        # after the exchange every gradient IS its bucket slice (packed by one multi-tensor copy per bucket); a
+        # parameter no rank used leaves with grad None, as under DDP(find_unused_parameters=True) (train.py:208)
+        assert all(p.grad.data_ptr() == red.bucket_view(p).data_ptr() for p in params if id(p) in used)
+        assert all(p.grad is None for p in params if id(p) not in used)
+        grads = [p.grad.clone() if p.grad is not None else None for p in params]
         # exactly one exchange per bucket per step, whichever form it takes
         cnt, nb = parallel.comm_counts(), red.num_buckets
         if exchange == "all_reduce":
@@ -74,7 +76,7 @@ def _worker(rank, world, port, q, exchange="all_reduce", overlap=True):
         else:
             assert cnt == {"grad_reduce_scatter": 2 * nb, "grad_all_gather": 2 * nb}, cnt
             assert all(b.buf.numel() % world == 0 for b in red.buckets)
-        q.put((rank, [g.tolist() for g in grads], [p.detach().tolist() for p in params]))
+        q.put((rank, [g.tolist() if g is not None else None for g in grads], [p.detach().tolist() for p in params]))
     finally:
         dist.destroy_process_group()
 
@@ -108,8 +110,10 @@ def test_bucketed_reducer_matches_full_batch_gradient(exchange, overlap):
     for rank, grads, params in res:
         for g, p, rp in zip(grads, params, ref_params):
             assert torch.allclose(torch.tensor(p), rp.detach(), atol=0), "broadcast failed"
-            want = rp.grad if rp.grad is not None else torch.zeros_like(rp)
-            assert torch.allclose(torch.tensor(g), want, atol=1e-6), f"rank {rank} grad mismatch"
+            if rp.grad is None:
+                assert g is None, f"rank {rank}: an unused parameter must keep grad None"
+                continue
+            assert torch.allclose(torch.tensor(g), rp.grad, atol=1e-6), f"rank {rank} grad mismatch"
     assert res[0][1] == res[1][1]          # identical on both ranks
 
 
