@@ -824,14 +824,19 @@ def hotpath_leg(args, rank, dev, nat, steps=20, warmup=5):
     step = HotPathStep(args, rank, dev)
     for _ in range(warmup):
         step()
-    nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
-    nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
+    # the loop's own time first, without instrumentation (an event pair around every unit launch is two extra
+    # packets per launch on the stream); then the same steps again with the events, for the kernel's launch time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
+    nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
     nat.lib().mvf_profile_enable(0)
     fb_ms, fb_n = nat.profile_read(nat.PROF_UNIT_FWDBWD)
     kernels, dom = kernel_rooflines(args, 0.0, 0, 0.0, 0, fb_ms, fb_n, nat.profile_read_work(nat.PROF_UNIT_FWDBWD),

@@ -566,14 +566,27 @@ __global__ void __launch_bounds__(64) k_silog_many_finish(const float *__restric
             for (int i = 0; i < 64; ++i) lt += acc[i];
         __syncthreads();
     }
+    __shared__ int s_last;
     if (threadIdx.x == 0) {
         publish(losses + jb, (float)(lt / (double)B));
-        if (take_ticket(tickets) == n_jobs - 1) {
-            float tt = 0.0f;
-            for (int k = 0; k < n_jobs; ++k) tt += fetch_published(losses + k);
-            total[0] = tt;
-            publish(tickets, 0);
-        }
+        s_last = (take_ticket(tickets) == n_jobs - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // (the jobs' losses fetched by as many lanes at once, summed in job order by one: a lane fetching them one after the
+    // other pays a round trip to the device-coherent level per job)
+    float tt = 0.0f;
+    for (int k0 = 0; k0 < n_jobs; k0 += 64) {
+        const int k = k0 + (int)threadIdx.x;
+        if (k < n_jobs) acc[threadIdx.x] = (double)fetch_published(losses + k);
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < min(64, n_jobs - k0); ++i) tt += (float)acc[i];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        total[0] = tt;
+        publish(tickets, 0);
     }
 }
 // element-wise adjoint of every job: upstream gradient = g_total[0] (nullable) + g_losses[job] (nullable)

@@ -130,8 +130,20 @@ MVF_DEV TileId tile_of_block_mg(int tiles_x, int tiles_y, int B, uint32_t mg_tx,
     const int total = tiles_x * tiles_y * B;
     const int lin = blockIdx.x;
     const int xcd = lin & 7, slot = lin >> 3;
+#ifndef MVF_FB_XCD_MAP
+#define MVF_FB_XCD_MAP 0      // 0: every XCD owns ONE contiguous run of tiles; 1: tile = workgroup index (consecutive tiles on
+                              // consecutive XCDs); k >= 2: runs of 2^k tiles dealt round robin to the XCDs
+#endif
+#if MVF_FB_XCD_MAP == 1
+    const int vid = lin;
+#elif MVF_FB_XCD_MAP >= 2
+    constexpr int LG = MVF_FB_XCD_MAP;
+    const int full = total & ~((8 << LG) - 1);
+    const int vid = lin < full ? ((((slot >> LG) << 3) + xcd) << LG) + (slot & ((1 << LG) - 1)) : lin;
+#else
     const int q = total >> 3, r = total & 7;
     const int vid = xcd * q + min(xcd, r) + slot;
+#endif
     TileId t;
     const int rest = div_magic(vid, mg_tx);
     t.bx = vid - rest * tiles_x;
@@ -1276,13 +1288,17 @@ __global__ void __launch_bounds__(256) k_units_prepare(FbArgs a, int S, unsigned
         if (t == 0) publish(tk + unit * a.B + b, 0);    // leave the counter as it was found
     } else if (chunk != 0) return;
     ImgTab &tb = reinterpret_cast<ImgTab *>(a.tab)[(size_t)unit * a.B + b];
+    // the NMEAN partials fetched by NMEAN lanes at once, then folded in index order by one (a lane fetching them one after
+    // the other paid 32 dependent round trips to the device-coherent level: 16 us of the launch's 17.5)
+    __shared__ float parts[NMEAN];
+    if (t >= 64 && t < 64 + NMEAN) parts[t - 64] = fetch_published(u.mean_ws + b * NMEAN + (t - 64));
+    __syncthreads();
     if (t < 24) {
         const int k = (t < 12 || S < 2) ? 0 : 1, e = t < 12 ? t : t - 12;
         tb.P[t < 12 ? 0 : 1][e] = proj_entry(u.K + b * 16, u.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
     } else if (t == 32) {
         float m = 0.0f;
-        for (int i = 0; i < NMEAN; ++i)
-            m += fetch_published(u.mean_ws + b * NMEAN + i);
+        for (int i = 0; i < NMEAN; ++i) m += parts[i];
         const float mean = m / (float)((size_t)a.H * a.W);
         const float den = mean + 1e-7f;
         tb.mean = mean;
@@ -1364,31 +1380,50 @@ __global__ void __launch_bounds__(32 * FIN_SLICES) k_units_finish(FbArgs a, int 
         publish(iw, red[24]);
         publish(iw + 1, sxb + syb);
         s_last = (take_ticket(a.tickets + unit) == a.B - 1);       // the image's terms are complete before its ticket
-        if (s_last) {
-            double photo = 0.0, smooth = 0.0;
-            for (int i = 0; i < a.B; ++i) {
-                const double *jw = a.img_ws + ((size_t)unit * a.B + i) * NIMG;
-                photo += fetch_published(jw);
-                smooth += fetch_published(jw + 1);
-            }
-            const double pmn = photo / ((double)a.B * (double)N);
-            const float l0 = (float)(pmn + (double)a.smoothness * smooth);
-            u.loss[0] = l0;
-            u.loss[1] = (float)pmn;
-            u.loss[2] = (float)smooth;
-            publish(a.tickets + unit, 0);      // leave the counter as it was found
-            if (a.loss_sum) {
-                // the launch's last unit to finish adds the units' losses in UNIT order (whoever it is: the
-                // result does not depend on the arrival order); each finisher publishes its loss[0] first
-                publish(u.loss, l0);
-                if (take_ticket(a.tickets + a.nunits) == a.nunits - 1) {
-                    float tot = a.loss_sum_in ? a.loss_sum_in[0] : 0.0f;
-                    for (int i = 0; i < a.nunits; ++i) tot += fetch_published(a.u[i].loss);
-                    a.loss_sum[0] = tot;
-                    publish(a.tickets + a.nunits, 0);
-                }
+    }
+    __syncthreads();          // (also: everybody is done with `red`)
+    if (!s_last) return;      // workgroup-uniform
+    // the unit's last block folds its images in index order.  The published terms are fetched by as many lanes at once and
+    // summed from LDS by one (lane 0 fetching them one after the other: 2 B dependent round trips, 10 us per launch)
+    double photo = 0.0, smooth = 0.0;
+    for (int i0 = 0; i0 < a.B; i0 += 512) {
+        const int which = threadIdx.x >> 9, ii = i0 + (threadIdx.x & 511);
+        if (ii < a.B) red[threadIdx.x] = fetch_published(a.img_ws + ((size_t)unit * a.B + ii) * NIMG + which);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int nb = min(512, a.B - i0);
+            for (int k = 0; k < nb; ++k) {
+                photo += red[k];
+                smooth += red[512 + k];
             }
         }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double pmn = photo / ((double)a.B * (double)N);
+        const float l0 = (float)(pmn + (double)a.smoothness * smooth);
+        u.loss[0] = l0;
+        u.loss[1] = (float)pmn;
+        u.loss[2] = (float)smooth;
+        publish(a.tickets + unit, 0);      // leave the counter as it was found
+        s_last = 0;
+        if (a.loss_sum) {
+            // the launch's last unit to finish adds the units' losses in UNIT order (whoever it is: the
+            // result does not depend on the arrival order); each finisher publishes its loss[0] first
+            publish(u.loss, l0);
+            s_last = (take_ticket(a.tickets + a.nunits) == a.nunits - 1);
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float *lsum = reinterpret_cast<float *>(red);
+    if ((int)threadIdx.x < a.nunits) lsum[threadIdx.x] = fetch_published(a.u[threadIdx.x].loss);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float tot = a.loss_sum_in ? a.loss_sum_in[0] : 0.0f;
+        for (int i = 0; i < a.nunits; ++i) tot += lsum[i];
+        a.loss_sum[0] = tot;
+        publish(a.tickets + a.nunits, 0);
     }
 }
 

@@ -18,8 +18,15 @@ from . import _native as nat
 NO_SSIM, AVG_REPROJ, NO_AUTOMASK = nat.NO_SSIM, nat.AVG_REPROJ, nat.NO_AUTOMASK
 
 
+def _raw_stream():
+    """The current HIP stream of the current device as an integer handle.  (`torch.cuda.current_stream()` builds a
+    Python Stream object through three layers of device-index helpers: 11 us per call, four calls per unit launch --
+    a twentieth of the host-bound stand-alone hot-path loop; the raw getter is a C call.)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
+
+
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())
 
 
 def _c(t):
@@ -403,7 +410,8 @@ _TICKETS = {}
 
 
 def _ticket_key(dev):
-    return (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    # (require_device has already held `dev` to the current device: its current stream is the launch stream)
+    return (dev.index, _raw_stream())
 
 
 def _tickets(dev, n):
@@ -491,6 +499,8 @@ class Units(torch.autograd.Function):
         g_T = torch.empty((n, S, B, 4, 4), dtype=torch.float32, device=dev)
         outs = []
         needs = []
+        empty = torch.empty(0, device=dev)
+        seeds = None
         for u in range(n):
             disp, tgt, T, K, inv_K, mask_rec, noise, ident_in = flat[u * per:u * per + UNIT_FIELDS]
             src = flat[u * per + UNIT_FIELDS:(u + 1) * per]
@@ -527,8 +537,10 @@ class Units(torch.autograd.Function):
             seed = 0
             if noise is None and automask:
                 # tie-break draw of train.py:1023-1024 generated in the kernel: one 64-bit key per
-                # unit from torch's CPU generator (reproducible under torch.manual_seed)
-                seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+                # unit from torch's CPU generator (reproducible under torch.manual_seed; the keys of a launch in one draw)
+                if seeds is None:
+                    seeds = torch.randint(0, 2 ** 62, (n,), dtype=torch.int64).tolist()
+                seed = int(seeds[u])
             d = descs[u]
             d.disp, d.disp_stride = disp.data_ptr(), ds
             d.tgt, d.tgt_stride = tgt.data_ptr(), ts
@@ -550,7 +562,6 @@ class Units(torch.autograd.Function):
             d.idx_xy = idx.data_ptr() if idx is not None else None
             d.noise_out = noise_outs[u].data_ptr() if noise_outs[u] is not None else None
             keep += [disp, tgt, mask_rec, T, K, inv_K, noise, ident_in, mp, srcs]
-            empty = torch.empty(0, device=dev)
             outs += [auto_mask if auto_mask is not None else empty, argmin,
                      idx if idx is not None else empty, ident if ident is not None else empty]
             needs.append((ctx.needs_input_grad[1 + u * per], ctx.needs_input_grad[1 + u * per + 2]))
