@@ -1,6 +1,7 @@
-"""Fill the @TOKEN@ placeholders of DESIGN.md from the round's measured files (profiles/r05_*): the numbers of the
-document are the numbers of the committed bench line and rocprofv3 summaries, not retyped ones.
-    python tools/fill_design.py [--check]      (--check: print the substitutions, leave the file alone)"""
+"""DESIGN.md = tools/DESIGN.md.in with its @TOKEN@ placeholders filled from the round's measured files (profiles/r05_*):
+the numbers of the document are the numbers of the committed bench line and rocprofv3 summaries, not retyped ones.  Edit
+the text in tools/DESIGN.md.in and re-run.
+    python tools/fill_design.py [--check]      (--check: print the substitutions, write nothing)"""
 import csv
 import json
 import os
@@ -73,7 +74,7 @@ def main():
         "PIN_C4": pin(oc["C4"].get("pinned_eager_over_unpinned")), "PIN_C5": pin(oc["C5"].get("pinned_eager_over_unpinned")),
     }
     path = os.path.join(R, "DESIGN.md")
-    s = open(path).read()
+    s = open(os.path.join(R, "tools", "DESIGN.md.in")).read()
     missing = sorted(set(re.findall(r"@([A-Z_0-9]+)@", s)) - set(sub))
     if missing:
         sys.exit("no value for: " + ", ".join(missing))
