@@ -410,3 +410,28 @@ def test_deferred_unit_gradients_through_the_disparity_head(dev, shape, G, with_
     # the groups no unit read got no disparity gradient (only the depth term, if any)
     if not with_depth_grad and G > n:
         assert float(np.abs(b[1].reshape(B, G, -1)[:, n:]).max()) == 0.0
+
+
+@pytest.mark.parametrize("shape", [(2, 33, 70), (3, 37, 53), (1, 64, 200), (4, 192, 640), (2, 320, 1024)])
+def test_preparing_launch_means_equal_the_heads_partials(dev, shape):
+    """The mean disparity a launch computes itself (k_units_prepare: 32 chunk sums per image, sixteen loads in
+    flight per lane, folded by the last block to arrive) equals, bit for bit, the one it forms from the partials the
+    disparity head supplies (k_disp_head_fwd: the same partition and summation order) -- stats[:, 0:2] = (mean, mean +
+    1e-7) of both routes, ragged chunk tails included; losses and raw gradients follow."""
+    from mono_vifi_amd import ops
+    B, H, W = shape
+    inp = _inputs(8800 + H, B, H, W, 0, with_mask=False)
+    dnp = np.clip(inp["disp"], 1e-4, 1 - 1e-4)
+    logit = T(np.log(dnp / (1 - dnp)).astype(np.float32), dev)
+    disp, _, part = ops.disp_head(logit, 0.1, 100.0, want_depth=False, want_sink=False)
+    disp = disp.detach()
+    res = []
+    for parts in (None, [part.contiguous()]):
+        d = disp.clone().requires_grad_(True)
+        _, Tt, flat = _flat(inp, dev, 0, disp=d)
+        torch.manual_seed(3)
+        out = ops.Units.apply(_cfg(1, 0, mean_parts=parts), *flat)
+        out[0].sum().backward()
+        res.append((N(out[0]), N(out[1]), N(d.grad), N(Tt.grad)))
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), "loss: own mean != head partials"
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
