@@ -141,11 +141,18 @@ __global__ void __launch_bounds__(NT) k_fusion_level_fwd(const float *__restrict
         for (int c = c0; c < c1; ++c) {
             const size_t pl = ((size_t)b * C + c) * n;
             ob[(size_t)c * n] = f0[pl + i];
+#ifdef MVF_ABL_FUS_NOGATHER      // timing ablation: the two warps read their own pixel (streaming loads instead of tap gathers)
+            const float a = fn1[pl + i], q = fp1[pl + i];
+#else
             const float a = bilerp(fn1 + pl, w, tn), q = bilerp(fp1 + pl, w, tp);
+#endif
             ob[(size_t)(C + EMB + c) * n] = m * a + om * q;
         }
         return;
     }
+#ifdef MVF_ABL_FUS_NOEMB         // timing ablation: the embedding channels are not written
+    return;
+#endif
     // ---- embedding channels: [x, sin(2^k x), cos(2^k x)] of the (zero | n1 | p1) flows
     const float en[2] = {pp[0], pp[(size_t)n]}, ep[2] = {pp[2 * (size_t)n], pp[3 * (size_t)n]};
     float *o0 = ob + (size_t)C * n;                 // emb(0)
