@@ -714,11 +714,21 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 
     // ---- 3: fused warp of the source pair
     MVF_PHASE("3_warp");
+#ifndef MVF_FB_PRIO
+#define MVF_FB_PRIO 0        // experiment: wave priority by phase (1: raised over the warp phase -- its tap loads leave earlier;
+                             // 2: raised from the SSIM adjoint to the end -- the oldest workgroup frees its slot earlier)
+#endif
+#if MVF_FB_PRIO == 1
+    __builtin_amdgcn_s_setprio(2);
+#endif
 #ifdef MVF_ABL_NOWARP    // timing ablation: the raw sources instead of the warped pair
     stage_pair3(pairP, wk_ctx.sa, wk_ctx.sb, N, H, W, py0, px0);
     if (false)
 #endif
         warp_pair_into_lds_fb(wk_ctx, 0);
+#if MVF_FB_PRIO == 1
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __syncthreads();
 
     // ---- 4: warped candidates; the SSIM partials of the three channels stay in registers
@@ -889,6 +899,9 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // hold row sums, and the vertical step reads two rows instead of nine row segments.
     // Reflect-pad multiplicities only exist next to the image border (rows 1, H-2, cols 1, W-2).
     MVF_PHASE("6_ssim_adjoint");
+#if MVF_FB_PRIO == 2
+    __builtin_amdgcn_s_setprio(1);
+#endif
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
     float mlx[PX], mrx[PX];
 #pragma unroll
