@@ -167,19 +167,32 @@ class _AllReduceSyncBN(torch.autograd.Function):
 class _FusedSyncBN(torch.autograd.Function):
     """Synchronised batch norm on a HIP device from ATen's fused building blocks
     (torch.batch_norm_stats / batch_norm_gather_stats_with_counts / batch_norm_elemt and the
-    two backward kernels): ONE all_gather of (mean, invstd, count) forward and ONE all_reduce
+    two backward kernels): ONE all_gather of (mean, invstd) forward and ONE all_reduce
     of (sum dy, sum dy*xmu) backward per layer, both on RCCL.  Same arithmetic as
     nn.SyncBatchNorm, without its dependency on torch's private ``nn.modules._functions`` and
     without its per-layer host synchronisation (it filters empty ranks with a boolean mask;
-    every rank here always holds the same non-empty batch, `drop_last=True`)."""
+    every rank here always holds the same non-empty batch, `drop_last=True`).
+
+    ``x`` is the folded view ``[B, G*C, ...]`` of ``groups`` interleaved calls; ``weight`` / ``bias`` are the layer's
+    ``[C]`` parameters.  Round 5: the vector glue of a layer was ten tiny launches each way (the element count as a
+    fresh tensor, its gather and conversion, a differentiable ``repeat`` of weight and bias and the two reductions of
+    its adjoint) -- 428 launches and +3 % per ResNet18 step on one GPU.  Now: the counts are a cached constant (every
+    rank holds the same batch, so they need no gather), weight and bias are tiled by `mvf_bn_tile` (or come tiled
+    from the layer plan) and their gradients untiled by `mvf_bn_untile`."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group, world, out_shape):
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, group, world, out_shape, groups,
+                tiled_wb):
         x = x.contiguous()
-        C = x.shape[1]
+        GC = x.shape[1]
+        if tiled_wb is not None:
+            wG, bG = tiled_wb
+        elif groups == 1:
+            wG, bG = weight, bias
+        else:
+            wG, bG = weight.repeat(groups), bias.repeat(groups)        # (inside forward(): plain copies, no autograd nodes)
         mean, invstd = torch.batch_norm_stats(x, eps)
-        count = torch.full((1,), x.numel() // C, dtype=mean.dtype, device=mean.device)
-        combined = torch.cat([mean, invstd, count])
+        combined = torch.cat([mean, invstd])
         if dist.get_backend(group) == "gloo":          # no all_gather_into_tensor on gloo
             parts = [torch.empty_like(combined) for _ in range(world)]
             dist.all_gather(parts, combined, group)
@@ -189,21 +202,22 @@ class _FusedSyncBN(torch.autograd.Function):
             dist.all_gather_into_tensor(flat, combined, group)
             allc = flat.view(world, combined.numel())
         _count("bn_all_gather")
-        mean_all, invstd_all, count_all = torch.split(allc, C, dim=1)
-        counts = count_all.reshape(-1)
+        mean_all, invstd_all = allc[:, :GC], allc[:, GC:]
+        n = x.numel() // GC
+        counts = const_tensor((float(n),) * world, x.device, mean.dtype)
         mean, invstd = torch.batch_norm_gather_stats_with_counts(
             x, mean_all.contiguous(), invstd_all.contiguous(), running_mean, running_var, momentum, eps,
             counts)
-        ctx.save_for_backward(x, weight, mean, invstd, counts.to(torch.int32))
-        ctx.group = group
-        return _alias(torch.batch_norm_elemt(x, weight, bias, mean, invstd, eps), out_shape)
+        ctx.save_for_backward(x, wG, mean, invstd, const_tensor((float(n),) * world, x.device, torch.int32))
+        ctx.group, ctx.groups = group, groups
+        return _alias(torch.batch_norm_elemt(x, wG, bG, mean, invstd, eps), out_shape)
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight, mean, invstd, counts = ctx.saved_tensors
+        x, wG, mean, invstd, counts = ctx.saved_tensors
         gy = gy.contiguous().view_as(x)
         sum_dy, sum_dy_xmu, gw, gb = torch.batch_norm_backward_reduce(
-            gy, x, mean, invstd, weight, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+            gy, x, mean, invstd, wG, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
             ctx.needs_input_grad[2])
         gx = None
         if ctx.needs_input_grad[0]:
@@ -212,8 +226,21 @@ class _FusedSyncBN(torch.autograd.Function):
             dist.all_reduce(both, op=dist.ReduceOp.SUM, group=ctx.group)
             _count("bn_all_reduce")
             sum_dy, sum_dy_xmu = torch.split(both, C)
-            gx = torch.batch_norm_backward_elemt(gy, x, mean, invstd, weight, sum_dy, sum_dy_xmu, counts)
-        return gx, gw, gb, None, None, None, None, None, None, None
+            gx = torch.batch_norm_backward_elemt(gy, x, mean, invstd, wG, sum_dy, sum_dy_xmu, counts)
+        G = ctx.groups
+        if G > 1 and gw is not None and gb is not None:
+            if _native_vectors(gw, gb):
+                nat, st = _nat()
+                Cn = gw.numel() // G
+                gwb = torch.empty((2, Cn), dtype=torch.float32, device=gw.device)
+                nat.check(nat.lib().mvf_bn_untile(nat.ptr(gw), nat.ptr(gb), nat.ptr(gwb), Cn, G, st), "bn_untile")
+                gw, gb = gwb[0], gwb[1]
+            else:
+                gw, gb = gw.view(G, -1).sum(0), gb.view(G, -1).sum(0)
+        elif G > 1:
+            gw = gw.view(G, -1).sum(0) if gw is not None else None
+            gb = gb.view(G, -1).sum(0) if gb is not None else None
+        return gx, gw, gb, None, None, None, None, None, None, None, None, None
 
 
 class GroupedBatchNorm2d(nn.BatchNorm2d):
@@ -228,11 +255,12 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
         self.force_sync = False      # take the synchronised branch even in a group of one (tests)
         self.process_group = None
 
-    def _sync_bn(self, xv, w, b, rm, rv, world, out_shape):
-        """SyncBatchNorm over the folded view; updates rm/rv in place."""
+    def _sync_bn(self, xv, w, b, rm, rv, world, out_shape, G=1, tiled_wb=None):
+        """SyncBatchNorm over the folded view; updates rm/rv in place.  On a HIP device `w`, `b` are the layer's [C]
+        parameters (tiled inside `_FusedSyncBN`: `tiled_wb` = the plan's tiled copies); on the CPU they come tiled."""
         if xv.is_cuda:
             group = self.process_group or dist.group.WORLD
-            return _FusedSyncBN.apply(xv, w, b, rm, rv, self.eps, self.momentum, group, world, out_shape)
+            return _FusedSyncBN.apply(xv, w, b, rm, rv, self.eps, self.momentum, group, world, out_shape, G, tiled_wb)
         y, mean, var, n = _AllReduceSyncBN.apply(xv, w, b, self.eps, self.process_group)
         with torch.no_grad():
             rm.mul_(1 - self.momentum).add_(mean, alpha=self.momentum)
@@ -266,13 +294,17 @@ class GroupedBatchNorm2d(nn.BatchNorm2d):
                 self._called = True
         if sync:
             xv = x.view(N // G, G * C, *x.shape[2:])
-            # (weight and bias reach the synchronised function through autograd: their tiling stays a differentiable repeat)
-            w, b = self.weight.repeat(G), self.bias.repeat(G)
             if tiled is not None:
                 rm, rv = tiled[2], tiled[3]
             else:
                 rm, rv = self.running_mean.repeat(G), self.running_var.repeat(G)
-            y = self._sync_bn(xv, w, b, rm, rv, world, x.shape)
+            if xv.is_cuda:
+                # the fused function tiles weight / bias itself (or takes the plan's copies) and untiles their gradients
+                y = self._sync_bn(xv, self.weight, self.bias, rm, rv, world, x.shape, G,
+                                  (tiled[0], tiled[1]) if tiled is not None else None)
+            else:
+                # (CPU: weight and bias reach the synchronised function through a differentiable repeat)
+                y = self._sync_bn(xv, self.weight.repeat(G), self.bias.repeat(G), rm, rv, world, x.shape)
         else:
             y, rm, rv = _FoldedBN.apply(x, self.weight, self.bias, self.running_mean, self.running_var, G,
                                         self.momentum, self.eps, tiled)
