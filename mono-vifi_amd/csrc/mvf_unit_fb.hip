@@ -372,14 +372,25 @@ MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restric
 #define MVF_FB_KEEPTAPS 1     // the adjoint takes the forward's taps from registers (0: re-runs the projection chain)
 #endif
 
-// What phase 7 needs of the forward's projection chain at an output pixel, kept in FOUR registers per
+// What phase 7 needs of the forward's projection chain at an output pixel, kept in SIX registers per
 // position: per source the byte offset of the row-y0 tap pair (< 2^28) with four flags above it (pair
-// anchored one pixel left, row y1 below y0, x / y strictly inside) and the fractional tap position as two
-// 16-bit fixed-point numbers (the adjoint is tolerance arithmetic: 1.5e-5 on a bilinear weight).  For this to
-// work a lane must warp in phase 3 the pixels whose adjoint it evaluates in phases 7 + 8: the warp walks the
-// 30 x 14 interior first, in the lane order of phase 7, then the border ring of the 34 x 18 plane.
+// anchored one pixel left, row y1 below y0, x / y strictly inside) and the fractional tap position (two floats).
+// For this to work a lane must warp in phase 3 the pixels whose adjoint it evaluates in phases 7 + 8: the warp
+// walks the 30 x 14 interior first, in the lane order of phase 7, then the border ring of the 34 x 18 plane.
+#ifndef MVF_FB_STASH_F32
+#define MVF_FB_STASH_F32 1    // 0: the fractional positions as two 16-bit fixed-point numbers per source (round 4: four
+                              // registers per position).  Round 5 measured both against the adjoint evaluated in double
+                              // (tools/grad_vs_f64_adjoint.py): the same worst pixels either way -- the 1.5e-5 of a
+                              // truncated weight is not what separates fp32 evaluations -- and the float form is 0.9 %
+                              // FASTER (no pack / unpack conversions: 1,721 -> 1,705 instr/px, 123 VGPRs)
+#endif
 struct TapStash {
-    uint32_t oa, ob, wa, wb;
+    uint32_t oa, ob;
+#if MVF_FB_STASH_F32
+    float wxa, wya, wxb, wyb;
+#else
+    uint32_t wa, wb;
+#endif
 };
 constexpr uint32_t kOffMask = 0x0fffffffu;
 MVF_DEV uint32_t pack_w(float wx, float wy)
@@ -391,8 +402,12 @@ MVF_DEV TapStash pack_taps(const WarpSlot &s)
     TapStash t;
     t.oa = s.qa.q.o0 | (s.qa.q.sh ? 1u << 28 : 0u) | (s.qa.q.o1 != s.qa.q.o0 ? 1u << 29 : 0u) | (s.fla << 28);
     t.ob = s.qb.q.o0 | (s.qb.q.sh ? 1u << 28 : 0u) | (s.qb.q.o1 != s.qb.q.o0 ? 1u << 29 : 0u) | (s.flb << 28);
+#if MVF_FB_STASH_F32
+    t.wxa = s.wxa; t.wya = s.wya; t.wxb = s.wxb; t.wyb = s.wyb;
+#else
     t.wa = pack_w(s.wxa, s.wya);
     t.wb = pack_w(s.wxb, s.wyb);
+#endif
     return t;
 }
 // plane position (r, c) of warp slot q (0 .. NSTAGE-1) of this lane; false beyond the plane
@@ -1093,8 +1108,13 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 const f2 rzz = mk2(__builtin_amdgcn_rcpf(w.z.x), __builtin_amdgcn_rcpf(w.z.y));
                 w.u = c[0] * rzz;
                 w.v = c[1] * rzz;
+#if MVF_FB_STASH_F32
+                w.ta.wx = ts.wxa; w.ta.wy = ts.wya;
+                w.tb.wx = ts.wxb; w.tb.wy = ts.wyb;
+#else
                 w.ta.wx = (float)(ts.wa & 0xffffu) * 0x1p-16f; w.ta.wy = (float)(ts.wa >> 16) * 0x1p-16f;
                 w.tb.wx = (float)(ts.wb & 0xffffu) * 0x1p-16f; w.tb.wy = (float)(ts.wb >> 16) * 0x1p-16f;
+#endif
                 w.ta.inx = ts.oa & (1u << 30); w.ta.iny = ts.oa & (1u << 31);
                 w.tb.inx = ts.ob & (1u << 30); w.tb.iny = ts.ob & (1u << 31);
             }

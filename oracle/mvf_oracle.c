@@ -1136,3 +1136,256 @@ MVFO_API void mvfo_affine_restore_bwd(const float *g_out, const float *angle, co
             free(acc);
         }
 }
+
+/* ====================================================================================
+ * The adjoint of one unit evaluated in DOUBLE (test infrastructure for the 1e-4 per-element gradient bar).
+ * Same chain as mvfo_losses_base_bwd -> mvfo_warp_bwd -> mvfo_smooth_bwd above (autograd of reference
+ * train.py:956-1051, layers.py:231-290).  Every DECISION is the fp32 forward's -- the argmin map it is given, the
+ * bilinear cell and the clipped-coordinate flags (tap_of on the fp32 chain), whether SSIM's clamp passes the gradient
+ * (the fp32 raw value), the sign of a disparity difference -- so this differentiates the SAME piecewise function the
+ * fp32 forward evaluated; every VALUE (window means, SSIM partials, projection chain, bilinear weights, smoothness
+ * weights, all sums) is formed in double from the fp32 inputs.  Three legitimate fp32 evaluation orders of this
+ * adjoint (the reference's autograd, the fp32 oracle above, the HIP kernel) sit up to 2.7e-4 of the tensor max
+ * apart at their worst pixel; against this double evaluation each of them can be held to 1e-4.  Pinned to the
+ * reference evaluated in float64 (tests/golden/g4_f64_C2_*.npz) by tests/test_oracle_golden.py.
+ * ==================================================================================== */
+typedef struct { double mu_x, mu_y, exx, eyy, exy; } win64_t;
+
+static inline win64_t window_stats64(const float *x, const float *y, int H, int W, int py, int px)
+{
+    double sx = 0.0, sy = 0.0, sxx = 0.0, syy = 0.0, sxy = 0.0;
+    for (int dy = -1; dy <= 1; ++dy) {
+        int yy = refl(py + dy, H);
+        for (int dx = -1; dx <= 1; ++dx) {
+            int xx = refl(px + dx, W);
+            double a = x[yy * W + xx], b = y[yy * W + xx];
+            sx += a; sy += b; sxx += a * a; syy += b * b; sxy += a * b;
+        }
+    }
+    win64_t w = {sx / 9.0, sy / 9.0, sxx / 9.0, syy / 9.0, sxy / 9.0};
+    return w;
+}
+
+typedef struct { double dmux, dexx, dexy; } dwin64_t;
+
+/* d SSIM / d (mu_x, Exx, Exy) of the un-clamped map (the caller has checked that the clamp is inactive) */
+static inline dwin64_t ssim_partials64(const win64_t *w)
+{
+    const double C1 = 0.01 * 0.01, C2 = 0.03 * 0.03;
+    double mx = w->mu_x, my = w->mu_y;
+    double sigma_x = w->exx - mx * mx, sigma_y = w->eyy - my * my, sigma_xy = w->exy - mx * my;
+    double A1 = 2.0 * mx * my + C1, A2 = 2.0 * sigma_xy + C2;
+    double B1 = mx * mx + my * my + C1, B2 = sigma_x + sigma_y + C2;
+    double n = A1 * A2, d = B1 * B2;
+    double kn = -0.5 / d, kd = 0.5 * n / (d * d);
+    dwin64_t g;
+    g.dmux = kn * (2.0 * my * A2 - 2.0 * my * A1) + kd * (2.0 * mx * B2 - 2.0 * mx * B1);
+    g.dexy = kn * 2.0 * A1;
+    g.dexx = kd * B1;
+    return g;
+}
+
+/* gwarped[k] [B,3,H,W] double, overwritten */
+MVFO_API void mvfo_losses_base_bwd_f64(const float *tgt, const float *const *warped, const int32_t *idx,
+                                       const float *mask_rec, int S, int flags, double gloss,
+                                       double *const *gwarped, int B, int H, int W)
+{
+    long N = (long)H * W;
+    int no_ssim = flags & MVFO_NO_SSIM, avg = flags & MVFO_AVG_REPROJ, automask = !(flags & MVFO_NO_AUTOMASK);
+    int n_id = automask ? (avg ? 1 : S) : 0;
+    float C1 = ssim_c1(), C2 = ssim_c2();
+    double gpix = gloss / ((double)B * (double)N);
+    for (int k = 0; k < S; ++k) {
+        double *gw = gwarped[k];
+        memset(gw, 0, sizeof(double) * B * 3 * N);
+        const int BAND = 8, nband = (H + BAND - 1) / BAND;      /* row bands of one colour never touch the same row */
+        for (int colour = 0; colour < 2; ++colour) {
+#pragma omp parallel for schedule(dynamic, 1) collapse(2)
+        for (int bc = 0; bc < B * 3; ++bc)
+        for (int band = colour; band < nband; band += 2) {
+            int b = bc / 3;
+            const float *xb = warped[k] + bc * N, *yb = tgt + bc * N;
+            int py_end = (band + 1) * BAND < H ? (band + 1) * BAND : H;
+            for (int py = band * BAND; py < py_end; ++py)
+                for (int px = 0; px < W; ++px) {
+                    long i = (long)py * W + px;
+                    int sel = idx ? idx[b * N + i] : -1;
+                    double wgt;
+                    if (sel < 0) wgt = avg ? 1.0 / (double)S : 1.0;
+                    else if (avg) wgt = (sel == n_id) ? 1.0 / (double)S : 0.0;
+                    else wgt = (sel == n_id + k) ? 1.0 : 0.0;
+                    if (wgt == 0.0) continue;
+                    double g = gpix * wgt;
+                    if (mask_rec) g *= (double)mask_rec[b * N + i];
+                    if (g == 0.0) continue;
+                    float df = yb[i] - xb[i];
+                    double sg = (df > 0.f) ? -1.0 : ((df < 0.f) ? 1.0 : 0.0);
+                    gw[bc * N + i] += g * (no_ssim ? 1.0 : 0.15) * sg / 3.0;
+                    if (no_ssim) continue;
+                    /* the clamp decision is the fp32 forward's */
+                    win_t wf = window_stats(xb, yb, H, W, py, px);
+                    float raw;
+                    (void)ssim_from(&wf, C1, C2, &raw);
+                    if (!(raw >= 0.0f && raw <= 1.0f)) continue;
+                    win64_t w = window_stats64(xb, yb, H, W, py, px);
+                    dwin64_t p = ssim_partials64(&w);
+                    double gs = g * 0.85 / 3.0;
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        int yy = refl(py + dy, H);
+                        for (int dx = -1; dx <= 1; ++dx) {
+                            int xx = refl(px + dx, W);
+                            double a = xb[yy * W + xx], bq = yb[yy * W + xx];
+                            gw[bc * N + yy * W + xx] += gs * (p.dmux + 2.0 * a * p.dexx + bq * p.dexy) / 9.0;
+                        }
+                    }
+                }
+        }
+        }
+    }
+}
+
+/* gwarped [B,3,H,W] double -> gdisp [B,1,H,W] double (ACCUMULATED into), gT [B,4,4] double (overwritten) */
+MVFO_API void mvfo_warp_bwd_f64(const float *disp, const float *invK, const float *K, const float *T,
+                                const float *src, const double *gwarped, double *gdisp, double *gT,
+                                int B, int H, int W, float min_disp, float range, float eps)
+{
+    long N = (long)H * W;
+    float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    for (int b = 0; b < B; ++b) {
+        float P[12];
+        proj_matrix(K + b * 16, T + b * 16, P);
+        double Pd[12];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double a = 0.0;
+                for (int q = 0; q < 4; ++q) a += (double)K[b * 16 + i * 4 + q] * (double)T[b * 16 + q * 4 + j];
+                Pd[i * 4 + j] = a;
+            }
+        const float *iK = invK + b * 16;
+        double gP[12];
+        for (int k = 0; k < 12; ++k) gP[k] = 0.0;
+#pragma omp parallel
+        {
+            double lP[12];
+            for (int k = 0; k < 12; ++k) lP[k] = 0.0;
+#pragma omp for schedule(static)
+            for (int y = 0; y < H; ++y)
+                for (int x = 0; x < W; ++x) {
+                    long i = (long)y * W + x;
+                    /* the fp32 forward chain: the cell and the clipped-coordinate flags */
+                    float r[3], X[4], c[3];
+                    ray_of(iK, (float)x, (float)y, r);
+                    float scaled = min_disp + range * disp[b * N + i];
+                    float d = 1.0f / scaled;
+                    X[0] = d * r[0]; X[1] = d * r[1]; X[2] = d * r[2]; X[3] = 1.0f;
+                    for (int q = 0; q < 3; ++q) {
+                        float a = P[q * 4 + 0] * X[0];
+                        a = fmaf(P[q * 4 + 1], X[1], a);
+                        a = fmaf(P[q * 4 + 2], X[2], a);
+                        a = fmaf(P[q * 4 + 3], X[3], a);
+                        c[q] = a;
+                    }
+                    float z = c[2] + eps;
+                    float u = c[0] / z, v = c[1] / z;
+                    tap_t t = tap_of((u / wm1 - 0.5f) * 2.0f, (v / hm1 - 0.5f) * 2.0f, H, W);
+                    /* the same chain in double: values */
+                    double rd[3], Xd[4], cd[3];
+                    for (int q = 0; q < 3; ++q)
+                        rd[q] = (double)iK[q * 4 + 0] * x + (double)iK[q * 4 + 1] * y + (double)iK[q * 4 + 2];
+                    double dd = 1.0 / ((double)min_disp + (double)range * (double)disp[b * N + i]);
+                    Xd[0] = dd * rd[0]; Xd[1] = dd * rd[1]; Xd[2] = dd * rd[2]; Xd[3] = 1.0;
+                    for (int q = 0; q < 3; ++q)
+                        cd[q] = Pd[q * 4 + 0] * Xd[0] + Pd[q * 4 + 1] * Xd[1] + Pd[q * 4 + 2] * Xd[2] + Pd[q * 4 + 3];
+                    double zd = cd[2] + (double)eps, ud = cd[0] / zd, vd = cd[1] / zd;
+                    /* un-normalised sample position = (u, v) clipped to the image; weights inside the fp32 cell */
+                    double ix = ud < 0.0 ? 0.0 : (ud > (double)wm1 ? (double)wm1 : ud);
+                    double iy = vd < 0.0 ? 0.0 : (vd > (double)hm1 ? (double)hm1 : vd);
+                    double wx = ix - (double)t.x0, wy = iy - (double)t.y0;
+                    double gix = 0.0, giy = 0.0;
+                    for (int ch = 0; ch < 3; ++ch) {
+                        const float *im = src + ((long)(b * 3 + ch)) * N;
+                        double nw = im[t.y0 * W + t.x0], ne = im[t.y0 * W + t.x1];
+                        double sw = im[t.y1 * W + t.x0], se = im[t.y1 * W + t.x1];
+                        double g = gwarped[((long)(b * 3 + ch)) * N + i];
+                        gix += g * ((ne - nw) * (1.0 - wy) + (se - sw) * wy);
+                        giy += g * ((sw - nw) * (1.0 - wx) + (se - ne) * wx);
+                    }
+                    /* d(ix)/d(gx) * d(gx)/d(u) = (W-1)/2 * 2/(W-1) = 1 where the coordinate was not clipped */
+                    double gu = t.inx ? gix : 0.0, gv = t.iny ? giy : 0.0;
+                    double gc[3];
+                    gc[0] = gu / zd;
+                    gc[1] = gv / zd;
+                    gc[2] = -(gu * ud + gv * vd) / zd;
+                    double gd = 0.0;
+                    for (int j = 0; j < 3; ++j)
+                        gd += (gc[0] * Pd[0 * 4 + j] + gc[1] * Pd[1 * 4 + j] + gc[2] * Pd[2 * 4 + j]) * rd[j];
+                    for (int q = 0; q < 3; ++q)
+                        for (int j = 0; j < 4; ++j) lP[q * 4 + j] += gc[q] * Xd[j];
+                    gdisp[b * N + i] += -gd * dd * dd * (double)range;
+                }
+#pragma omp critical
+            for (int k = 0; k < 12; ++k) gP[k] += lP[k];
+        }
+        const float *Kb = K + b * 16;
+        for (int k = 0; k < 4; ++k)
+            for (int j = 0; j < 4; ++j) {
+                double a = 0.0;
+                for (int q = 0; q < 3; ++q) a += (double)Kb[q * 4 + k] * gP[q * 4 + j];
+                gT[b * 16 + k * 4 + j] = a;
+            }
+    }
+}
+
+/* grad of `scale * smooth(disp / (mean_hw(disp)+1e-7), img)` w.r.t. disp, ACCUMULATED into gdisp (double) */
+MVFO_API void mvfo_smooth_bwd_f64(const float *disp, const float *img, double *gdisp, int B, int H, int W,
+                                  int normalise, double scale)
+{
+    long N = (long)H * W;
+    double cx = scale / ((double)B * H * (W - 1));
+    double cy = scale / ((double)B * (H - 1) * W);
+    double *gn = (double *)malloc(sizeof(double) * N);
+    for (int b = 0; b < B; ++b) {
+        const float *d = disp + b * N;
+        const float *im = img + b * 3 * N;
+        float denom = 1.0f;
+        double denom_d = 1.0;
+        if (normalise) {
+            double m = 0.0;
+            for (long i = 0; i < N; ++i) m += d[i];
+            denom = (float)(m / (double)N) + 1e-7f;       /* the forward's (signs) */
+            denom_d = m / (double)N + 1e-7;
+        }
+#pragma omp parallel for schedule(static)
+        for (int y = 0; y < H; ++y)
+            for (int x = 0; x < W; ++x) {
+                long i = (long)y * W + x;
+                double acc = 0.0;
+#define MVFO_SM_TERM(j_, i_, c_, sign_)                                                                       \
+                {                                                                                              \
+                    float df = d[j_] / denom - d[i_] / denom;                                                  \
+                    double gi = ((fabs((double)im[j_] - (double)im[i_]) +                                      \
+                                  fabs((double)im[N + (j_)] - (double)im[N + (i_)])) +                         \
+                                 fabs((double)im[2 * N + (j_)] - (double)im[2 * N + (i_)])) / 3.0;             \
+                    double sg = (df > 0.f) ? 1.0 : ((df < 0.f) ? -1.0 : 0.0);                                  \
+                    acc += (sign_) * (c_) * exp(-gi) * sg;                                                     \
+                }
+                if (y >= 1) MVFO_SM_TERM(i - W, i, cy, -1.0)
+                if (x >= 1) MVFO_SM_TERM(i - 1, i, cx, -1.0)
+                if (x + 1 < W) MVFO_SM_TERM(i, i + 1, cx, 1.0)
+                if (y + 1 < H) MVFO_SM_TERM(i, i + W, cy, 1.0)
+#undef MVFO_SM_TERM
+                gn[i] = acc;
+            }
+        if (normalise) {
+            double dot = 0.0;
+            for (long i = 0; i < N; ++i) dot += gn[i] * (double)d[i];
+            double corr = dot / (denom_d * denom_d) / (double)N;
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < N; ++i) gdisp[b * N + i] += gn[i] / denom_d - corr;
+        } else {
+#pragma omp parallel for schedule(static)
+            for (long i = 0; i < N; ++i) gdisp[b * N + i] += gn[i];
+        }
+    }
+    free(gn);
+}

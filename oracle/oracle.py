@@ -228,10 +228,43 @@ def pose(axisangle, translation, invert=False):
     return M
 
 
+_dp = C.POINTER(C.c_double)
+
+
+def _pd(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def unit_grads_f64(disp, tgt, src, T, K, inv_K, warped, idx, mask_rec=None, flags=0, smoothness=1e-3,
+                   min_depth=0.1, max_depth=100.0, gloss=1.0, eps=1e-7):
+    """The adjoint of a unit evaluated in DOUBLE (mvfo_*_bwd_f64: every decision -- argmin `idx`, bilinear cell, clamp,
+    signs -- is the fp32 forward's, every value is formed in double): grad_disp [B,1,H,W] float64, grad_T [S,B,4,4]
+    float64.  `warped`, `idx`: what `unit()` returned for the same inputs."""
+    disp, tgt, inv_K, K = _f(disp), _f(tgt), _f(inv_K), _f(K)
+    warped = [_f(w) for w in warped]
+    S = len(warped)
+    B, _, H, W = tgt.shape
+    mask = _f(mask_rec) if mask_rec is not None else None
+    idx = np.ascontiguousarray(idx, np.int32)
+    gw = [np.empty((B, 3, H, W), np.float64) for _ in range(S)]
+    lib().mvfo_losses_base_bwd_f64(_p(tgt), _ptr_array(warped), _pi(idx), _p(mask), S, int(flags), C.c_double(gloss),
+                                   (_dp * S)(*[a.ctypes.data_as(_dp) for a in gw]), B, H, W)
+    md, rg = depth_consts(min_depth, max_depth)
+    gdisp = np.zeros((B, 1, H, W), np.float64)
+    gT = np.empty((S, B, 4, 4), np.float64)
+    for k in range(S):
+        Tk, sk = _f(T[k]), _f(src[k])
+        lib().mvfo_warp_bwd_f64(_p(disp), _p(inv_K), _p(K), _p(Tk), _p(sk), _pd(gw[k]), _pd(gdisp), _pd(gT[k]),
+                                B, H, W, C.c_float(md), C.c_float(rg), C.c_float(eps))
+    lib().mvfo_smooth_bwd_f64(_p(disp), _p(tgt), _pd(gdisp), B, H, W, 1, C.c_double(gloss * smoothness))
+    return gdisp, gT
+
+
 def unit(disp, tgt, src, T, K, inv_K, noise=None, mask_rec=None, flags=0,
-         smoothness=1e-3, min_depth=0.1, max_depth=100.0, want_grads=False, gloss=1.0):
+         smoothness=1e-3, min_depth=0.1, max_depth=100.0, want_grads=False, gloss=1.0, adjoint64=False):
     """One hot-path unit end to end: S x generate_images_pred + compute_losses_base
-    (reference train.py:956-1051).  src [S,B,3,H,W], T [S,B,4,4]."""
+    (reference train.py:956-1051).  src [S,B,3,H,W], T [S,B,4,4].  `adjoint64` (with `want_grads`): also
+    `grad_disp64`, `grad_T64` -- the same adjoint evaluated in double (`unit_grads_f64`)."""
     S = len(src)
     w = [warp_fwd(disp, inv_K, K, T[k], src[k], min_depth, max_depth) for k in range(S)]
     warped = [x["warped"] for x in w]
@@ -254,6 +287,10 @@ def unit(disp, tgt, src, T, K, inv_K, noise=None, mask_rec=None, flags=0,
             gT.append(g)
         gdisp = smooth_bwd(disp, tgt, gloss * smoothness, True, gdisp)
         out.update(grad_disp=gdisp, grad_T=np.stack(gT, 0), grad_warped=gw)
+        if adjoint64:
+            g64, t64 = unit_grads_f64(disp, tgt, src, T, K, inv_K, warped, fw["idx"] if fw["idx"] is not None else None,
+                                      mask_rec, flags, smoothness, min_depth, max_depth, gloss)
+            out.update(grad_disp64=g64, grad_T64=t64)
     return out
 
 
