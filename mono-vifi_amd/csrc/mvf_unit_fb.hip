@@ -49,6 +49,13 @@
 #ifndef MVF_FB_TH
 #define MVF_FB_TH 16
 #endif
+#ifndef MVF_FB_PACKROWS_WARP
+#define MVF_FB_PACKROWS_WARP 0   // 1 = warp phase: (west, east) x (west weight, east weight) as ONE packed multiply per loaded tap row,
+                                 // the four products summed as scalars (pinned); 0: scalar products, which the compiler pairs
+                                 // across the two sources (18 register moves per position).  Same products, same order of sums.
+                                 // Measured (alternating 200-step A/B, three rounds): 54 moves fewer per lane, NO change in time
+                                 // (362.6 vs 363.2 us) -- the static cost model over-prices register moves; off.
+#endif
 #ifndef MVF_FB_PACKROWS
 #define MVF_FB_PACKROWS 0     // 1: tap rows x weight pairs as packed multiplies.  Measured (profiles/r03_unit_kernel_variants.log):
                               // +0.8 % VALU instructions -- the compiler pairs the sums of the two sources instead and
@@ -100,7 +107,9 @@ struct FbArgs {
 // serially and dividing twice, 24 lanes re-multiplying K @ T -- behind a chain of five dependent memory round
 // trips (kernel arguments -> unit descriptor -> partials pointer -> partials -> ...) in front of its first barrier.
 struct ImgTab {
-    float P[2][12];       // (K @ T)[:3] per source (the second source's copy of the first when S == 1)
+    float P[12][2];       // (K @ T)[:3], the two sources' entries side by side (S == 1: the first source's twice): a workgroup
+                          // reads them as the twelve packed pairs it computes with (stored per source they cost 18 register
+                          // moves per load to interleave, twice per lane)
     float mean, den, rden;   // mean disparity, mean + 1e-7, 1 / den
     float pad[5];
 };
@@ -119,7 +128,7 @@ inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(ImgTab) + MVF_
 MVF_DEV void load_pose_pair(const ImgTab &sh, int ka, int kb, f2 P2[12])
 {
 #pragma unroll
-    for (int i = 0; i < 12; ++i) P2[i] = mk2(sh.P[ka][i], sh.P[kb][i]);
+    for (int i = 0; i < 12; ++i) P2[i] = mk2(sh.P[i][ka], sh.P[i][kb]);
 }
 // workgroup -> tile with the launcher's reciprocals (mg = floor(2^32 / d) + 1: exact for n * d < 2^32, which the
 // launcher checks; mg == 0 stands for d == 1).  Three 32-bit integer divisions on the scalar unit -- a v_rcp round trip
@@ -525,11 +534,15 @@ MVF_DEV void warp_finish(const WarpCtx &k, const WarpBatch<U> &w)
         row_weights(w.s[u].qb, wbt, wbb);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-#if MVF_FB_PACKROWS
+#if MVF_FB_PACKROWS_WARP
             const f2 ta = mk2(w.a0[u][ch].x, w.a0[u][ch].y) * wat, ba = mk2(w.a1[u][ch].x, w.a1[u][ch].y) * wab;
             const f2 tb = mk2(w.b0[u][ch].x, w.b0[u][ch].y) * wbt, bb = mk2(w.b1[u][ch].x, w.b1[u][ch].y) * wbb;
-            const float va = ((ta.x + ta.y) + ba.x) + ba.y;
-            const float vb = ((tb.x + tb.y) + bb.x) + bb.y;
+            float va = ((ta.x + ta.y) + ba.x) + ba.y;
+            float vb = ((tb.x + tb.y) + bb.x) + bb.y;
+            // (pins the two sums as scalars: the SLP vectoriser otherwise pairs them ACROSS the sources again and pays
+            // three register moves per tap row to interleave the loaded pairs -- why round 3 measured this form at +0.8 %)
+            asm volatile("" : "+v"(va));
+            asm volatile("" : "+v"(vb));
 #else
             const float va = w.a0[u][ch].x * wat.x + w.a0[u][ch].y * wat.y + w.a1[u][ch].x * wab.x + w.a1[u][ch].y * wab.y;
             const float vb = w.b0[u][ch].x * wbt.x + w.b0[u][ch].y * wbt.y + w.b1[u][ch].x * wbb.x + w.b1[u][ch].y * wbb.y;
@@ -1029,6 +1042,23 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             for (int j = 0; j < PX; ++j) gp[j] = gw[j];
         }
     }
+#ifndef MVF_FB_PREFETCH7
+#define MVF_FB_PREFETCH7 0     // experiment: the tap rows of a lane's FIRST adjoint position requested before the barrier that ends the
+                               // SSIM adjoint (their offsets have been in registers since phase 3), unconditionally
+#endif
+#if MVF_FB_PREFETCH7 && MVF_FB_KEEPTAPS && !defined(MVF_ABL_NO7) && !defined(MVF_ABL_FB_LDSTAPS)
+    float2 pra0[3], pra1[3], prb0[3], prb1[3];
+    {
+        const unsigned W4p = (unsigned)W * 4u;
+        const unsigned pa0 = stash[0].oa & kOffMask, pa1 = pa0 + ((stash[0].oa & (1u << 29)) ? W4p : 0u);
+        const unsigned pb0 = stash[0].ob & kOffMask, pb1 = pb0 + ((stash[0].ob & (1u << 29)) ? W4p : 0u);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            pra0[ch] = ldg2_at(sa + ch * N, pa0); pra1[ch] = ldg2_at(sa + ch * N, pa1);
+            prb0[ch] = ldg2_at(sb + ch * N, pb0); prb1[ch] = ldg2_at(sb + ch * N, pb1);
+        }
+    }
+#endif
     __syncthreads();      // every grad_warped is parked
 
     // ---- 7 + 8: bilinear + projection adjoint, smoothness value + gradient, store grad_disp.
@@ -1154,6 +1184,12 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 float2 ra0[3], ra1[3], rb0[3], rb1[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
+#if MVF_FB_PREFETCH7 && MVF_FB_KEEPTAPS
+                    if (k == 0) {
+                        ra0[ch] = pra0[ch]; ra1[ch] = pra1[ch]; rb0[ch] = prb0[ch]; rb1[ch] = prb1[ch];
+                        continue;
+                    }
+#endif
                     ra0[ch] = ldg2_at(sa + ch * N, qa.o0); ra1[ch] = ldg2_at(sa + ch * N, qa.o1);
                     rb0[ch] = ldg2_at(sb + ch * N, qb.o0); rb1[ch] = ldg2_at(sb + ch * N, qb.o1);
                 }
@@ -1178,8 +1214,22 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 }
             }
 #endif
+#ifndef MVF_FB_SCALAR_GI
+#define MVF_FB_SCALAR_GI 0     // 1 = the bilinear adjoint per source as pinned scalars (0: packed over the two sources, which costs twelve
+                               // register moves per position to pair the tap derivatives that come out of separate loads);
+                               // measured together with MVF_FB_PACKROWS_WARP: no change in time; off
+#endif
+#if MVF_FB_SCALAR_GI
+            float gixa = fmaf(g2.x, dxa[2], fmaf(g1.x, dxa[1], g0.x * dxa[0]));
+            float gixb = fmaf(g2.y, dxb[2], fmaf(g1.y, dxb[1], g0.y * dxb[0]));
+            float giya = fmaf(g2.x, dya[2], fmaf(g1.x, dya[1], g0.x * dya[0]));
+            float giyb = fmaf(g2.y, dyb[2], fmaf(g1.y, dyb[1], g0.y * dyb[0]));
+            asm volatile("" : "+v"(gixa), "+v"(gixb), "+v"(giya), "+v"(giyb));      // (keeps the SLP vectoriser from re-pairing them)
+            const f2 gix = mk2(gixa, gixb), giy = mk2(giya, giyb);
+#else
             const f2 gix = pk_fma(g2, mk2(dxa[2], dxb[2]), pk_fma(g1, mk2(dxa[1], dxb[1]), g0 * mk2(dxa[0], dxb[0])));
             const f2 giy = pk_fma(g2, mk2(dya[2], dyb[2]), pk_fma(g1, mk2(dya[1], dyb[1]), g0 * mk2(dya[0], dyb[0])));
+#endif
             // adjoint of unnormalise / normalise ((W-1)/2 * 2/(W-1) = 1) and of the perspective
             // divide; tolerance arithmetic: one reciprocal of z per source (see warp_point_bwd)
             const f2 gu = mk2(w.ta.inx ? gix.x : 0.0f, w.tb.inx ? gix.y : 0.0f);
@@ -1328,7 +1378,7 @@ __global__ void __launch_bounds__(256) k_units_prepare(FbArgs a, int S, unsigned
     __syncthreads();
     if (t < 24) {
         const int k = (t < 12 || S < 2) ? 0 : 1, e = t < 12 ? t : t - 12;
-        tb.P[t < 12 ? 0 : 1][e] = proj_entry(u.K + b * 16, u.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
+        tb.P[e][t < 12 ? 0 : 1] = proj_entry(u.K + b * 16, u.T + ((size_t)k * a.B + b) * 16, e >> 2, e & 3);
     } else if (t == 32) {
         float m = 0.0f;
         for (int i = 0; i < NMEAN; ++i) m += parts[i];
