@@ -132,9 +132,9 @@ class DepthDecoder(nn.Module):
                 if ops.pad_act_ok(pend[0], *pend[0].shape[-2:]):
                     xp = ops.reflect_pad1_act(pend[0], pend[1])
                 else:
-                    if i > 0:
-                        pend = (pend[0].clone(), pend[1])      # (settle works in place; the next level still needs y)
-                    xp = ops.reflect_pad1(settle(pend))
+                    # settle works in place and the next level (i > 0) applies the epilogue to the RAW output on its own
+                    # load: activate a copy, leave `pend` raw (rebinding `pend` to the clone ran it twice)
+                    xp = ops.reflect_pad1(settle((pend[0].clone(), pend[1])) if i > 0 else settle(pend))
                 x_logit = ops.bias_act(raw_conv(dc, xp), dc.bias, "none", None, None, inplace=True)
             if i in self.scales:
                 logit = x_logit if defer else self._blk("dispconv", i)(x)

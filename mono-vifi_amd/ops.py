@@ -1311,7 +1311,10 @@ class HeadSink:
 
 def pad_act_ok(x_like, H, W):
     """The fused pad + bias + ELU kernels take wide shapes only (W % 4 == 0, W >= 8, H >= 4, 16-byte aligned)."""
-    return bool(x_like.is_cuda and x_like.dtype == torch.float32 and x_like.is_contiguous() and
+    # (planes: the adjoint kernels put B x C in grid.y -- ADVICE r05: the forward accepted more and the backward then
+    # failed mid-step; beyond the limit the separate epilogue + pad kernels run)
+    planes = x_like.shape[0] * x_like.shape[1] if x_like.dim() == 4 else 1 << 30
+    return bool(x_like.is_cuda and x_like.dtype == torch.float32 and x_like.is_contiguous() and planes <= 65535 and
                 x_like.data_ptr() % 16 == 0 and nat.lib().mvf_pad_act_supported(int(H), int(W)))
 
 

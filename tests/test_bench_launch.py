@@ -26,6 +26,55 @@ def _line(out):
     return json.loads(lines[0])
 
 
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def test_the_line_is_small_flat_and_last_on_stdout():
+    """the driver keeps a bounded tail of stdout; a 20.8 KB line was not parsed.  The line is one
+    JSON object under 4 KB, the LAST line on stdout, with the contract's keys; `config` names the workload in at most
+    200 characters; nothing in it is nested deeper than two levels."""
+    for gpus in (1, 8):
+        r = _run(["--gpus", str(gpus), "--workload", "mock", "--steps", "3", "--warmup", "1", "--batch", "2"],
+                 {"MVF_DIST_BACKEND": "gloo", "OMP_NUM_THREADS": "1"}, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        last = r.stdout.rstrip("\n").splitlines()[-1]
+        assert last.startswith("{") and len(last.encode()) < 4096, len(last)
+        d = json.loads(last)
+        assert json.loads(json.dumps(d)) == d
+        for k in REQUIRED_KEYS:
+            assert k in d, k
+        assert d["n_gpus"] == gpus and len(d["config"]["workload"]) <= 200
+        assert set(d["config"]) == {"workload", "global_batch", "parallelism"}
+
+        def depth(o):
+            return 1 + max([depth(v) for v in o.values()] + [0]) if isinstance(o, dict) else 0
+        assert depth(d) <= 3, depth(d)
+
+
+def test_an_oversized_line_is_refused():
+    """bench.emit() is the only place the line is printed, and it asserts the size bound."""
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mvf_bench_under_test", os.path.join(ROOT, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.LINE_LIMIT == 4096
+    with pytest.raises(AssertionError):
+        b.emit(json.dumps({"x": "y" * 5000}))
+
+
+def test_the_default_run_has_no_detail_legs():
+    """The driver's default command runs the headline, the hot-path leg, the live counters and the CPU baseline only;
+    the child-process legs live in tools/measure_detail.py behind --detail."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert len(src.splitlines()) < 700
+    for name in ("def mfma_leg", "def host_leg", "def graph_step_leg", "def other_config_leg", "cpu_baseline_unfused"):
+        assert name not in src
+    a = __import__("subprocess").run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert "--detail" in a.stdout
+
+
 def test_gpus_2_spawns_two_ranks_and_reports_the_group():
     r = _run(["--gpus", "2", "--workload", "mock", "--steps", "4", "--warmup", "1", "--batch", "4"],
              {"MVF_DIST_BACKEND": "gloo"})

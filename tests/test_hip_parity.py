@@ -1648,3 +1648,38 @@ def test_decoder_epilogue_inside_the_pad_kernels(dev):
     assert float((res[True][0] - res[False][0]).abs().max()) <= 1e-6
     for a, b_ in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
         assert float((a - b_).norm()) <= 1e-5 * float(b_.norm())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("narrow", [False, True])
+def test_decoder_deferred_epilogue_with_four_scales(dev, narrow, monkeypatch):
+    """with num_scales > 1 a ConvBlock output has TWO consumers (the disparity convolution's pad and
+    the next level).  When the fused pad + epilogue kernel is refused (MVF_PAD_NARROW, tiny planes) the disparity branch
+    must activate a COPY and leave the raw output to the next level -- rebinding it ran bias + ELU twice (wrong features
+    in eval, an autograd version error in training).  All four scales, forward and backward, against the un-deferred
+    decoder; with the wide kernels allowed and refused, and at a shape whose coarse levels are refused anyway."""
+    from mono_vifi_amd.networks import monodepth2
+    if narrow:
+        monkeypatch.setenv("MVF_PAD_NARROW", "1")
+    torch.manual_seed(9)
+    for (Hh, Ww) in ((96, 160), (32, 48)):
+        dec = monodepth2.DepthDecoder([64, 64, 128, 256, 512], range(4)).to(dev)
+        feats = [torch.randn(2, c, max(1, Hh >> i), max(1, Ww >> i), device=dev) for i, c in enumerate([64, 64, 128, 256, 512])]
+        res = {}
+        for flag in (True, False):
+            monodepth2.FUSE_EPILOGUE_INTO_PAD = flag
+            try:
+                fs = [f.clone().requires_grad_(True) for f in feats]
+                dec.zero_grad()
+                out = dec(fs, 0.1, 100.0)
+                loss = sum((out[("disp", i)] * torch.linspace(0, 1, out[("disp", i)].shape[-1], device=dev)).sum()
+                           for i in range(4))
+                loss.backward()
+                res[flag] = ([out[("disp", i)].detach().clone() for i in range(4)], [f.grad.clone() for f in fs],
+                             [p.grad.clone() for p in dec.parameters()])
+            finally:
+                monodepth2.FUSE_EPILOGUE_INTO_PAD = True
+        for a, b_ in zip(res[True][0], res[False][0]):
+            assert float((a - b_).abs().max()) <= 2e-6
+        for a, b_ in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+            assert float((a - b_).norm()) <= 1e-5 * float(b_.norm())
