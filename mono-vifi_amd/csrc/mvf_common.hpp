@@ -469,11 +469,7 @@ MVF_DEV f2 div_core(f2 n, f2 d, f2 r1)
 // guard-free IEEE core; MVF_FAST_SSIM = v_rcp and one multiply
 MVF_DEV f2 ssim_recip(f2 d)
 {
-#ifdef MVF_FAST_SSIM
-    return mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
-#else
-    return recip_refined(d);
-#endif
+    return recip_refined(d);              // v_rcp + one Newton step; in fast mode the quotient is then ONE multiply
 }
 MVF_DEV f2 ssim_quot(f2 n, f2 d, f2 r1)
 {

@@ -242,6 +242,15 @@ MVF_DEV void window_xp(const f2 *__restrict__ xs, const float *__restrict__ ys, 
 // reference: layers.py:281-290 for a candidate pair -- literal expression order per lane
 MVF_DEV f2 ssim_raw_pk(f2 mu_x, f2 mu_y, f2 exx, f2 eyy, f2 exy)
 {
+#ifdef MVF_FAST_SSIM     // opt-in fast mode: the same formula contracted (mvf_unit_fb.hip: ssim_val_partials_pk)
+    {
+        const f2 mxx = mu_x * mu_x, myy = mu_y * mu_y, mxy = mu_x * mu_y;
+        const f2 A1 = pk_fma(f2s(2.0f), mxy, f2s(kC1)), A2 = pk_fma(f2s(2.0f), exy - mxy, f2s(kC2));
+        const f2 B1 = (mxx + myy) + f2s(kC1), B2 = ((exx - mxx) + (eyy - myy)) + f2s(kC2);
+        const f2 dd = B1 * B2;
+        return pk_fma(ssim_quot(A1 * A2, dd, ssim_recip(dd)), f2s(-0.5f), f2s(0.5f));
+    }
+#endif
     f2 sigma_x = exx - mu_x * mu_x;
     f2 sigma_y = eyy - mu_y * mu_y;
     f2 sigma_xy = exy - mu_x * mu_y;

@@ -37,33 +37,12 @@
 // Addressing: every image base is wave-uniform (blockIdx) and held in scalar registers; pixels
 // and taps are 32-bit byte offsets from it (scalar-base global loads, 24-bit multiplies) -- round
 // 2's ISA spent 236 64-bit VALU address instructions, partly quarter rate, on the same accesses.
-#ifndef MVF_FB_TW
-#define MVF_FB_TW 32
-#endif
-#ifndef MVF_FB_PX
-#define MVF_FB_PX 2
-#endif
-#ifndef MVF_FB_WAVES
-#define MVF_FB_WAVES (MVF_FB_PX == 2 ? 4 : 2)      // launch bound: waves per SIMD the register budget must allow
-#endif
-#ifndef MVF_FB_TH
-#define MVF_FB_TH 16
-#endif
-#ifndef MVF_FB_PACKROWS_WARP
-#define MVF_FB_PACKROWS_WARP 0   // 1 = warp phase: (west, east) x (west weight, east weight) as ONE packed multiply per loaded tap row,
-                                 // the four products summed as scalars (pinned); 0: scalar products, which the compiler pairs
-                                 // across the two sources (18 register moves per position).  Same products, same order of sums.
-                                 // Measured (alternating 200-step A/B, three rounds): 54 moves fewer per lane, NO change in time
-                                 // (362.6 vs 363.2 us) -- the static cost model over-prices register moves; off.
-#endif
-#ifndef MVF_FB_PACKROWS
-#define MVF_FB_PACKROWS 0     // 1: tap rows x weight pairs as packed multiplies.  Measured (profiles/r03_unit_kernel_variants.log):
-                              // +0.8 % VALU instructions -- the compiler pairs the sums of the two sources instead and
-                              // pays register moves either way; the scalar products with the swapped weight pair win
-#endif
-#define MVF_TILE_TW MVF_FB_TW
-#define MVF_TILE_PX MVF_FB_PX
-#define MVF_TILE_TH MVF_FB_TH
+// geometry (mvf_tile.hpp): 32 x 16 region, 2 px per lane, 256 lanes; the register budget must allow 4 waves per SIMD.
+// (What other geometries measured: HISTORY.md, "Why this geometry".)
+#define MVF_TILE_TW 32
+#define MVF_TILE_PX 2
+#define MVF_TILE_TH 16
+#define MVF_FB_WAVES 4
 #include "mvf_tile.hpp"
 
 namespace {
@@ -121,10 +100,7 @@ constexpr int TABF = sizeof(ImgTab) / sizeof(float);
 constexpr int FB_TGT = 0, FB_PAIR = 3 * PLANE, FB_DISP = FB_PAIR + 6 * PLANE,
               FB_COEF = FB_DISP + PLANE, FB_POSE = FB_COEF + 6 * RPLANE;
 static_assert((NT / 16) * NRED <= 6 * RPLANE, "the final reduction parks its row sums in the (then free) coefficient planes");
-#ifndef MVF_FB_EXTRA_LDS
-#define MVF_FB_EXTRA_LDS 0     // occupancy experiments: pad the workgroup's LDS
-#endif
-inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(ImgTab) + MVF_FB_EXTRA_LDS; }
+inline size_t fb_smem() { return FB_POSE * sizeof(float) + sizeof(ImgTab); }
 MVF_DEV void load_pose_pair(const ImgTab &sh, int ka, int kb, f2 P2[12])
 {
 #pragma unroll
@@ -139,20 +115,8 @@ MVF_DEV TileId tile_of_block_mg(int tiles_x, int tiles_y, int B, uint32_t mg_tx,
     const int total = tiles_x * tiles_y * B;
     const int lin = blockIdx.x;
     const int xcd = lin & 7, slot = lin >> 3;
-#ifndef MVF_FB_XCD_MAP
-#define MVF_FB_XCD_MAP 0      // 0: every XCD owns ONE contiguous run of tiles; 1: tile = workgroup index (consecutive tiles on
-                              // consecutive XCDs); k >= 2: runs of 2^k tiles dealt round robin to the XCDs
-#endif
-#if MVF_FB_XCD_MAP == 1
-    const int vid = lin;
-#elif MVF_FB_XCD_MAP >= 2
-    constexpr int LG = MVF_FB_XCD_MAP;
-    const int full = total & ~((8 << LG) - 1);
-    const int vid = lin < full ? ((((slot >> LG) << 3) + xcd) << LG) + (slot & ((1 << LG) - 1)) : lin;
-#else
     const int q = total >> 3, r = total & 7;
     const int vid = xcd * q + min(xcd, r) + slot;
-#endif
     TileId t;
     const int rest = div_magic(vid, mg_tx);
     t.bx = vid - rest * tiles_x;
@@ -205,15 +169,26 @@ MVF_DEV f2 clamp01_med3_pk(f2 v)
 MVF_DEV void ssim_val_partials_pk(f2 mx, f2 my, f2 exx, f2 eyy, f2 exy, f2 &val, f2 &dmux, f2 &dexx2,
                                   f2 &dexy)
 {
+#ifdef MVF_FAST_SSIM     // contracted: every a * b + c of the formula is one fused multiply-add
+    const f2 mxx = mx * mx, myy = my * my, mxy = mx * my;
+    f2 sigma_x = exx - mxx, sigma_y = eyy - myy, sigma_xy = exy - mxy;
+    f2 A1 = pk_fma(f2s(2.0f), mxy, f2s(kC1)), A2 = pk_fma(f2s(2.0f), sigma_xy, f2s(kC2));
+    f2 B1 = (mxx + myy) + f2s(kC1), B2 = (sigma_x + sigma_y) + f2s(kC2);
+#else
     f2 sigma_x = exx - mx * mx, sigma_y = eyy - my * my, sigma_xy = exy - mx * my;
     f2 A1 = 2.0f * mx * my + f2s(kC1), A2 = 2.0f * sigma_xy + f2s(kC2);
     f2 B1 = mx * mx + my * my + f2s(kC1), B2 = sigma_x + sigma_y + f2s(kC2);
+#endif
     f2 n = A1 * A2, d = B1 * B2;
     // d >= C1*(C2 - rounding) > 0 and |n|, d = O(1) for images in [0,1]: the guard-free
     // division core gives the correctly rounded quotient (see mvf_common.hpp)
     const f2 r1 = ssim_recip(d);
     const f2 q = ssim_quot(n, d, r1);
+#ifdef MVF_FAST_SSIM
+    const f2 raw = pk_fma(q, f2s(-0.5f), f2s(0.5f));
+#else
     const f2 raw = (f2s(1.0f) - q) / 2.0f;
+#endif
     val = clamp01_med3_pk(raw);
     // the clamp passes the gradient where it changed nothing (NaN compares unequal: no gradient)
     const f2 live = mk2(val.x == raw.x ? 1.0f : 0.0f, val.y == raw.y ? 1.0f : 0.0f);
@@ -257,16 +232,9 @@ MVF_DEV f2 tstat_of(const f2 tm[PX], int j) { return j == 0 ? mk2(tm[0].x, tm[1]
 // (a NaN operand yields the minimum of the others: -1 -- the compare form gave 0; a NaN difference only arises from
 // a NaN image, which poisons the loss anyway).  Two full-rate multiplies + one half-rate op instead of two compares
 // and two selects (tools/valu_ubench.hip: 3.7 vs 6.8 ns of issue time per value).
-#ifndef MVF_FB_SIGN_MED3
-#define MVF_FB_SIGN_MED3 1
-#endif
 MVF_DEV float sign_of(float v)
 {
-#if MVF_FB_SIGN_MED3
     return __builtin_amdgcn_fmed3f((v * 0x1p127f) * 0x1p127f, -1.0f, 1.0f);
-#else
-    return (v > 0.0f) ? 1.0f : ((v < 0.0f) ? -1.0f : 0.0f);
-#endif
 }
 
 struct Stats4X {
@@ -274,6 +242,52 @@ struct Stats4X {
     f2 xc[PX];
     float yc[PX];
 };
+#ifdef MVF_FAST_SSIM
+// Fast mode (opt-in build, never the default, never in the parity suite): what the reference's evaluation order
+// (layers.py:277-290: nine taps row-major, products rounded before they are summed) costs on this chip is measured
+// against THIS form -- separable 3x3 sums: the three rows of a column first (products folded in by fused
+// multiply-adds), then the horizontal 3-sums of the lane's two outputs with the middle column pair shared.  Per channel
+// and candidate pair: 41 packed operations for the three window sums of two pixels instead of 72; the target's sums
+// likewise.  Same quantities up to rounding (a few ulp of the sums): argmin / auto-mask may flip where candidates
+// nearly tie; the integer sampling indices are untouched (tools/fast_mode_report.py).
+MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X &o, TStat2 *t = nullptr)
+{
+    static_assert(PX == 2, "fast-mode window sums: two pixels per lane");
+    f2 cx[RW], cxx[RW], cxy[RW];
+    float cy[RW], cyy[RW];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        Row6P x = load_row6p(xs + r * LDW);
+        Row6 y = load_row6(ys + r * LDW);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            if (r == 0) {
+                cx[i] = x.v[i]; cxx[i] = x.v[i] * x.v[i]; cxy[i] = x.v[i] * f2s(y.v[i]);
+                cy[i] = y.v[i]; cyy[i] = y.v[i] * y.v[i];
+            } else {
+                cx[i] = cx[i] + x.v[i];
+                cxx[i] = pk_fma(x.v[i], x.v[i], cxx[i]);
+                cxy[i] = pk_fma(x.v[i], f2s(y.v[i]), cxy[i]);
+                cy[i] = cy[i] + y.v[i];
+                cyy[i] = fmaf(y.v[i], y.v[i], cyy[i]);
+            }
+        }
+        if (r == 1) {
+#pragma unroll
+            for (int j = 0; j < PX; ++j) { o.xc[j] = x.v[j + 1]; o.yc[j] = y.v[j + 1]; }
+        }
+    }
+    const f2 mx = cx[1] + cx[2], mxx = cxx[1] + cxx[2], mxy = cxy[1] + cxy[2];
+    o.sx[0] = cx[0] + mx; o.sx[1] = mx + cx[3];
+    o.sxx[0] = cxx[0] + mxx; o.sxx[1] = mxx + cxx[3];
+    o.sxy[0] = cxy[0] + mxy; o.sxy[1] = mxy + cxy[3];
+    if (t) {
+        const float my = cy[1] + cy[2], myy = cyy[1] + cyy[2];
+        t->sy = mk2(cy[0] + my, my + cy[3]);
+        t->syy = mk2(cyy[0] + myy, myy + cyy[3]);
+    }
+}
+#else
 MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X &o, TStat2 *t = nullptr)
 {
 #pragma unroll
@@ -308,6 +322,7 @@ MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, S
         }
     }
 }
+#endif
 MVF_DEV void stash_tstats(f2 *__restrict__ statP, const f2 my[PX])
 {
     float4 *p = reinterpret_cast<float4 *>(statP);
@@ -328,8 +343,24 @@ MVF_DEV void fetch_tstats(const f2 *__restrict__ statP, f2 my[PX])
 MVF_DEV void target_stats(const float *__restrict__ ys, f2 my[PX])
 {
     TStat2 t;
+#ifdef MVF_FAST_SSIM
+    float cy[RW], cyy[RW];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const Row6 y = load_row6(ys + r * LDW);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            cy[i] = r == 0 ? y.v[i] : cy[i] + y.v[i];
+            cyy[i] = r == 0 ? y.v[i] * y.v[i] : fmaf(y.v[i], y.v[i], cyy[i]);
+        }
+    }
+    const float m = cy[1] + cy[2], mm = cyy[1] + cyy[2];
+    t.sy = mk2(cy[0] + m, m + cy[3]);
+    t.syy = mk2(cyy[0] + mm, mm + cyy[3]);
+#else
 #pragma unroll
     for (int r = 0; r < 3; ++r) tstat_row(load_row6(ys + r * LDW), r == 0, t);
+#endif
     my[0] = div9(t.sy);        // (mu_y px0, mu_y px1)
     my[1] = div9(t.syy);       // (E[yy] px0, E[yy] px1)
 }
@@ -374,32 +405,15 @@ MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restric
 // warp of the source pair into the pair planes: plane positions tid + k*NT, k < NSTAGE.  Full
 // iterations take U positions at a time (their divide chains interleave, all taps in flight);
 // the last position runs alone, and waves whose positions all lie beyond the plane skip it.
-#ifndef MVF_FB_LDS_REDUCE
-#define MVF_FB_LDS_REDUCE 1   // final reduction of the 27 tile partials through an LDS transpose (0: DPP row sums)
-#endif
-#ifndef MVF_FB_KEEPTAPS
-#define MVF_FB_KEEPTAPS 1     // the adjoint takes the forward's taps from registers (0: re-runs the projection chain)
-#endif
 
 // What phase 7 needs of the forward's projection chain at an output pixel, kept in SIX registers per
 // position: per source the byte offset of the row-y0 tap pair (< 2^28) with four flags above it (pair
 // anchored one pixel left, row y1 below y0, x / y strictly inside) and the fractional tap position (two floats).
 // For this to work a lane must warp in phase 3 the pixels whose adjoint it evaluates in phases 7 + 8: the warp
 // walks the 30 x 14 interior first, in the lane order of phase 7, then the border ring of the 34 x 18 plane.
-#ifndef MVF_FB_STASH_F32
-#define MVF_FB_STASH_F32 1    // 0: the fractional positions as two 16-bit fixed-point numbers per source (round 4: four
-                              // registers per position).  Round 5 measured both against the adjoint evaluated in double
-                              // (tools/grad_vs_f64_adjoint.py): the same worst pixels either way -- the 1.5e-5 of a
-                              // truncated weight is not what separates fp32 evaluations -- and the float form is 0.9 %
-                              // FASTER (no pack / unpack conversions: 1,721 -> 1,705 instr/px, 123 VGPRs)
-#endif
 struct TapStash {
     uint32_t oa, ob;
-#if MVF_FB_STASH_F32
     float wxa, wya, wxb, wyb;
-#else
-    uint32_t wa, wb;
-#endif
 };
 constexpr uint32_t kOffMask = 0x0fffffffu;
 MVF_DEV uint32_t pack_w(float wx, float wy)
@@ -411,41 +425,34 @@ MVF_DEV TapStash pack_taps(const WarpSlot &s)
     TapStash t;
     t.oa = s.qa.q.o0 | (s.qa.q.sh ? 1u << 28 : 0u) | (s.qa.q.o1 != s.qa.q.o0 ? 1u << 29 : 0u) | (s.fla << 28);
     t.ob = s.qb.q.o0 | (s.qb.q.sh ? 1u << 28 : 0u) | (s.qb.q.o1 != s.qb.q.o0 ? 1u << 29 : 0u) | (s.flb << 28);
-#if MVF_FB_STASH_F32
     t.wxa = s.wxa; t.wya = s.wya; t.wxb = s.wxb; t.wyb = s.wyb;
-#else
-    t.wa = pack_w(s.wxa, s.wya);
-    t.wb = pack_w(s.wxb, s.wyb);
-#endif
     return t;
 }
 // plane position (r, c) of warp slot q (0 .. NSTAGE-1) of this lane; false beyond the plane
 MVF_DEV bool fb_slot_pos(int q, int &r, int &c)
 {
-#if MVF_FB_KEEPTAPS
-    constexpr int NI = (TW - 2) * (TH - 2);              // interior positions, phase-7 order
-    constexpr int OWc = TW - 2;
+    // The interior ROWS first, all TW region columns of each (plane columns 1 .. TW): the order phase 7 walks them in.
+    // Round 6: rows of TW = 32 lanes instead of the OW = 30 output columns -- a 30-wide walk wraps inside every
+    // 32-lane LDS access group and the two wrapped lanes land LDW - OW = 6 banks further, on banks the group already
+    // uses (2-way conflict on every ds_read_b32 of phases 7 + 8: the smoothness reads alone were 23 % of the kernel's
+    // SQ_LDS_BANK_CONFLICT, profiles/r06_unit_kernel_lds_conflicts.csv).  Two lanes per row idle in phase 7 (their
+    // positions are ring columns, warped here like any other); the round count is the same (448 positions: 2 rounds).
+    constexpr int NI = TW * (TH - 2);
     const int s = (int)threadIdx.x + q * NT;
     if (s < NI) {
-        const int pr = s / OWc;
-        r = pr + 2; c = s - pr * OWc + 2;
+        const int pr = s / TW;
+        r = pr + 2; c = s - pr * TW + 1;
         return true;
     }
-    const int j = s - NI;                                // the ring: rows 0, 1, PH-2, PH-1, then the side columns
+    const int j = s - NI;                                // the ring: rows 0, 1, PH-2, PH-1, then the two side columns
     if (j < 4 * PW) {
         const int rr = j / PW;
         r = (rr < 2) ? rr : rr + (PH - 4); c = j - rr * PW;
         return true;
     }
-    const int jj = min(j - 4 * PW, 4 * (PH - 4) - 1), rr = jj >> 2, cc = jj & 3;
-    r = rr + 2; c = (cc < 2) ? cc : cc + (PW - 4);
-    return j - 4 * PW < 4 * (PH - 4);
-#else
-    const int idx = (int)threadIdx.x + q * NT;
-    const int ic = min(idx, PH * PW - 1);
-    r = ic / PW; c = ic - r * PW;
-    return idx < PH * PW;
-#endif
+    const int jj = min(j - 4 * PW, 2 * (PH - 4) - 1), rr = jj >> 1;
+    r = rr + 2; c = (jj & 1) ? PW - 1 : 0;
+    return j - 4 * PW < 2 * (PH - 4);
 }
 
 struct WarpCtx {
@@ -471,15 +478,6 @@ struct WarpBatch {
     float2 a0[U][3], a1[U][3], b0[U][3], b1[U][3];     // rows y0 / y1 of source a / b
 };
 
-#ifdef MVF_ABL_FB_LDSTAPS
-// the access pattern of a window-staged source: two 8-byte LDS reads per tap set at the tap's
-// (clamped) position inside the workgroup's plane; the values are NOT the source's
-MVF_DEV void lds_taps(const float *__restrict__ plane, int lx, int ly, int ch, float t[4])
-{
-    const float *l = plane + min(max(ly, 0), PH - 2) * LDW + min(max(lx, 0), PW - 2);
-    t[0] = l[0] + (float)ch; t[1] = l[1]; t[2] = l[LDW]; t[3] = l[LDW + 1];
-}
-#endif
 
 template <int U>
 MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
@@ -491,27 +489,16 @@ MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
         const bool live = fb_slot_pos(slot0 + u, r, c);
         w.s[u] = warp_slot_rc(r, c, live, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0, k.min_disp, k.range, k.eps,
                               k.inner);
-#if MVF_FB_KEEPTAPS
         if (slot0 + u < 2) k.stash[slot0 + u] = pack_taps(w.s[u]);
-#endif
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-#ifdef MVF_ABL_FB_LDSTAPS   // timing ablation: every tap pair from an LDS plane (upper bound of what an
-                           // LDS-staged source window could gain -- at NO cost in LDS capacity)
-            float ta[4], tb[4];
-            lds_taps(k.dispP, w.s[u].x0a - k.px0, w.s[u].y0a - k.py0, ch, ta);
-            lds_taps(k.dispP, w.s[u].x0b - k.px0, w.s[u].y0b - k.py0, ch, tb);
-            w.a0[u][ch] = make_float2(ta[0], ta[1]); w.a1[u][ch] = make_float2(ta[2], ta[3]);
-            w.b0[u][ch] = make_float2(tb[0], tb[1]); w.b1[u][ch] = make_float2(tb[2], tb[3]);
-#else
             w.a0[u][ch] = ldg2_at(k.sa + ch * N, w.s[u].qa.q.o0);
             w.a1[u][ch] = ldg2_at(k.sa + ch * N, w.s[u].qa.q.o1);
             w.b0[u][ch] = ldg2_at(k.sb + ch * N, w.s[u].qb.q.o0);
             w.b1[u][ch] = ldg2_at(k.sb + ch * N, w.s[u].qb.q.o1);
-#endif
         }
 }
 
@@ -534,19 +521,8 @@ MVF_DEV void warp_finish(const WarpCtx &k, const WarpBatch<U> &w)
         row_weights(w.s[u].qb, wbt, wbb);
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-#if MVF_FB_PACKROWS_WARP
-            const f2 ta = mk2(w.a0[u][ch].x, w.a0[u][ch].y) * wat, ba = mk2(w.a1[u][ch].x, w.a1[u][ch].y) * wab;
-            const f2 tb = mk2(w.b0[u][ch].x, w.b0[u][ch].y) * wbt, bb = mk2(w.b1[u][ch].x, w.b1[u][ch].y) * wbb;
-            float va = ((ta.x + ta.y) + ba.x) + ba.y;
-            float vb = ((tb.x + tb.y) + bb.x) + bb.y;
-            // (pins the two sums as scalars: the SLP vectoriser otherwise pairs them ACROSS the sources again and pays
-            // three register moves per tap row to interleave the loaded pairs -- why round 3 measured this form at +0.8 %)
-            asm volatile("" : "+v"(va));
-            asm volatile("" : "+v"(vb));
-#else
             const float va = w.a0[u][ch].x * wat.x + w.a0[u][ch].y * wat.y + w.a1[u][ch].x * wab.x + w.a1[u][ch].y * wab.y;
             const float vb = w.b0[u][ch].x * wbt.x + w.b0[u][ch].y * wbt.y + w.b1[u][ch].x * wbb.x + w.b1[u][ch].y * wbb.y;
-#endif
             k.pairP[ch * PPLANE + w.s[u].r * LDW + w.s[u].c] = mk2(va, vb);
         }
         if (k.idx_a) {
@@ -569,22 +545,14 @@ MVF_DEV void warp_slots(const WarpCtx &k, int slot0)
     warp_finish<U>(k, w);
 }
 
-// positions first .. NSTAGE-1 (position 0 may have been started by the caller), two at a time;
-// waves whose lanes all lie beyond the plane at a position skip it (wave-uniform)
+// plane positions first .. NSTAGE-1, ONE per batch (24 tap pairs in flight; two per batch cost a workgroup per CU:
+// 128 VGPRs + spills, +4 %, HISTORY.md); waves whose lanes all lie beyond the plane at a position skip it (wave-uniform)
 MVF_DEV void warp_pair_into_lds_fb(const WarpCtx &k, int first)
 {
-#ifndef MVF_FB_WARP_U
-#define MVF_FB_WARP_U (MVF_FB_PX == 2 ? 1 : 2)     // plane positions per batch: 24 tap pairs in flight each
-#endif
     const int wave_base = (int)threadIdx.x & ~(kWave - 1);
-    auto live = [&](int q) { return q < NSTAGE && (wave_base + q * NT) < PH * PW; };
 #pragma unroll
-    for (int q0 = 0; q0 < NSTAGE + 1; q0 += MVF_FB_WARP_U) {
-        const int q = q0 + first;
-        if (q >= NSTAGE) break;
-        if (MVF_FB_WARP_U == 2 && live(q + 1)) warp_slots<2>(k, q);
-        else if (live(q)) warp_slots<1>(k, q);
-    }
+    for (int q = first; q < NSTAGE; ++q)
+        if ((wave_base + q * NT) < PH * PW) warp_slots<1>(k, q);
 }
 
 // ---- static analysis build (tools/isa_cost.py; never shipped) -----------------------------------------------
@@ -613,9 +581,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     float *dispP = smem + FB_DISP;
     f2 *coefP = reinterpret_cast<f2 *>(smem + FB_COEF);
     ImgTab &sh = *reinterpret_cast<ImgTab *>(smem + FB_POSE);
-#if !MVF_FB_LDS_REDUCE
-    float *scratch = smem + FB_COEF;       // the coefficient planes are free when the final reduction runs
-#endif
 
     // workgroup -> (unit, image, tile): the images of all units form one batch of nunits * B
     const TileId tid = tile_of_block_mg(a.tiles_x, a.tiles_y, a.B * a.nunits, a.mg_tx, a.mg_ty);
@@ -627,12 +592,9 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     const size_t N = (size_t)H * W;
     const int cy0 = tid.by * OH - 1, cx0 = tid.bx * OW - 1;   // region origin
     const int py0 = cy0 - 1, px0 = cx0 - 1;                   // plane origin
-#if MVF_ANALYSIS
-    constexpr bool no_ssim = false, automask = true;
-#else
-    const bool no_ssim = a.flags & MVF_NO_SSIM;
-    const bool automask = !(a.flags & MVF_NO_AUTOMASK);
-#endif
+    // (MVF_ANALYSIS: compile-time constants -- the branches the frozen configuration never takes fold away)
+    const bool no_ssim = MVF_ANALYSIS ? false : bool(a.flags & MVF_NO_SSIM);
+    const bool automask = MVF_ANALYSIS ? true : !(a.flags & MVF_NO_AUTOMASK);
     constexpr bool avg = AVG;
     const int n_id = automask ? (avg ? 1 : S) : 0;
     constexpr bool hasb = S > 1;
@@ -644,11 +606,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     const float *sa = uniform_ptr(u.src0 + (size_t)b * u.src0_stride);
     const float *sb = hasb ? uniform_ptr(u.src1 + (size_t)b * u.src1_stride) : sa;
     const float *iK = u.invK + b * 16;
-#if MVF_ANALYSIS
-    constexpr bool ident_given = (MVF_ANALYSIS == 2);
-#else
-    const bool ident_given = automask && (u.ident_in != nullptr);
-#endif
+    const bool ident_given = MVF_ANALYSIS ? (MVF_ANALYSIS == 2) : (automask && (u.ident_in != nullptr));
 
     // the image's constants: one 128-byte line of the table k_units_prepare wrote, in flight with the staging loads
     if (threadIdx.x < TABF)
@@ -663,18 +621,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // ---- 1: target, disparity (and the identity pair) -> LDS
     // tiles whose staged plane lies inside the image need no reflect / clamp mapping of the
     // coordinates they stage and warp (scalar branch; 240 of 308 tiles at 640x192)
-#if MVF_ANALYSIS
-    constexpr bool inner = true;
-#else
-    const bool inner = (py0 >= 0) && (px0 >= 0) && (py0 + PH <= H) && (px0 + PW <= W);
-#endif
+    const bool inner = MVF_ANALYSIS ? true : ((py0 >= 0) && (px0 >= 0) && (py0 + PH <= H) && (px0 + PW <= W));
     MVF_PHASE("1_stage");
 #ifndef MVF_ABL_NOSTAGE   // timing ablation: nothing staged (the planes keep what the previous workgroup left there)
-#ifndef MVF_FB_STAGE2
-#define MVF_FB_STAGE2 1     // inner tiles staged as 8-byte pixel pairs (0: one pixel per load)
-#endif
     // (the pair form needs 8-byte aligned image bases: checked by the launcher, which clears FB_PAIR_OK otherwise)
-    const bool pairs_ok = MVF_FB_STAGE2 && inner && (a.flags_int & 1);
+    const bool pairs_ok = inner && (a.flags_int & 1);
     if (automask && !ident_given) {
         if (pairs_ok) stage_first_inner(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, W, py0, px0);
         else stage_first(tgtP, dispP, pairP, tgt_b, disp_b, sa, sb, N, H, W, py0, px0, inner);
@@ -742,21 +693,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 
     // ---- 3: fused warp of the source pair
     MVF_PHASE("3_warp");
-#ifndef MVF_FB_PRIO
-#define MVF_FB_PRIO 0        // experiment: wave priority by phase (1: raised over the warp phase -- its tap loads leave earlier;
-                             // 2: raised from the SSIM adjoint to the end -- the oldest workgroup frees its slot earlier)
-#endif
-#if MVF_FB_PRIO == 1
-    __builtin_amdgcn_s_setprio(2);
-#endif
 #ifdef MVF_ABL_NOWARP    // timing ablation: the raw sources instead of the warped pair
     stage_pair3(pairP, wk_ctx.sa, wk_ctx.sb, N, H, W, py0, px0);
     if (false)
 #endif
         warp_pair_into_lds_fb(wk_ctx, 0);
-#if MVF_FB_PRIO == 1
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __syncthreads();
 
     // ---- 4: warped candidates; the SSIM partials of the three channels stay in registers
@@ -773,11 +714,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
             for (int q = 0; q < 3; ++q) pm[q][j] = px2[q][j] = pg[q][j] = f2s(0.0f);
         }
-#ifndef MVF_FB_ROLL4
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
         for (int c = 0; c < 3; ++c) {
 #ifdef MVF_ABL_NOSSIM4
             if (true) {
@@ -817,11 +754,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     MVF_PHASE("5a_mask_noise");
     float mraw[PX];            // mask value (1 without a mask), 0 outside the image
     f2 nz[PX];
-#if MVF_ANALYSIS
-    const float *mask_b = (MVF_ANALYSIS == 3) ? uniform_ptr(u.mask + (size_t)b * u.mask_stride) : nullptr;
-#else
-    const float *mask_b = u.mask ? uniform_ptr(u.mask + (size_t)b * u.mask_stride) : nullptr;
-#endif
+    const float *mask_b = (MVF_ANALYSIS ? (MVF_ANALYSIS == 3) : (u.mask != nullptr)) ? uniform_ptr(u.mask + (size_t)b * u.mask_stride) : nullptr;
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         const int x = x0 + j;
@@ -927,9 +860,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // hold row sums, and the vertical step reads two rows instead of nine row segments.
     // Reflect-pad multiplicities only exist next to the image border (rows 1, H-2, cols 1, W-2).
     MVF_PHASE("6_ssim_adjoint");
-#if MVF_FB_PRIO == 2
-    __builtin_amdgcn_s_setprio(1);
-#endif
     const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
     float mlx[PX], mrx[PX];
 #pragma unroll
@@ -949,11 +879,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     };
     auto from_left = [&](f2 v) { return mk2(dpp1(v.x, false), dpp1(v.y, false)); };    // lane seg-1 (0 at seg 0)
     auto from_right = [&](f2 v) { return mk2(dpp1(v.x, true), dpp1(v.y, true)); };     // lane seg+1 (0 at seg 15)
-#ifndef MVF_FB_ROLL4
 #pragma unroll
-#else
-#pragma unroll 1
-#endif
     for (int c = 0; c < 3; ++c) {
         f2 hs[3][PX];              // row sums of A, B, G at this lane's columns
 #ifdef MVF_ABL_NO6H      // timing ablation: no SSIM adjoint at all (coefficients, DPP row sums, LDS round trip, gather)
@@ -1042,23 +968,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             for (int j = 0; j < PX; ++j) gp[j] = gw[j];
         }
     }
-#ifndef MVF_FB_PREFETCH7
-#define MVF_FB_PREFETCH7 0     // experiment: the tap rows of a lane's FIRST adjoint position requested before the barrier that ends the
-                               // SSIM adjoint (their offsets have been in registers since phase 3), unconditionally
-#endif
-#if MVF_FB_PREFETCH7 && MVF_FB_KEEPTAPS && !defined(MVF_ABL_NO7) && !defined(MVF_ABL_FB_LDSTAPS)
-    float2 pra0[3], pra1[3], prb0[3], prb1[3];
-    {
-        const unsigned W4p = (unsigned)W * 4u;
-        const unsigned pa0 = stash[0].oa & kOffMask, pa1 = pa0 + ((stash[0].oa & (1u << 29)) ? W4p : 0u);
-        const unsigned pb0 = stash[0].ob & kOffMask, pb1 = pb0 + ((stash[0].ob & (1u << 29)) ? W4p : 0u);
-#pragma unroll
-        for (int ch = 0; ch < 3; ++ch) {
-            pra0[ch] = ldg2_at(sa + ch * N, pa0); pra1[ch] = ldg2_at(sa + ch * N, pa1);
-            prb0[ch] = ldg2_at(sb + ch * N, pb0); prb1[ch] = ldg2_at(sb + ch * N, pb1);
-        }
-    }
-#endif
     __syncthreads();      // every grad_warped is parked
 
     // ---- 7 + 8: bilinear + projection adjoint, smoothness value + gradient, store grad_disp.
@@ -1079,25 +988,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     float fb_sx = 0.0f, fb_sy = 0.0f;
     const float rden = sh.rden;
     const float cxs = a.cxs, cys = a.cys;
-#ifndef MVF_FB_UNROLL7
-#define MVF_FB_UNROLL7 2
-#endif
-    // (only the OW x OH interior is enumerated: 420 positions = 7 wave passes; walking the whole
-    // 32 x 16 region cost 8, a fifth of its lanes idle on the border ring)
-#ifdef MVF_FB_WALK_REGION
-    constexpr int NPOS7 = TW * TH;
-#else
-    constexpr int NPOS7 = OW * OH;
-#endif
-#pragma unroll MVF_FB_UNROLL7
+    // (the OH interior rows are enumerated, TW lanes each: 448 positions = 7 wave passes, same as the 420 of an OW-wide
+    // walk; see fb_slot_pos for why the rows are TW wide)
+    constexpr int NPOS7 = TW * OH;
+#pragma unroll 2
     for (int k = 0; k < (NPOS7 + NT - 1) / NT; ++k) {
         const int p = (int)threadIdx.x + k * NT;
-#ifdef MVF_FB_WALK_REGION
-        const int r = p / TW, cc = p - r * TW;
-#else
         if ((NPOS7 % NT) && ((int)(threadIdx.x & ~(kWave - 1)) + k * NT >= NPOS7)) break;   // whole wave beyond: wave-uniform
-        const int r = 1 + p / OW, cc = 1 + (p - (p / OW) * OW);
-#endif
+        const int r = 1 + p / TW, cc = p - (p / TW) * TW;
         const int yy = cy0 + r, xx = cx0 + cc;
         const bool outp = (p < NPOS7) && (r >= 1) && (r <= OH) && (cc >= 1) && (cc <= OW) && (yy < H) && (xx < W);
         if (!outp) continue;       // yy, xx >= 0 for interior positions
@@ -1113,7 +1011,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         const bool live = (g0.x != 0.0f) || (g1.x != 0.0f) || (g2.x != 0.0f) ||
                           (hasb && ((g0.y != 0.0f) || (g1.y != 0.0f) || (g2.y != 0.0f)));
         if (live) {
-#if MVF_FB_KEEPTAPS && !defined(MVF_ABL_FB_LDSTAPS)
             // the forward's taps come out of the registers phase 3 left them in (same lane, same position);
             // what the projection adjoint needs besides -- the camera point, z, u, v -- is tolerance
             // arithmetic: one v_rcp each for the depth (one Newton step) and for z
@@ -1138,13 +1035,8 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 const f2 rzz = mk2(__builtin_amdgcn_rcpf(w.z.x), __builtin_amdgcn_rcpf(w.z.y));
                 w.u = c[0] * rzz;
                 w.v = c[1] * rzz;
-#if MVF_FB_STASH_F32
                 w.ta.wx = ts.wxa; w.ta.wy = ts.wya;
                 w.tb.wx = ts.wxb; w.tb.wy = ts.wyb;
-#else
-                w.ta.wx = (float)(ts.wa & 0xffffu) * 0x1p-16f; w.ta.wy = (float)(ts.wa >> 16) * 0x1p-16f;
-                w.tb.wx = (float)(ts.wb & 0xffffu) * 0x1p-16f; w.tb.wy = (float)(ts.wb >> 16) * 0x1p-16f;
-#endif
                 w.ta.inx = ts.oa & (1u << 30); w.ta.iny = ts.oa & (1u << 31);
                 w.tb.inx = ts.ob & (1u << 30); w.tb.iny = ts.ob & (1u << 31);
             }
@@ -1154,28 +1046,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             qa.sh = stash[k].oa & (1u << 28);
             qb.o0 = stash[k].ob & kOffMask; qb.o1 = qb.o0 + ((stash[k].ob & (1u << 29)) ? W4 : 0u);
             qb.sh = stash[k].ob & (1u << 28);
-#else
-            // the exact chain again: the taps must be the forward's (a flipped cell would flip the
-            // bilinear gradient)
-            const WarpPair w = warp_point_pair(dispP[e], iK, P2, xx, yy, H, W, a.min_disp,
-                                               a.range, a.eps);
-#if !defined(MVF_ABL_FB_LDSTAPS)
-            const TapRows qa = taprows_of(w.ta, W), qb = taprows_of(w.tb, W);
-#endif
-#endif
             float dxa[3], dya[3], dxb[3], dyb[3];
-#ifdef MVF_ABL_FB_LDSTAPS
-#pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                float ta4[4], tb4[4];
-                lds_taps(dispP, w.ta.x0 - px0, w.ta.y0 - py0, ch, ta4);
-                lds_taps(dispP, w.tb.x0 - px0, w.tb.y0 - py0, ch, tb4);
-                dxa[ch] = (ta4[1] - ta4[0]) * (1.0f - w.ta.wy) + (ta4[3] - ta4[2]) * w.ta.wy;
-                dya[ch] = (ta4[2] - ta4[0]) * (1.0f - w.ta.wx) + (ta4[3] - ta4[1]) * w.ta.wx;
-                dxb[ch] = (tb4[1] - tb4[0]) * (1.0f - w.tb.wy) + (tb4[3] - tb4[2]) * w.tb.wy;
-                dyb[ch] = (tb4[2] - tb4[0]) * (1.0f - w.tb.wx) + (tb4[3] - tb4[1]) * w.tb.wx;
-            }
-#else
             {
                 // the tap rows as the 8-byte pairs they are loaded as: d/dy of the bilinear sample is
                 // (row1 - row0) . (e, w) -- one packed subtract and one packed multiply per channel; at
@@ -1184,12 +1055,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                 float2 ra0[3], ra1[3], rb0[3], rb1[3];
 #pragma unroll
                 for (int ch = 0; ch < 3; ++ch) {
-#if MVF_FB_PREFETCH7 && MVF_FB_KEEPTAPS
-                    if (k == 0) {
-                        ra0[ch] = pra0[ch]; ra1[ch] = pra1[ch]; rb0[ch] = prb0[ch]; rb1[ch] = prb1[ch];
-                        continue;
-                    }
-#endif
                     ra0[ch] = ldg2_at(sa + ch * N, qa.o0); ra1[ch] = ldg2_at(sa + ch * N, qa.o1);
                     rb0[ch] = ldg2_at(sb + ch * N, qb.o0); rb1[ch] = ldg2_at(sb + ch * N, qb.o1);
                 }
@@ -1202,34 +1067,12 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
                     // translation unit's -ffp-contract=off only guards the forward's exact-mode expressions)
                     dxa[ch] = fmaf(ra1[ch].y - ra1[ch].x, na, (ra0[ch].y - ra0[ch].x) * sna);
                     dxb[ch] = fmaf(rb1[ch].y - rb1[ch].x, nb, (rb0[ch].y - rb0[ch].x) * snb);
-#if MVF_FB_PACKROWS
-                    const f2 va = (mk2(ra1[ch].x, ra1[ch].y) - mk2(ra0[ch].x, ra0[ch].y)) * ewa;
-                    const f2 vb = (mk2(rb1[ch].x, rb1[ch].y) - mk2(rb0[ch].x, rb0[ch].y)) * ewb;
-                    dya[ch] = va.x + va.y;
-                    dyb[ch] = vb.x + vb.y;
-#else
                     dya[ch] = fmaf(ra1[ch].y - ra0[ch].y, ewa.y, (ra1[ch].x - ra0[ch].x) * ewa.x);
                     dyb[ch] = fmaf(rb1[ch].y - rb0[ch].y, ewb.y, (rb1[ch].x - rb0[ch].x) * ewb.x);
-#endif
                 }
             }
-#endif
-#ifndef MVF_FB_SCALAR_GI
-#define MVF_FB_SCALAR_GI 0     // 1 = the bilinear adjoint per source as pinned scalars (0: packed over the two sources, which costs twelve
-                               // register moves per position to pair the tap derivatives that come out of separate loads);
-                               // measured together with MVF_FB_PACKROWS_WARP: no change in time; off
-#endif
-#if MVF_FB_SCALAR_GI
-            float gixa = fmaf(g2.x, dxa[2], fmaf(g1.x, dxa[1], g0.x * dxa[0]));
-            float gixb = fmaf(g2.y, dxb[2], fmaf(g1.y, dxb[1], g0.y * dxb[0]));
-            float giya = fmaf(g2.x, dya[2], fmaf(g1.x, dya[1], g0.x * dya[0]));
-            float giyb = fmaf(g2.y, dyb[2], fmaf(g1.y, dyb[1], g0.y * dyb[0]));
-            asm volatile("" : "+v"(gixa), "+v"(gixb), "+v"(giya), "+v"(giyb));      // (keeps the SLP vectoriser from re-pairing them)
-            const f2 gix = mk2(gixa, gixb), giy = mk2(giya, giyb);
-#else
             const f2 gix = pk_fma(g2, mk2(dxa[2], dxb[2]), pk_fma(g1, mk2(dxa[1], dxb[1]), g0 * mk2(dxa[0], dxb[0])));
             const f2 giy = pk_fma(g2, mk2(dya[2], dyb[2]), pk_fma(g1, mk2(dya[1], dyb[1]), g0 * mk2(dya[0], dyb[0])));
-#endif
             // adjoint of unnormalise / normalise ((W-1)/2 * 2/(W-1) = 1) and of the perspective
             // divide; tolerance arithmetic: one reciprocal of z per source (see warp_point_bwd)
             const f2 gu = mk2(w.ta.inx ? gix.x : 0.0f, w.tb.inx ? gix.y : 0.0f);
@@ -1306,13 +1149,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #pragma unroll
         for (int q = 0; q < NRED; ++q) asm volatile("" :: "v"(flat[q]));
         tot = (threadIdx.x & 1) ? flat[1] : flat[0];
-#elif MVF_FB_LDS_REDUCE
+#else
         // every plane is dead by now: the transpose uses the workgroup's LDS from its start (the pose block
         // behind the planes stays untouched)
         static_assert(NRED * (NT + 8) + NRED * 8 <= FB_POSE, "the reduction's transpose fits in front of the pose block");
         const float tot = block_sum_many_lds<NT, NRED>(flat, smem);
-#else
-        const float tot = block_sum_many<NT, NRED>(flat, scratch);
 #endif
         const int t = threadIdx.x;
         // gp_ws [S][U*B][ntiles][12], part [U*B][ntiles][NPART]; folded by k_units_finish

@@ -34,15 +34,15 @@ if [ "$1" = build ]; then
 else
   O=$R/${2:-gpurun_out/var}; mkdir -p $O; : > $O/variants.csv
   cd /tmp && export TMPDIR=/tmp
-  echo "variant,flags,us_per_launch_events,valu_instr_per_px,valu_busy,gpu_cycles_per_launch,wave_active,wave_wait_any,wave_wait_inst,parity" >> $O/variants.csv
+  echo "variant,flags,us_per_launch_events,valu_instr_per_px,valu_busy,gpu_cycles_per_launch,wave_active,wave_wait_any,wave_wait_inst,lds_idx_active_per_launch,lds_bank_conflict_per_launch,lds_conflict_share,parity" >> $O/variants.csv
   for d in $L/var_*; do
     n=$(basename $d | sed s/var_//); export MVF_HOTPATH_LIB=$d/libmvf_hotpath.so
     par=""
     if [ -n "$3" ]; then par=$(cd $R && python -m pytest tests/test_hip_parity.py -q -x -k "$3" 2>&1 | tail -1 | tr ',' ';'); fi
-    us=$(python $R/bench.py --workload hotpath --steps 20 --warmup 5 --no-cpu-baseline --no-replay-leg $VBENCH 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['kernels']['unit_fwdbwd']['avg_us'])")
+    us=$(python $R/bench.py --workload hotpath --steps 20 --warmup 5 --no-cpu-baseline --no-pmc-leg $VBENCH 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['roofline']['avg_us'])")
     rm -rf $O/pmc_$n
-    rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
-      --kernel-trace --output-format csv -d $O/pmc_$n -- python $R/bench.py --workload hotpath --steps 4 --warmup 2 --no-cpu-baseline --no-replay-leg $VBENCH > /dev/null 2>&1 || true
+    rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE \
+      --kernel-trace --output-format csv -d $O/pmc_$n -- python $R/bench.py --workload hotpath --steps 4 --warmup 2 --no-cpu-baseline --no-pmc-leg $VBENCH > /dev/null 2>&1 || true
     python - "$O/pmc_$n" "$n" "$(cat $d/flags.txt)" "$us" "$par" >> $O/variants.csv <<'PY'
 import csv, glob, sys
 d, name, flags, us, par = sys.argv[1:6]
@@ -52,13 +52,13 @@ for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         if "k_unit_fb" in row["Kernel_Name"]:
             a = acc.setdefault(row["Counter_Name"], [0.0, 0]); a[0] += float(row["Counter_Value"]); a[1] += 1
 g = {k: v[0] / v[1] for k, v in acc.items()}
-px = float(__import__('os').environ.get('VUNITS', '3')) * 12 * 192 * 640
+px = float(__import__('os').environ.get('VUNITS', '4.5')) * 12 * 192 * 640     # mean units per launch of the 6 + 3 step
 if g:
     quad = g["GRBM_GUI_ACTIVE"] / 8.0 / 4.0 * 1024.0
     print(f"{name},{flags},{us},{g['SQ_INSTS_VALU']*64/px:.0f},{g['SQ_ACTIVE_INST_VALU']/quad:.3f},{g['GRBM_GUI_ACTIVE']/8:.0f},"
-          f"{g['SQ_ACTIVE_INST_ANY']/g['SQ_WAVE_CYCLES']:.3f},{g['SQ_WAIT_ANY']/g['SQ_WAVE_CYCLES']:.3f},{g['SQ_WAIT_INST_ANY']/g['SQ_WAVE_CYCLES']:.3f},{par}")
+          f"{g['SQ_ACTIVE_INST_ANY']/g['SQ_WAVE_CYCLES']:.3f},{g['SQ_WAIT_ANY']/g['SQ_WAVE_CYCLES']:.3f},{g['SQ_WAIT_INST_ANY']/g['SQ_WAVE_CYCLES']:.3f},{g.get('SQ_LDS_IDX_ACTIVE',0):.0f},{g.get('SQ_LDS_BANK_CONFLICT',0):.0f},{g.get('SQ_LDS_BANK_CONFLICT',0)/max(g.get('SQ_LDS_IDX_ACTIVE',1),1):.3f},{par}")
 else:
-    print(f"{name},{flags},{us},,,,,,,{par}")
+    print(f"{name},{flags},{us},,,,,,,,,,{par}")
 PY
     rm -rf $O/pmc_$n
   done
