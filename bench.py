@@ -12,14 +12,12 @@ synchronize on both sides; the maximum over ranks is used and rank 0 prints ONE 
 LAST line on stdout.
 
 Workloads (``config.workload`` names the one that ran):
-
 * ``train`` (default) -- the whole optimisation step of the drop-in trainer (reference train.py:640-696): networks +
   the 9 hot-path units + backward + gradient exchange + clip + AdamW at BASELINE.json configs[1] (ResNet18, batch 12,
   640x192, 3-frame, fp32), synthetic batch resident in HBM.
 * ``hotpath`` -- only the 9 view-synthesis + photometric-loss units of a step (reference train.py:747-883), forward +
   backward, on distinct buffers (531 MB > 256 MiB Infinity Cache).
 * ``mock`` -- a toy CPU step over gloo: plumbing test of the launcher and of the line (tests/test_bench_launch.py).
-
 The line: ``value`` (images/sec), ``roofline`` (the unit kernel ``k_unit_fb``: algorithmic bytes over the launch time
 from HIP events the library records on the launch stream inside the timed region, live ``rocprofv3 --pmc`` traffic and
 VALU counters from short child runs), ``cpu_baseline`` (the C / OpenMP oracle on the host's granted CPUs, median of
@@ -76,34 +74,26 @@ def parse(argv=None):
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--backbone", default="ResNet18")
     ap.add_argument("--disp", default="smooth", choices=["smooth", "noise"], help="hotpath: disparity statistics")
-    ap.add_argument("--noise", default="kernel", choices=["kernel", "tensor"],
-                    help="auto-mask tie-break noise: drawn inside the tile kernel or supplied as a tensor (+8 B/px)")
+    ap.add_argument("--noise", default="kernel", choices=["kernel", "tensor"], help="tie-break noise: in-kernel, or a tensor (+8 B/px)")
     ap.add_argument("--detail", action="store_true", help="also run tools/measure_detail.py -> gpurun_out/bench_detail.json")
     ap.add_argument("--detail-out", dest="detail_out", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
-    ap.add_argument("--detail-legs", dest="detail_legs", default="all", help="comma list of tools/measure_detail.py LEGS")
+    ap.add_argument("--detail-legs", dest="detail_legs", default="all", help="comma list of measure_detail.LEGS")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work of the cpu_baseline leg (three samples)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work of the cpu_baseline leg (3 samples)")
     ap.add_argument("--no-hotpath-leg", dest="hotpath_leg", action="store_false")
     ap.add_argument("--no-pmc-leg", dest="pmc_leg", action="store_false")
     ap.add_argument("--time-budget", dest="time_budget", type=float, default=240.0, help="optional legs are skipped after it")
     ap.add_argument("--hip-graph", dest="hip_graph", action="store_true", help="train: the step replayed as ONE HIP graph")
     ap.add_argument("--hip-graph-scope", dest="hip_graph_scope", default="step", choices=["step", "backward"])
     ap.add_argument("--amp-bf16", dest="amp_bf16", action="store_true", help="reduced precision: never the default")
-    ap.add_argument("--channels-last", dest="channels_last", action="store_true")
-    ap.add_argument("--miopen-find", dest="miopen_find", action="store_true")
+    for flag in ("--channels-last", "--miopen-find", "--no-share-identity", "--no-regroup"):
+        ap.add_argument(flag, action="store_true")
     ap.add_argument("--no-batch-units", dest="no_batch_units", action="store_true", help="one launch per unit")
     ap.add_argument("--no-merge-unit-groups", dest="no_merge_unit_groups", action="store_true", help="3 x 3 units, not 6 + 3")
-    ap.add_argument("--no-share-identity", dest="no_share_identity", action="store_true")
-    ap.add_argument("--no-regroup", dest="no_regroup", action="store_true")
     ap.add_argument("--grad-exchange", dest="grad_exchange", default="all_reduce", choices=["all_reduce", "reduce_scatter"])
     ap.add_argument("--no-overlap", dest="no_overlap", action="store_true", help="gradient exchange AFTER backward")
     ap.add_argument("--force-collectives", dest="force_collectives", action="store_true", help="N = 1: RCCL group of one")
-    ap.add_argument("--comm-leg-steps", dest="comm_leg_steps", type=int, default=10,
-                    help="N > 1: timed steps of the other issue order of the gradient exchange (0 = skip)")
-    # flags of earlier rounds' scripts under tools/: accepted, no effect (their legs live behind --detail now)
-    for old in ("--no-graph-leg", "--no-mfma-leg", "--no-kernel-leg", "--no-host-leg", "--no-replay-leg"):
-        ap.add_argument(old, action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--also-configs", default="none", help=argparse.SUPPRESS)
+    ap.add_argument("--comm-leg-steps", dest="comm_leg_steps", type=int, default=10, help="N > 1: steps of the other issue order")
     a = ap.parse_args(argv)
     if a.workload == "auto":
         a.workload = "train"
@@ -192,6 +182,14 @@ def comm_report(args, rank, dev, backend, step, counts_per_step):
     if red is not None:
         rep["exchanges_issued_during_backward"] = red.issued_from_hook
         rep["exchanges_issued_after_backward"] = red.issued_from_finish
+        # data-parallel replicas must hold the same parameters after the same steps: two checksums per rank, compared
+        # bit for bit (the same operations on the same values give the same bits)
+        with torch.no_grad():
+            ps = [p.detach().double() for p in red.params]
+            mine = torch.stack([torch.stack([p.sum() for p in ps]).sum(), torch.stack([p.abs().sum() for p in ps]).sum()])
+        sums = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(sums, mine)
+        rep["replicas_identical"] = all(torch.equal(s_, sums[0]) for s_ in sums)
     return rep
 
 
@@ -200,7 +198,6 @@ def barrier_sync(world):
         torch.distributed.barrier()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
-
 
 def timed_steps(step, steps, world):
     barrier_sync(world)
@@ -544,17 +541,14 @@ def static_pmc():
     try:
         with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
             j = json.load(f)
-    except (OSError, ValueError):
+        v = j["_valu"][UNIT_KERNEL]
+        return {"traffic": j[UNIT_KERNEL], "valu_busy": v["valu_busy"], "valu_instr_per_px": v["valu_instr_per_px"]}
+    except (OSError, ValueError, KeyError):
         return None
-    v = j.get("_valu", {}).get(UNIT_KERNEL)
-    if UNIT_KERNEL not in j or not v:
-        return None
-    return {"traffic": j[UNIT_KERNEL], "valu_busy": v["valu_busy"], "valu_instr_per_px": v["valu_instr_per_px"]}
 
 
 def over_budget(args, need_s):
     return (time.perf_counter() - T_START) + need_s > args.time_budget
-
 
 def emit(line):
     """The ONE JSON line is the last thing on stdout: RCCL writes its banner through C stdio, which is block-buffered
@@ -657,6 +651,10 @@ def main():
     if rank == 0:
         n_gpus = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         assert n_gpus == args.gpus == world
+        if comm and dev.type == "cuda" and len(set(comm["devices"])) < world:
+            # rehearsal only (MVF_BENCH_SHARE_GPU=1, gloo): several ranks on one device -- the line says how many GPUs
+            # really worked, the group size rides beside it
+            n_gpus = len(set(comm["devices"]))
         images = step.images_per_step * world * args.steps
         metric = {"train": "training images/sec (640x192, 3-frame)", "mock": "mock plumbing steps/sec x batch (NOT a benchmark)"}.get(
             workload, "hot-path images/sec (9 view-synthesis + photometric-loss units fwd+bwd per batch)")
@@ -666,6 +664,8 @@ def main():
                "config": {"workload": (f"{workload}: " + (step.describe() or ""))[:200],
                           "global_batch": args.batch * world, "parallelism": f"dp{world}"},
                "roofline": roofline}
+        if n_gpus != world:
+            out["world"] = world
         if workload != "mock":
             out["host_process_cpu_ms_per_step"] = host_cpu.get("process_cpu_ms_per_step")
         if in_step:

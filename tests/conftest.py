@@ -66,6 +66,43 @@ def assert_grad_close(a, b, tol=1e-4, what="grad", max_tol=None):
     assert mx <= max_tol, f"{what}: max error {mx:.3e} of tensor max > {max_tol}"
 
 
+# Per-element guards (of the tensor max) of the WHOLE-tensor gradient comparisons at the BASELINE shapes, per configuration
+# and arbiter: the worst this build measured in round 6 x 1.25 (profiles/r06_grad_error_report.txt; VERDICT r05 item 7: a
+# flat 5e-4 let a regression hide).  "oracle": the fp32 oracle's whole tensor (two fp32 evaluation orders);
+# "f64": the oracle's adjoint evaluated in double.  The 1e-4 bar of north_star is held where the reference's own
+# numbers exist (its 4,096 samples, fp32 and float64); these guards bound the far, high-contrast pixels where every
+# fp32 evaluation -- the reference's autograd included -- amplifies the rounding of a cancelling parallax term.
+GRAD_GUARD = {
+    "oracle": {"C1": 1.4e-4, "C2": 3.0e-4, "C4": 2.5e-4, "C5": 2.4e-4, "C2_no_ssim": 6.3e-4, "C2_avg": 2.9e-4, "C2_noauto": 3.7e-4},
+    "f64": {"C1": 1.1e-4, "C2": 3.0e-4, "C4": 1.9e-4, "C5": 2.8e-4, "C2_no_ssim": 5.2e-4, "C2_avg": 2.5e-4, "C2_noauto": 3.4e-4},
+}
+# pixels beyond 1e-4 of the tensor max (of 0.5-2.6 M), same run: the tracked regression number; bound = 2 x measured + 5
+GRAD_BEYOND = {
+    "oracle": {"C1": 2, "C2": 5, "C4": 4, "C5": 3, "C2_no_ssim": 74, "C2_avg": 8, "C2_noauto": 57},
+    "f64": {"C1": 0, "C2": 5, "C4": 2, "C5": 1, "C2_no_ssim": 42, "C2_avg": 4, "C2_noauto": 39},
+}
+
+
+def grad_guard(arbiter, cfg, got, want, what=""):
+    """Assert the per-element guard of `cfg` and append the tracked regression numbers (worst pixel over the tensor max,
+    pixels beyond 1e-4 of it) to gpurun_out/grad_error_counts.tsv (copied to profiles/ per round)."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    mx = float(np.abs(want).max())
+    e = np.abs(got - want)
+    worst, beyond = float(e.max() / mx), int((e > 1e-4 * mx).sum())
+    try:
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "grad_error_counts.tsv"), "a") as f:
+            f.write(f"{arbiter}\t{cfg}\t{what}\t{worst:.3e}\t{beyond}\t{e.size}\t{GRAD_GUARD[arbiter][cfg]:.2e}\n")
+    except OSError:
+        pass
+    assert worst <= GRAD_GUARD[arbiter][cfg], f"{what} {cfg} vs {arbiter}: worst pixel {worst:.3e} of the tensor max > {GRAD_GUARD[arbiter][cfg]:.2e}"
+    cap = 2 * GRAD_BEYOND[arbiter][cfg] + 5
+    assert beyond <= cap, f"{what} {cfg} vs {arbiter}: {beyond} pixels beyond 1e-4 of the tensor max (tracked bound {cap})"
+    return worst, beyond
+
+
 def torch_flow_warp(img, flow):
     """Test-only torch restatement of the reference's IFRNet.warp (networks/IFRNet.py:7-15),
     injected into mono_vifi_amd.networks.ifrnet.WARP_IMPL by the CPU tests that compare the

@@ -160,10 +160,11 @@ def test_train_workload_with_two_ranks_on_the_test_gpu(launcher):
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
-    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
+    # two ranks SHARE the one GPU of the test box: the line says so (n_gpus = devices that worked, world = group size)
+    assert d["n_gpus"] == 1 and d["world"] == 2 and d["config"]["global_batch"] == 4 and d["scaling"] == "weak"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and d["roofline"]["launches"] == 2 * 2      # two unit launches per step (6 + 3 units)
     c = d["comm"]
-    assert c["world_size"] == 2 and c["distinct_processes"] == 2 and c["backend"] == "gloo"
+    assert c["world_size"] == 2 and c["distinct_processes"] == 2 and c["backend"] == "gloo" and c["replicas_identical"] is True
     per = c["collectives_per_step"]
     # per step: one exchange per gradient bucket, one statistics collective per BatchNorm layer per grouped
     # call and direction (the CPU/gloo branch of the synchronised batch norm all-reduces in both directions
@@ -172,6 +173,36 @@ def test_train_workload_with_two_ranks_on_the_test_gpu(launcher):
     assert per.get("bn_all_gather", per.get("bn_all_reduce_fwd")) == 40.0 and per["bn_all_reduce"] == 40.0
     assert c["no_overlap"]["ms_per_step"] > 0
     assert "other_configs" not in d and "cpu_baseline" not in d
+
+
+@pytest.mark.gpu
+def test_eight_rank_dress_rehearsal_on_the_test_gpu():
+    """no 8-GPU node exists for this project, so the eight-rank form of the job is rehearsed on the
+    one GPU there is -- eight processes on cuda:0 over gloo (MVF_BENCH_SHARE_GPU=1), the REAL training step at a tiny
+    shape, `--grad-exchange reduce_scatter`, grouped SyncBatchNorm, one MIOpen find-db copy per process (reference:
+    train.py:205-208 DDP + SyncBatchNorm, :692-693).  Held: eight distinct processes in the group, one collective per
+    BatchNorm layer per grouped call and direction (40 + 40), one reduce-scatter + one all-gather per gradient bucket,
+    identical parameters on all eight ranks after the steps, and a line that reports ONE GPU with a world of eight."""
+    args = ["--gpus", "8", "--workload", "train", "--batch", "1", "--height", "64", "--width", "96", "--steps", "2",
+            "--warmup", "1", "--no-cpu-baseline", "--comm-leg-steps", "0", "--grad-exchange", "reduce_scatter"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MVF_DIST_BACKEND="gloo", MVF_BENCH_SHARE_GPU="1", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, capture_output=True,
+                       text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert last.startswith("{") and len(last.encode()) < 4096
+    d = json.loads(last)
+    assert d["n_gpus"] == 1 and d["world"] == 8 and d["config"]["parallelism"] == "dp8" and d["config"]["global_batch"] == 8
+    c = d["comm"]
+    assert c["world_size"] == 8 and c["distinct_processes"] == 8 and len(set(c["pids"])) == 8 and set(c["devices"]) == {0}
+    assert c["grad_exchange"] == "reduce_scatter" and c["grad_buckets"] >= 2 and c["replicas_identical"] is True
+    per = c["collectives_per_step"]
+    nb = float(c["grad_buckets"])
+    assert per["grad_reduce_scatter"] == nb and per["grad_all_gather"] == nb and "grad_all_reduce" not in per
+    assert per.get("bn_all_gather", per.get("bn_all_reduce_fwd")) == 40.0 and per["bn_all_reduce"] == 40.0
+    assert c["exchanges_issued_during_backward"] + c["exchanges_issued_after_backward"] == c["grad_buckets"]
+    assert d["roofline"]["launches"] == 2 * 2 and d["value"] > 0
 
 
 @pytest.mark.gpu

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import affine_case, assert_grad_close, load_golden, rel_err, rel_l2
+from conftest import affine_case, assert_grad_close, grad_guard, load_golden, rel_err, rel_l2
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -253,9 +253,11 @@ def test_fullsize_unit(dev, cfg, unit_kernel):
     ref = O.unit(inp["disp"], inp["tgt"], inp["src"], g["T"], inp["K"], inp["inv_K"], inp["noise"],
                  inp["mask_rec"], 0, want_grads=True)
     assert np.array_equal(N(argmin).astype(np.int32), ref["idx"])
-    # whole tensor vs the oracle: two fp32 evaluation orders of a cancelling adjoint differ by up to 2.7e-4 of the
-    # tensor max at the worst of 1.5-2.6 M pixels (profiles/r03_grad_error_report.txt): per-element bar 5e-4
-    assert_grad_close(gd, ref["grad_disp"], TOL, "grad_disp vs oracle", max_tol=5e-4 if unit_kernel == "fwdbwd" else None)
+    # whole tensor vs the oracle: two fp32 evaluation orders of a cancelling adjoint; the per-element guard is this
+    # configuration's measured worst x 1.5 (conftest.GRAD_GUARD), the count of pixels beyond 1e-4 is tracked
+    assert_grad_close(gd, ref["grad_disp"], TOL, "grad_disp vs oracle", max_tol=1e-3)
+    if unit_kernel == "fwdbwd":
+        grad_guard("oracle", cfg, gd, ref["grad_disp"], "grad_disp")
     assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
     # the reference itself reduces grad_P in fp32; its own value is only good to ~5e-3
     assert rel_err(N(Tt.grad), g["grad_T"]) <= 5e-3
@@ -314,7 +316,9 @@ def test_fullsize_unit_flag_sets(dev, name, unit_kernel):
     am = N(argmin).astype(np.int32)
     am[am == 255] = -1
     assert np.array_equal(am, ref["idx"])
-    assert_grad_close(gd, ref["grad_disp"], TOL, "grad_disp vs oracle", max_tol=5e-4 if unit_kernel == "fwdbwd" else None)
+    assert_grad_close(gd, ref["grad_disp"], TOL, "grad_disp vs oracle", max_tol=1e-3)
+    if unit_kernel == "fwdbwd":
+        grad_guard("oracle", "C2_" + name, gd, ref["grad_disp"], "grad_disp")
     assert rel_err(N(Tt.grad), ref["grad_T"]) <= TOL
     assert rel_err(N(Tt.grad), g["grad_T"]) <= 5e-3
 
@@ -356,8 +360,8 @@ def test_fullsize_gradients_vs_double_adjoint(dev, case):
     mx = np.abs(r64).max()
     e = np.abs(gd - r64)
     assert np.linalg.norm(gd - r64) <= 5e-5 * np.linalg.norm(r64)
-    assert e.max() <= 5e-4 * mx, e.max() / mx
-    assert int((e > 1e-4 * mx).sum()) <= 1e-4 * e.size
+    _, beyond = grad_guard("f64", case, gd, r64, "grad_disp")
+    assert beyond <= 1e-4 * e.size
     assert np.abs(N(Tt.grad) - ref["grad_T64"]).max() <= 1e-4 * np.abs(ref["grad_T64"]).max()
 
 

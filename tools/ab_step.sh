@@ -5,7 +5,7 @@
 ROUNDS=${ROUNDS:-2}
 OUT=gpurun_out/ab_step.txt
 mkdir -p gpurun_out; : > $OUT
-COMMON="--no-cpu-baseline --no-hotpath-leg --no-graph-leg --no-pmc-leg --no-mfma-leg --no-kernel-leg --no-host-leg --also-configs none --steps ${STEPS:-30} --warmup 8"
+COMMON="--no-cpu-baseline --no-hotpath-leg --no-pmc-leg --steps ${STEPS:-30} --warmup 8"
 for r in $(seq 1 $ROUNDS); do
   for v in "$@"; do
     label=${v%%:*}; rest=${v#*:}

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 # (no child legs inside a profiled run: a profiler around a run that starts profilers of its own hung the round-4 suite)
-BENCH="timeout 600 python $R/bench.py --workload train --no-cpu-baseline --no-hotpath-leg --no-graph-leg --no-pmc-leg --no-mfma-leg --no-host-leg --no-kernel-leg --also-configs none"
+BENCH="timeout 600 python $R/bench.py --workload train --no-cpu-baseline --no-hotpath-leg --no-pmc-leg"
 $BENCH --steps 2 --warmup 2 "$@" > /dev/null 2>&1      # warm the MIOpen find db of this box
 rm -rf $R/gpurun_out/pmc_mfma
 timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE \
