@@ -33,16 +33,30 @@ struct Trig {
     float c, s;
 };
 
-// per-workgroup: lane 0 evaluates the double-precision trig once
-MVF_DEV Trig block_trig(float deg, Trig *sh)
+// cos / sin of an angle in degrees, evaluated in double and rounded to fp32 (torchvision builds its matrix from python
+// floats).  Rounds 2-5 had lane 0 of every workgroup call libm's double cos / sin and the other 255 lanes wait at a barrier
+// for it: the four affine kernels took 24-39 us each for 24 MB (kernel trace of round 6) -- ocml's generic routines
+// (argument reduction for any magnitude) run for microseconds on one lane.  Now EVERY lane evaluates it itself, without
+// a barrier: Cody-Waite reduction by pi/2 in two pieces and fdlibm's kernel polynomials on [-pi/4, pi/4] (error below
+// one double ulp: the fp32 rounding of the result can differ from libm's only when the exact value lies within
+// ~1e-16 of a rounding boundary), ~30 double operations per lane.  |deg| < 1e6 (the augmentation draws +-5 degrees).
+MVF_DEV Trig trig_of(float deg)
 {
-    if (threadIdx.x == 0) {
-        double a = (double)deg * (3.14159265358979323846 / 180.0);
-        sh->c = (float)cos(a);
-        sh->s = (float)sin(a);
-    }
-    __syncthreads();
-    return *sh;
+    const double x = (double)deg * (3.14159265358979323846 / 180.0);
+    const double kd = rint(x * 0.63661977236758134308);
+    const double r = fma(-kd, 6.12323399573676603587e-17, fma(-kd, 1.57079632679489655800e+00, x));
+    const double z = r * r;
+    const double sp = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 +
+                      z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+    const double sn = r + (z * r) * (-1.66666666666666324348e-01 + z * sp);
+    const double cp = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                      z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double cs = 1.0 - (0.5 * z - z * cp);
+    const int k = (int)kd & 3;
+    Trig t;
+    t.c = (float)(k == 0 ? cs : k == 1 ? -sn : k == 2 ? -cs : sn);
+    t.s = (float)(k == 0 ? sn : k == 1 ? cs : k == 2 ? -sn : -cs);
+    return t;
 }
 
 // source position (pixels) of output pixel (y,x) under torchvision's rotate:
@@ -116,83 +130,130 @@ MVF_DEV Box box_of(const int32_t *__restrict__ box, int b, int H, int W)
 }
 
 // ---------------------------------------------------------------- affine_transform forward
-// out = resize( rotate(img, angle)[box] -> (H,W) ): 4 resize taps x 4 rotate taps per channel
+// out = resize( rotate(img, angle)[box] -> (H,W) ): 4 resize taps x 4 rotate taps per channel.
+// Round 6: the crop is UP-scaled (ratio 1.2 .. 2.0, mono_dataset.py:41), so neighbouring output pixels share their
+// resize taps: a 64 x 8 output tile reads at most (64 + 2) x (8 + 2) crop pixels.  Rounds 2-5 evaluated the rotate at
+// the four resize taps of EVERY output pixel (16 gathers + four position chains per pixel and channel: 52 us for
+// 47 MB); now the workgroup rotates each crop pixel of its patch ONCE into LDS (stage A) and the output pixels take
+// their four resize taps from there (stage B).  Same products in the same order per rotated sample and per output:
+// the same bits as the per-pixel form.
+constexpr int ATX = 64, ATY = 8;                   // output tile of the transform (two rows per lane)
+constexpr int APW = ATX + 2, APH = ATY + 2;        // largest patch of crop pixels a tile can touch (scale <= 1)
+constexpr int ACH_LDS = 4;                         // channels held in LDS at a time
+constexpr int APOS = (APW * APH + NT - 1) / NT;    // patch positions per lane (3)
+
+// rotated sample of crop pixel (cy, cx) (image coordinates), channel plane `im`: the four products in sample_zeros' order
+struct RotTap {
+    unsigned o0;          // byte offset of the row-y0 tap pair (inner positions)
+    float w[4];
+    ZTap z;
+    bool inner;
+};
+MVF_DEV RotTap rot_tap(Trig t, int cy, int cx, int H, int W)
+{
+    RotTap r;
+    float px, py;
+    rot_pos(t, cy, cx, H, W, px, py);
+    r.z = ztap_of(px, py);
+    r.inner = r.z.x0 >= 0 && r.z.x0 + 1 < W && r.z.y0 >= 0 && r.z.y0 + 1 < H;
+    r.w[0] = (1.0f - r.z.lx) * (1.0f - r.z.ly);
+    r.w[1] = r.z.lx * (1.0f - r.z.ly);
+    r.w[2] = (1.0f - r.z.lx) * r.z.ly;
+    r.w[3] = r.z.lx * r.z.ly;
+    r.o0 = r.inner ? (unsigned)(r.z.y0 * W + r.z.x0) * 4u : 0u;
+    return r;
+}
+MVF_DEV float rot_sample(const float *__restrict__ im, int H, int W, const RotTap &r)
+{
+    if (r.inner) {
+        const float2 r0 = ldg2_at(im, r.o0), r1 = ldg2_at(im, r.o0 + (unsigned)W * 4u);
+        float a = r0.x * r.w[0];
+        a += r0.y * r.w[1];
+        a += r1.x * r.w[2];
+        a += r1.y * r.w[3];
+        return a;
+    }
+    return sample_zeros(im, H, W, r.z);
+}
+
 __global__ void __launch_bounds__(NT) k_affine_transform(const float *__restrict__ img,
                                                          const float *__restrict__ angle,
                                                          const int32_t *__restrict__ box,
                                                          float *__restrict__ out, int C, int H, int W, int Bm)
 {
-    __shared__ Trig sh;
+    __shared__ float patch[ACH_LDS][APH][APW + 1];
     const int b = blockIdx.z, bm = b % Bm;       // image b takes angle / box of sample b % Bm (several views per sample)
-    const Trig t = block_trig(angle[bm], &sh);
-    const int x = blockIdx.x * TX + (threadIdx.x & (TX - 1)), y = blockIdx.y * TY + threadIdx.x / TX;
-    if (x >= W || y >= H) return;
+    const Trig t = trig_of(angle[bm]);
     const Box k = box_of(box, bm, H, W);
-    const RTap ry = resize_src(y, k.h, H), rx = resize_src(x, k.w, W);
-    ZTap z[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        float px, py;
-        rot_pos(t, k.y0 + ((q >> 1) ? ry.i1 : ry.i0), k.x0 + ((q & 1) ? rx.i1 : rx.i0), H, W, px, py);
-        z[q] = ztap_of(px, py);
-    }
+    const int lx = threadIdx.x & (ATX - 1), ly = threadIdx.x / ATX;          // 64 x 4 lanes, two output rows each
+    const int x_lo = blockIdx.x * ATX, y_lo = blockIdx.y * ATY;
+    const int x_hi = min(x_lo + ATX, W) - 1, y_hi = min(y_lo + ATY, H) - 1;
+    // the patch: crop pixels [cy0, cy1] x [cx0, cx1] (resize taps are monotone in the output index)
+    const int cx0 = resize_src(x_lo, k.w, W).i0, cx1 = resize_src(x_hi, k.w, W).i1;
+    const int cy0 = resize_src(y_lo, k.h, H).i0, cy1 = resize_src(y_hi, k.h, H).i1;
+    const int pw = cx1 - cx0 + 1, ph = cy1 - cy0 + 1;
+    const bool fits = pw <= APW && ph <= APH;    // always for crops no larger than the image (the caller's contract)
     const size_t N = (size_t)H * W;
-    // Round 5: a pixel whose four rotate-tap sets all lie inside the image (everywhere but a thin border for the
-    // +-5 degree rotations of the augmentation) takes its 16 taps as eight unconditional 8-byte row pairs per channel,
-    // weights formed once -- sample_zeros' sixteen predicated 4-byte loads per channel were the kernel's cost
-    // (50 us for 17.7 MB).  Same products, same left-to-right sums (0 + a == a): the same bits.
-    bool inner = true;
+    const int x = x_lo + lx;
+    RTap rx = resize_src(min(x, W - 1), k.w, W), ry[2];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) inner = inner && z[q].x0 >= 0 && z[q].x0 + 1 < W && z[q].y0 >= 0 && z[q].y0 + 1 < H;
-    if (inner) {
-        float w4[4][4];
-        unsigned o0[4];
+    for (int j = 0; j < 2; ++j) ry[j] = resize_src(min(y_lo + ly + 4 * j, H - 1), k.h, H);
+    if (!fits) {
+        // (a box larger than the contract allows: per-pixel form, no sharing)
+        for (int j = 0; j < 2; ++j) {
+            const int y = y_lo + ly + 4 * j;
+            if (x >= W || y >= H) continue;
+            for (int c = 0; c < C; ++c) {
+                const float *im = img + ((size_t)b * C + c) * N;
+                float v[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            w4[q][0] = (1.0f - z[q].lx) * (1.0f - z[q].ly);
-            w4[q][1] = z[q].lx * (1.0f - z[q].ly);
-            w4[q][2] = (1.0f - z[q].lx) * z[q].ly;
-            w4[q][3] = z[q].lx * z[q].ly;
-            o0[q] = (unsigned)(z[q].y0 * W + z[q].x0) * 4u;
-        }
-        const unsigned W4b = (unsigned)W * 4u;
-        for (int c = 0; c < C; ++c) {
-            const float *im = img + ((size_t)b * C + c) * N;
-            float v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float2 r0 = ldg2_at(im, o0[q]), r1 = ldg2_at(im, o0[q] + W4b);
-                float a = r0.x * w4[q][0];
-                a += r0.y * w4[q][1];
-                a += r1.x * w4[q][2];
-                a += r1.y * w4[q][3];
-                v[q] = a;
+                for (int q = 0; q < 4; ++q)
+                    v[q] = rot_sample(im, H, W, rot_tap(t, k.y0 + ((q >> 1) ? ry[j].i1 : ry[j].i0),
+                                                        k.x0 + ((q & 1) ? rx.i1 : rx.i0), H, W));
+                out[((size_t)b * C + c) * N + (size_t)y * W + x] =
+                    (1.0f - ry[j].l) * ((1.0f - rx.l) * v[0] + rx.l * v[1]) + ry[j].l * ((1.0f - rx.l) * v[2] + rx.l * v[3]);
             }
-            out[((size_t)b * C + c) * N + (size_t)y * W + x] =
-                (1.0f - ry.l) * ((1.0f - rx.l) * v[0] + rx.l * v[1]) + ry.l * ((1.0f - rx.l) * v[2] + rx.l * v[3]);
         }
         return;
     }
-    for (int c = 0; c < C; ++c) {
-        const float *im = img + ((size_t)b * C + c) * N;
-        float v00 = sample_zeros(im, H, W, z[0]), v01 = sample_zeros(im, H, W, z[1]);
-        float v10 = sample_zeros(im, H, W, z[2]), v11 = sample_zeros(im, H, W, z[3]);
-        out[((size_t)b * C + c) * N + (size_t)y * W + x] =
-            (1.0f - ry.l) * ((1.0f - rx.l) * v00 + rx.l * v01) + ry.l * ((1.0f - rx.l) * v10 + rx.l * v11);
+    // stage A positions of this lane (row-major over the patch) and their rotate taps, shared by all channels
+    RotTap rt[APOS];
+    int pr[APOS], pc[APOS];
+    const int npos = pw * ph;
+#pragma unroll
+    for (int i = 0; i < APOS; ++i) {
+        const int p = min((int)threadIdx.x + i * NT, npos - 1);
+        pr[i] = p / pw; pc[i] = p - pr[i] * pw;
+        rt[i] = rot_tap(t, k.y0 + cy0 + pr[i], k.x0 + cx0 + pc[i], H, W);
+    }
+    for (int c0 = 0; c0 < C; c0 += ACH_LDS) {
+        const int nc = min(ACH_LDS, C - c0);
+        if (c0 > 0) __syncthreads();             // the previous chunk's reads are done
+#pragma unroll
+        for (int i = 0; i < APOS; ++i) {
+            if ((int)threadIdx.x + i * NT >= npos) break;
+            for (int c = 0; c < nc; ++c)
+                patch[c][pr[i]][pc[i]] = rot_sample(img + ((size_t)b * C + c0 + c) * N, H, W, rt[i]);
+        }
+        __syncthreads();
+        if (x < W) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int y = y_lo + ly + 4 * j;
+                if (y >= H) continue;
+                const int r0 = ry[j].i0 - cy0, r1 = ry[j].i1 - cy0, q0 = rx.i0 - cx0, q1 = rx.i1 - cx0;
+                for (int c = 0; c < nc; ++c) {
+                    const float v0 = patch[c][r0][q0], v1 = patch[c][r0][q1], v2 = patch[c][r1][q0], v3 = patch[c][r1][q1];
+                    out[((size_t)b * C + c0 + c) * N + (size_t)y * W + x] =
+                        (1.0f - ry[j].l) * ((1.0f - rx.l) * v0 + rx.l * v1) + ry[j].l * ((1.0f - rx.l) * v2 + rx.l * v3);
+                }
+            }
+        }
     }
 }
 
 // ---------------------------------------------------------------- affine_restore forward
 // canvas(Y,X) = inside the box ? resize(depth -> (h,w))(Y-y0, X-x0) : 0
-MVF_DEV float canvas_at(const float *__restrict__ d, int H, int W, const Box &k, int Y, int X)
-{
-    if (X < k.x0 || X >= k.x0 + k.w || Y < k.y0 || Y >= k.y0 + k.h) return 0.0f;
-    const RTap ry = resize_src(Y - k.y0, H, k.h), rx = resize_src(X - k.x0, W, k.w);
-    const float *r0 = d + (size_t)ry.i0 * W, *r1 = d + (size_t)ry.i1 * W;
-    return (1.0f - ry.l) * ((1.0f - rx.l) * r0[rx.i0] + rx.l * r0[rx.i1]) +
-           ry.l * ((1.0f - rx.l) * r1[rx.i0] + rx.l * r1[rx.i1]);
-}
-
 // out = ratio * rotate( paste(resize(depth)) , -angle )
 __global__ void __launch_bounds__(NT) k_affine_restore_fwd(const float *__restrict__ depth,
                                                            const float *__restrict__ angle,
@@ -201,9 +262,8 @@ __global__ void __launch_bounds__(NT) k_affine_restore_fwd(const float *__restri
                                                            float *__restrict__ out, int C, int H, int W,
                                                            size_t in_stride)
 {
-    __shared__ Trig sh;
     const int b = blockIdx.z;
-    const Trig t = block_trig(-angle[b], &sh);
+    const Trig t = trig_of(-angle[b]);
     const int x = blockIdx.x * TX + (threadIdx.x & (TX - 1)), y = blockIdx.y * TY + threadIdx.x / TX;
     if (x >= W || y >= H) return;
     const Box k = box_of(box, b, H, W);
@@ -214,13 +274,40 @@ __global__ void __launch_bounds__(NT) k_affine_restore_fwd(const float *__restri
     const bool ya = z.y0 >= 0 && z.y0 < H, yb = z.y0 + 1 >= 0 && z.y0 + 1 < H;
     const float r = ratio[b];
     const size_t N = (size_t)H * W;
+    // Round 6: everything about the four rotate taps that does not depend on the channel -- inside the image? inside
+    // the box? the resize taps of the canvas pixel (two IEEE divides each) and the weights -- is formed ONCE; rounds
+    // 2-5 re-derived it per channel inside canvas_at (three depth maps per image in the training step: 24 divides and
+    // the box tests three times over).  Same loads, same products, same order of sums per channel: the same bits.
+    bool use[4], inb[4];
+    int o00[4], o01[4], o10[4], o11[4];
+    float ly[4], lx[4], wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int Y = z.y0 + (q >> 1), X = z.x0 + (q & 1);
+        use[q] = ((q >> 1) ? yb : ya) && ((q & 1) ? xb : xa);
+        wq[q] = ((q & 1) ? z.lx : 1.0f - z.lx) * ((q >> 1) ? z.ly : 1.0f - z.ly);
+        inb[q] = use[q] && !(X < k.x0 || X >= k.x0 + k.w || Y < k.y0 || Y >= k.y0 + k.h);
+        o00[q] = o01[q] = o10[q] = o11[q] = 0;
+        ly[q] = lx[q] = 0.0f;
+        if (inb[q]) {
+            const RTap ry = resize_src(Y - k.y0, H, k.h), rx = resize_src(X - k.x0, W, k.w);
+            o00[q] = ry.i0 * W + rx.i0; o01[q] = ry.i0 * W + rx.i1;
+            o10[q] = ry.i1 * W + rx.i0; o11[q] = ry.i1 * W + rx.i1;
+            ly[q] = ry.l; lx[q] = rx.l;
+        }
+    }
     for (int c = 0; c < C; ++c) {
         const float *d = depth + (size_t)b * in_stride + (size_t)c * N;
         float v = 0.0f;
-        if (ya && xa) v += canvas_at(d, H, W, k, z.y0, z.x0) * ((1.0f - z.lx) * (1.0f - z.ly));
-        if (ya && xb) v += canvas_at(d, H, W, k, z.y0, z.x0 + 1) * (z.lx * (1.0f - z.ly));
-        if (yb && xa) v += canvas_at(d, H, W, k, z.y0 + 1, z.x0) * ((1.0f - z.lx) * z.ly);
-        if (yb && xb) v += canvas_at(d, H, W, k, z.y0 + 1, z.x0 + 1) * (z.lx * z.ly);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!use[q]) continue;
+            float cv = 0.0f;
+            if (inb[q])
+                cv = (1.0f - ly[q]) * ((1.0f - lx[q]) * d[o00[q]] + lx[q] * d[o01[q]]) +
+                     ly[q] * ((1.0f - lx[q]) * d[o10[q]] + lx[q] * d[o11[q]]);
+            v += cv * wq[q];
+        }
         out[((size_t)b * C + c) * N + (size_t)y * W + x] = v * r;
     }
 }
@@ -238,9 +325,8 @@ __global__ void __launch_bounds__(NT) k_affine_restore_bwd_rot(const float *__re
                                                                float *__restrict__ g_canvas, int C, int H,
                                                                int W)
 {
-    __shared__ Trig sh;
     const int b = blockIdx.z;
-    const Trig t = block_trig(-angle[b], &sh);
+    const Trig t = trig_of(-angle[b]);
     const int X = blockIdx.x * TX + (threadIdx.x & (TX - 1)), Y = blockIdx.y * TY + threadIdx.x / TX;
     if (X >= W || Y >= H) return;
     const Box k = box_of(box, b, H, W);
@@ -311,6 +397,33 @@ __global__ void __launch_bounds__(NT) k_affine_restore_bwd_resize(const float *_
     resize_candidates(i, H, k.h, ylo, yhi);
     resize_candidates(j, W, k.w, xlo, xhi);
     const size_t N = (size_t)H * W;
+    // (round 6: the separable weights -- a resize_src with an IEEE divide each -- once per pixel, not once per channel;
+    // ranges longer than the arrays below, i.e. crops far smaller than the contract's, take the per-channel form)
+    constexpr int MAXC = 8;
+    const int ny = yhi - ylo + 1, nx = xhi - xlo + 1;
+    if (ny <= MAXC && nx <= MAXC) {
+        float wy[MAXC], wx[MAXC];
+#pragma unroll
+        for (int a = 0; a < MAXC; ++a) {
+            wy[a] = a < ny ? resize_weight(ylo + a, i, H, k.h) : 0.0f;
+            wx[a] = a < nx ? resize_weight(xlo + a, j, W, k.w) : 0.0f;
+        }
+        for (int c = 0; c < C; ++c) {
+            const float *g = g_canvas + ((size_t)b * C + c) * N;
+            float acc = 0.0f;
+#pragma unroll
+            for (int a = 0; a < MAXC; ++a) {
+                if (a >= ny || wy[a] == 0.0f) continue;
+                float row = 0.0f;
+#pragma unroll
+                for (int e = 0; e < MAXC; ++e)
+                    if (e < nx && wx[e] != 0.0f) row += wx[e] * g[(size_t)(k.y0 + ylo + a) * W + k.x0 + xlo + e];
+                acc += wy[a] * row;
+            }
+            g_depth[((size_t)b * C + c) * N + (size_t)i * W + j] = acc;
+        }
+        return;
+    }
     for (int c = 0; c < C; ++c) {
         const float *g = g_canvas + ((size_t)b * C + c) * N;
         float acc = 0.0f;
@@ -349,8 +462,8 @@ int mvf_affine_transform_views_fwd(const float *img, const float *angle_deg, con
     if (B <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
     if (!img || !angle_deg || !box || !out || B > 65535 || B_meta < 1 || B % B_meta) return (int)hipErrorInvalidValue;
     ProfScope ps(MVF_PROF_AFFINE, stream, 8LL * B * C * H * W);
-    hipLaunchKernelGGL(k_affine_transform, tile_grid(B, H, W), dim3(NT), 0, (hipStream_t)stream, img,
-                       angle_deg, box, out, C, H, W, B_meta);
+    hipLaunchKernelGGL(k_affine_transform, dim3((unsigned)((W + ATX - 1) / ATX), (unsigned)((H + ATY - 1) / ATY), (unsigned)B),
+                       dim3(NT), 0, (hipStream_t)stream, img, angle_deg, box, out, C, H, W, B_meta);
     return hip_check_launch();
 }
 

@@ -599,86 +599,97 @@ __global__ void __launch_bounds__(NT, MVF_ANC_WAVES) k_fusion_level_bwd_anchor(c
 {
     __shared__ float S[2][2][ACH][NT];
     const int n = h * w;
-    const int s = blockIdx.z / B, b = blockIdx.z - s * B;
-    float *dst = (s == 0) ? g_fn1 : g_fp1;
-    if (!dst) return;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int b = blockIdx.z;
+    // Round 6 (counters of level 0 at B 36, 6 px flows: L2 hit rate 34 %, 0.95 GB fetched for 0.32 GB of inputs --
+    // profiles/r06_anchor_gather_pmc.csv): (i) BOTH sources in one workgroup, one after the other: they gather the same
+    // channel planes of g a few pixels apart, so the second walk hits the lines the first one brought in (before: one
+    // grid slice per source, dispatched far apart -- every plane fetched twice); (ii) every XCD owns one contiguous run
+    // of tiles (the dispatcher deals consecutive workgroups to the eight XCDs, whose L2s do not talk to each other:
+    // horizontally adjacent tiles read the same unaligned 128-byte lines and each fetched them for itself).
+    const int ntile = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile = xcd * (ntile >> 3) + min(xcd, ntile & 7) + slot;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int t = threadIdx.x, lx = t & (ATW - 1), ly = t / ATW;
     // region origin: one anchor row / column in front of the tile's cells
     const int ay = ty * (ATH - 1) - 1 + ly, ax = tx * (ATW - 1) - 1 + lx;
     const bool avalid = ay >= 0 && ay < h && ax >= 0 && ax < w;
-    const size_t sb = (size_t)s * B + b;
-    const int *off = off_all + sb * (n + 1);
-    const int4 *ent = ent_all + sb * n;
-    int lo = 0, hi = 0;
-    if (avalid) { lo = off[ay * w + ax]; hi = off[ay * w + ax + 1]; }
-    const int cnt = hi - lo;
-    // the first two entries of the list up front (lists average one entry); clamped index, predicated use
-    int4 e0 = ent[min(lo, n - 1)], e1 = ent[min(lo + 1, n - 1)];
-    if (cnt == 2 && e0.x > e1.x) { const int4 tmp = e0; e0 = e1; e1 = tmp; }     // (k_anc_sort leaves pairs to the reader)
-    float w0[4], w1[4];
-    corner_weights(e0, w0);
-    corner_weights(e1, w1);
     // the cell this lane emits: its own anchor position, if the three other anchors are in the region
     const bool emit = lx >= 1 && ly >= 1 && ay < h && ax < w;      // (ay, ax >= 0 follows)
     const int CT = 2 * (C + EMB);
     const int c_lo = blockIdx.y * AGRP, c_hi = min(c_lo + AGRP, C);
     const float *gb = uniform_ptr(g_out + ((size_t)b * CT + C + EMB) * n);
-    float *db = uniform_ptr(dst + (size_t)b * C * n);
-    const unsigned q4 = (unsigned)(max(ay, 0) * w + max(ax, 0)) * 4u, o0 = (unsigned)e0.x * 4u, o1 = (unsigned)e1.x * 4u;
+    const unsigned q4 = (unsigned)(max(ay, 0) * w + max(ax, 0)) * 4u;
     int buf = 0;
-    for (int c0 = c_lo; c0 < c_hi; c0 += ACH, buf ^= 1) {
-        const int nc = min(ACH, c_hi - c0);
-        const float *gc = gb + (size_t)c0 * n;
-        float acc[4][ACH];
+    for (int s = 0; s < 2; ++s) {
+        float *dst = (s == 0) ? g_fn1 : g_fp1;
+        if (!dst) continue;                                        // (workgroup-uniform)
+        const size_t sb = (size_t)s * B + b;
+        const int *off = off_all + sb * (n + 1);
+        const int4 *ent = ent_all + sb * n;
+        int lo = 0, hi = 0;
+        if (avalid) { lo = off[ay * w + ax]; hi = off[ay * w + ax + 1]; }
+        const int cnt = hi - lo;
+        // the first two entries of the list up front (lists average one entry); clamped index, predicated use
+        int4 e0 = ent[min(lo, n - 1)], e1 = ent[min(lo + 1, n - 1)];
+        if (cnt == 2 && e0.x > e1.x) { const int4 tmp = e0; e0 = e1; e1 = tmp; }     // (k_anc_sort leaves pairs to the reader)
+        float w0[4], w1[4];
+        corner_weights(e0, w0);
+        corner_weights(e1, w1);
+        float *db = uniform_ptr(dst + (size_t)b * C * n);
+        const unsigned o0 = (unsigned)e0.x * 4u, o1 = (unsigned)e1.x * 4u;
+        for (int c0 = c_lo; c0 < c_hi; c0 += ACH, buf ^= 1) {
+            const int nc = min(ACH, c_hi - c0);
+            const float *gc = gb + (size_t)c0 * n;
+            float acc[4][ACH];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+            for (int k = 0; k < 4; ++k)
 #pragma unroll
-            for (int j = 0; j < ACH; ++j) acc[k][j] = 0.0f;
-        if (cnt > 0) {
-            float v0[ACH], v1[ACH];
+                for (int j = 0; j < ACH; ++j) acc[k][j] = 0.0f;
+            if (cnt > 0) {
+                float v0[ACH], v1[ACH];
 #pragma unroll
-            for (int j = 0; j < ACH; ++j) v0[j] = ldg_at(gc + (size_t)min(j, nc - 1) * n, o0);
-            if (cnt > 1) {
+                for (int j = 0; j < ACH; ++j) v0[j] = ldg_at(gc + (size_t)min(j, nc - 1) * n, o0);
+                if (cnt > 1) {
 #pragma unroll
-                for (int j = 0; j < ACH; ++j) v1[j] = ldg_at(gc + (size_t)min(j, nc - 1) * n, o1);
-            }
-#pragma unroll
-            for (int j = 0; j < ACH; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[k][j] += w0[k] * v0[j];
-            if (cnt > 1) {
+                    for (int j = 0; j < ACH; ++j) v1[j] = ldg_at(gc + (size_t)min(j, nc - 1) * n, o1);
+                }
 #pragma unroll
                 for (int j = 0; j < ACH; ++j)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[k][j] += w1[k] * v1[j];
-            }
-            for (int q = lo + 2; q < hi; ++q) {
-                const int4 e = ent[q];
-                float wq[4];
-                corner_weights(e, wq);
+                    for (int k = 0; k < 4; ++k) acc[k][j] += w0[k] * v0[j];
+                if (cnt > 1) {
 #pragma unroll
-                for (int j = 0; j < ACH; ++j) {
-                    const float v = ldg_at(gc + (size_t)min(j, nc - 1) * n, (unsigned)e.x * 4u);
+                    for (int j = 0; j < ACH; ++j)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[k][j] += wq[k] * v;
+                        for (int k = 0; k < 4; ++k) acc[k][j] += w1[k] * v1[j];
+                }
+                for (int q = lo + 2; q < hi; ++q) {
+                    const int4 e = ent[q];
+                    float wq[4];
+                    corner_weights(e, wq);
+#pragma unroll
+                    for (int j = 0; j < ACH; ++j) {
+                        const float v = ldg_at(gc + (size_t)min(j, nc - 1) * n, (unsigned)e.x * 4u);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) acc[k][j] += wq[k] * v;
+                    }
                 }
             }
-        }
-        float west[ACH];
-#pragma unroll
-        for (int j = 0; j < ACH; ++j) {
-            west[j] = from_prev_lane(acc[1][j]);
-            S[buf][0][j][t] = acc[2][j];
-            S[buf][1][j][t] = from_prev_lane(acc[3][j]);
-        }
-        __syncthreads();        // (the buffer written two rounds ago was read before the previous round's barrier)
-        if (emit) {
+            float west[ACH];
 #pragma unroll
             for (int j = 0; j < ACH; ++j) {
-                if (j >= nc) break;
-                const float r = ((acc[0][j] + west[j]) + S[buf][0][j][t - ATW]) + S[buf][1][j][t - ATW];
-                stg_at(db + (size_t)(c0 + j) * n, q4, r);
+                west[j] = from_prev_lane(acc[1][j]);
+                S[buf][0][j][t] = acc[2][j];
+                S[buf][1][j][t] = from_prev_lane(acc[3][j]);
+            }
+            __syncthreads();        // (the buffer written two rounds ago was read before the previous round's barrier)
+            if (emit) {
+#pragma unroll
+                for (int j = 0; j < ACH; ++j) {
+                    if (j >= nc) break;
+                    const float r = ((acc[0][j] + west[j]) + S[buf][0][j][t - ATW]) + S[buf][1][j][t - ATW];
+                    stg_at(db + (size_t)(c0 + j) * n, q4, r);
+                }
             }
         }
     }
@@ -841,7 +852,7 @@ int mvf_fusion_level_bwd_lists(const float *g_out, const int32_t *lists, float *
     ProfScope ps(MVF_PROF_FUSION_BWD_GATHER, stream, 4LL * B * n * C * (1 + (g_feat_n1 ? 1 : 0) + (g_feat_p1 ? 1 : 0)));
     const int tiles_x = (w + ATW - 2) / (ATW - 1), tiles_y = (h + ATH - 2) / (ATH - 1);
     hipLaunchKernelGGL(k_fusion_level_bwd_anchor, dim3((unsigned)(tiles_x * tiles_y), (unsigned)((C + AGRP - 1) / AGRP),
-                                                      (unsigned)(2 * B)),
+                                                      (unsigned)B),
                        dim3(NT), 0, (hipStream_t)stream, g_out, lists + (size_t)2 * B * n * 4,
                        reinterpret_cast<const int4 *>(lists), g_feat_n1, g_feat_p1, B, C, h, w, tiles_x);
     return hip_check_launch();
