@@ -28,6 +28,7 @@ steps, the second CPU baseline -- is measured by ``tools/measure_detail.py`` und
 written to ``gpurun_out/bench_detail.json``, never into the line.
 """
 import argparse
+import glob
 import json
 import os
 import statistics
@@ -59,6 +60,9 @@ UNIT_KERNEL = "k_unit_fb<2>"
 # backward: samples/s of the loss path; scaled linearly by cores as `reference_cpu_expected`
 REFERENCE_CPU_SAMPLES_PER_S = {(4, 192, 640): 15.9, (12, 192, 640): 10.1, (8, 320, 1024): 3.9, (12, 192, 512): 23.8}
 REFERENCE_CPU_CORES = 8
+# same-core calibration in the build container (tools/cpu_reference_calibration.py, profiles/r06_cpu_baseline_calibration.json): the
+# C / OpenMP port runs a unit fwd + bwd this many times faster than the reference's own code on the same 8 cores (3.7-4.7 over runs)
+PORT_OVER_REFERENCE = 3.93
 HOST_CPU = {}                  # CPU time of the last timed region (this rank)
 
 
@@ -339,10 +343,9 @@ def cpu_quota():
 def cpu_baseline(args):
     """The oracle (oracle/mvf_oracle.c: the CPU port of the reference's algorithm, held bit-exact to the reference's
     golden vectors) on a bounded sample of the same workload: one unit forward + backward at the benchmark's batch and
-    resolution.  Threads = the CPUs the container is granted (no sweep: more threads than CPUs only contend, and which
-    oversubscription wins differs box to box -- VERDICT r05 item 7); THREE samples of cpu_seconds / 3 each, the median
-    is the value.  `reference_cpu_expected`: the reference's own CPU path as timed in the build container (BASELINE.md
-    section 2: 8 cores) scaled linearly to this box's cores -- the reference's Python cannot travel here."""
+    resolution.  Threads = the CPUs the container is granted (no sweep: which oversubscription wins differs box to
+    box -- VERDICT r05 item 7); THREE samples of cpu_seconds / 3 each, the median is the value.  The reference's Python
+    cannot travel here: `reference_cpu_expected` scales its build-container timing by cores."""
     from mono_vifi_amd import synthetic
     from oracle import oracle as O
     Bs = args.batch
@@ -370,15 +373,16 @@ def cpu_baseline(args):
     return {"value": round(statistics.median(samples), 3), "unit": "images/sec", "cores": cores, "threads": threads,
             "kind": "port", "runs": 3, "min": round(min(samples), 3), "max": round(max(samples), 3),
             "hardware_threads": hw,
-            # the same quantity (hot-path part of a step = 9 units fwd+bwd) from the reference's own measured CPU path
+            # the same quantity from the reference's own measured CPU path: BASELINE.md's timing scaled by cores, and
+            # THIS run's value / (port over reference on the same cores)
             "reference_cpu_expected": round(ref / UNITS_PER_STEP * cores / REFERENCE_CPU_CORES, 3) if ref else None,
+            "reference_cpu_estimate": round(statistics.median(samples) / PORT_OVER_REFERENCE, 3),
             "sample": f"{n_tot} x (1 unit fwd+bwd, batch {Bs}, {args.width}x{args.height}) in {t_tot:.1f} s, 3 runs, "
                       f"median; value = hot-path part of a step ({UNITS_PER_STEP} units)"}
 
 
 def isa_cost():
     """Static cost-weighted instruction stream of the shipped unit kernel (tools/isa_cost.py), newest file wins."""
-    import glob
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_isa_cost.json")), reverse=True):
         try:
             with open(p) as f:
@@ -489,7 +493,7 @@ def pmc_leg(args, timeout_s=120):
     TCC counter as /opt/skills/guides/MI355X_MICROARCH.md prescribes) around short hot-path child runs of this script,
     mean per launch of k_unit_fb.  FETCH_SIZE is doubled (the guide's gfx950 note; calibrated here on k_disp_mean),
     WRITE_SIZE taken 1:1.  None when rocprofv3 is missing or a pass fails."""
-    import csv, glob, shutil, subprocess, tempfile  # noqa: E401
+    import csv, shutil, subprocess, tempfile  # noqa: E401
     if not shutil.which("rocprofv3"):
         return None
     passes = [["FETCH_SIZE"], ["WRITE_SIZE"],
@@ -593,17 +597,13 @@ def main():
         while step.trainer._step_graph.graph is None:      # eager warm-up + capture stay untimed
             step()
     if nat:
-        nat.check(nat.lib().mvf_profile_reset(), "profile_reset")
-        nat.check(nat.lib().mvf_profile_enable(1), "profile_enable")
+        nat.check(nat.lib().mvf_profile_reset() or nat.lib().mvf_profile_enable(1), "profile_enable")
     parallel.reset_comm_counts()
     red = reducer_of(step)
     elapsed = timed_steps(step, args.steps, world)
     host_cpu = dict(HOST_CPU)
     counts = {k: round(v / args.steps, 2) for k, v in sorted(parallel.comm_counts().items())}
-    roofline = None
-    if nat:
-        nat.lib().mvf_profile_enable(0)
-        roofline = unit_roofline(nat, step, args)
+    roofline = (nat.lib().mvf_profile_enable(0), unit_roofline(nat, step, args))[1] if nat else None
 
     single = world == 1 and rank == 0 and workload != "mock"
     headline = single and not args.hip_graph
@@ -616,7 +616,7 @@ def main():
     # ---- communication report (every rank takes part in its collectives)
     comm = comm_report(args, rank, dev, backend, step, counts)
     if comm is not None and red is not None and args.comm_leg_steps > 0 and not args.hip_graph:
-        red.overlap = not red.overlap                  # the same step with the other issue order of the exchange
+        red.overlap = not red.overlap                  # the same step with the other issue order
         for _ in range(2):
             step()
         t_other = timed_steps(step, args.comm_leg_steps, world)

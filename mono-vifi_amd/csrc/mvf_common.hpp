@@ -590,6 +590,12 @@ MVF_DEV float wave_sum(float v)      // result in lane 63
 // published value is an agent-scope atomic store (sc1: written through to the device-coherent level), the ticket is
 // taken after `s_waitcnt vmcnt(0)` (the stores have completed), and the reader uses agent-scope atomic loads (sc1:
 // not served from a stale L2 line): the same ordering for exactly the values involved, no cache maintenance.
+// This ordering argument is the gfx9 family's: ONE counter (vmcnt) covers loads AND stores, and sc1 stores write
+// through.  Targets with a separate store counter (vscnt: gfx10 and later) would let the ticket overtake the published
+// values -- refuse to build the device code for anything else; this library is written for gfx950.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__) && !defined(__gfx90a__)
+#error "publish / take_ticket rely on gfx9 vmcnt semantics (stores counted by vmcnt): build for gfx950"
+#endif
 template <typename Tv>
 MVF_DEV void publish(Tv *p, Tv v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename Tv>
