@@ -656,11 +656,11 @@ MVF_DEV float block_sum_many(const float (&v)[NV], float *scratch)
 // adds up the 32 entries c, c + 8, ... of value q, and lane q folds the 8 chunk sums.  31 + 8 additions per
 // lane instead of 4 DPP steps for each of the NV values (NV = 27: 108) -- the workgroup reduction was 5 % of
 // the unit kernel's VALU instructions.  Fixed order: deterministic.  Result for value q in lane q;
-// `scratch` holds >= NV * (NT + 8) + NV * 8 floats and must be free of live data (barrier on entry).
+// `scratch` holds >= NV * (NT + 8) + NV * 8 floats (CH = 8 chunks; 4 when NV * 8 > NT) and must be free of live data (barrier on entry).
 template <int NT, int NV>
 MVF_DEV float block_sum_many_lds(const float (&v)[NV], float *scratch)
 {
-    constexpr int STR = NT + 8, CH = 8, PER = NT / CH;
+    constexpr int STR = NT + 8, CH = (NV * 8 <= NT) ? 8 : 4, PER = NT / CH;      // (128-lane workgroups: four chunks)
     static_assert(NT % CH == 0 && NV * CH <= NT, "one (value, chunk) pair per lane");
     const int t = threadIdx.x;
     __syncthreads();

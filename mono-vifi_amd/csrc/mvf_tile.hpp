@@ -25,11 +25,16 @@ using namespace mvf;
 
 namespace {
 
+#ifndef MVF_TILE_PY
+#define MVF_TILE_PY 1
+#endif
 constexpr int TW = MVF_TILE_TW, TH = MVF_TILE_TH; // compute region
-constexpr int PX = MVF_TILE_PX;          // pixels per lane (one row segment)
+constexpr int PX = MVF_TILE_PX;          // pixels per lane along x (one row segment)
+constexpr int PY = MVF_TILE_PY;          // rows per lane (mvf_unit_fb.hip: a lane owns a PY x PX block of the region)
 constexpr int RW = PX + 2;               // plane columns a lane's 3x3 windows span
 static_assert(PX == 4 || PX == 2, "row loaders below handle 4 or 2 pixels per lane");
-constexpr int NT = (TW / PX) * TH;       // 256 lanes
+static_assert(MVF_TILE_TH % MVF_TILE_PY == 0, "whole row blocks");
+constexpr int NT = (TW / PX) * (TH / PY);       // lanes per workgroup (256 at PY = 1)
 constexpr int PW = TW + 2;               // staged plane width (1-px halo)
 constexpr int PH = TH + 2;
 constexpr int LDW = TW + 4;              // LDS row stride (floats), multiple of 4

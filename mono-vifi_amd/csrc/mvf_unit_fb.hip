@@ -39,10 +39,14 @@
 // 2's ISA spent 236 64-bit VALU address instructions, partly quarter rate, on the same accesses.
 // geometry (mvf_tile.hpp): 32 x 16 region, 2 px per lane, 256 lanes; the register budget must allow 4 waves per SIMD.
 // (What other geometries measured: HISTORY.md, "Why this geometry".)
+#ifndef MVF_FB_PY
+#define MVF_FB_PY 1      // rows per lane: 1 = 256 lanes x (1 x 2) px, 4 waves per SIMD (shipped); 2 = 128 lanes x (2 x 2) px, 2 waves
+#endif                   // per SIMD with twice the registers (round 6's structural build: measured)
 #define MVF_TILE_TW 32
 #define MVF_TILE_PX 2
+#define MVF_TILE_PY MVF_FB_PY
 #define MVF_TILE_TH 16
-#define MVF_FB_WAVES 4
+#define MVF_FB_WAVES (MVF_FB_PY == 2 ? 2 : 4)
 #include "mvf_tile.hpp"
 
 namespace {
@@ -242,17 +246,21 @@ struct Stats4X {
     f2 xc[PX];
     float yc[PX];
 };
+// Window statistics of a lane's PY x PX block of region pixels.  The PY + 2 plane rows stream through ONCE: the products
+// x*x, x*y of a row are formed once and feed every output row whose window holds that row (PY = 2: 16 positions per four
+// outputs instead of 24), and each output still adds its nine taps in the reference's row-major order -- its three rows
+// arrive in order (exact mode untouched).  xs / ys point at plane element (first row of the block, PX * seg).
 #ifdef MVF_FAST_SSIM
 // Fast mode (opt-in build, never the default, never in the parity suite): what the reference's evaluation order
 // (layers.py:277-290: nine taps row-major, products rounded before they are summed) costs on this chip is measured
 // against THIS form -- separable 3x3 sums: the three rows of a column first (products folded in by fused
-// multiply-adds), then the horizontal 3-sums of the lane's two outputs with the middle column pair shared.  Per channel
-// and candidate pair: 41 packed operations for the three window sums of two pixels instead of 72; the target's sums
-// likewise.  Same quantities up to rounding (a few ulp of the sums): argmin / auto-mask may flip where candidates
-// nearly tie; the integer sampling indices are untouched (tools/fast_mode_report.py).
-MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X &o, TStat2 *t = nullptr)
+// multiply-adds), then the horizontal 3-sums of the lane's two outputs with the middle column pair shared (41 packed
+// operations for the three window sums of two pixels instead of 72; the target's sums likewise).  Same quantities up to rounding (a few ulp of the
+// sums): argmin / auto-mask may flip where candidates nearly tie; the integer sampling indices are untouched
+// (tools/fast_mode_report.py).
+MVF_DEV void window_blk(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X (&o)[PY], TStat2 *t = nullptr)
 {
-    static_assert(PX == 2, "fast-mode window sums: two pixels per lane");
+    static_assert(PX == 2 && PY == 1, "fast-mode window sums: 1 x 2 pixels per lane");
     f2 cx[RW], cxx[RW], cxy[RW];
     float cy[RW], cyy[RW];
 #pragma unroll
@@ -274,27 +282,42 @@ MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, S
         }
         if (r == 1) {
 #pragma unroll
-            for (int j = 0; j < PX; ++j) { o.xc[j] = x.v[j + 1]; o.yc[j] = y.v[j + 1]; }
+            for (int j = 0; j < PX; ++j) { o[0].xc[j] = x.v[j + 1]; o[0].yc[j] = y.v[j + 1]; }
         }
     }
     const f2 mx = cx[1] + cx[2], mxx = cxx[1] + cxx[2], mxy = cxy[1] + cxy[2];
-    o.sx[0] = cx[0] + mx; o.sx[1] = mx + cx[3];
-    o.sxx[0] = cxx[0] + mxx; o.sxx[1] = mxx + cxx[3];
-    o.sxy[0] = cxy[0] + mxy; o.sxy[1] = mxy + cxy[3];
+    o[0].sx[0] = cx[0] + mx; o[0].sx[1] = mx + cx[3];
+    o[0].sxx[0] = cxx[0] + mxx; o[0].sxx[1] = mxx + cxx[3];
+    o[0].sxy[0] = cxy[0] + mxy; o[0].sxy[1] = mxy + cxy[3];
     if (t) {
         const float my = cy[1] + cy[2], myy = cyy[1] + cyy[2];
-        t->sy = mk2(cy[0] + my, my + cy[3]);
-        t->syy = mk2(cyy[0] + myy, myy + cyy[3]);
+        t[0].sy = mk2(cy[0] + my, my + cy[3]);
+        t[0].syy = mk2(cyy[0] + myy, myy + cyy[3]);
     }
 }
-#else
-MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X &o, TStat2 *t = nullptr)
+MVF_DEV void target_rows(const float *__restrict__ ys, TStat2 (&t)[PY])
 {
+    float cy[RW], cyy[RW];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-        Row6P x = load_row6p(xs + r * LDW);
-        Row6 y = load_row6(ys + r * LDW);
-        if (t) tstat_row(y, r == 0, *t);
+        const Row6 y = load_row6(ys + r * LDW);
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            cy[i] = r == 0 ? y.v[i] : cy[i] + y.v[i];
+            cyy[i] = r == 0 ? y.v[i] * y.v[i] : fmaf(y.v[i], y.v[i], cyy[i]);
+        }
+    }
+    const float m = cy[1] + cy[2], mm = cyy[1] + cyy[2];
+    t[0].sy = mk2(cy[0] + m, m + cy[3]);
+    t[0].syy = mk2(cyy[0] + mm, mm + cyy[3]);
+}
+#else
+MVF_DEV void window_blk(const f2 *__restrict__ xs, const float *__restrict__ ys, Stats4X (&o)[PY], TStat2 *t = nullptr)
+{
+#pragma unroll
+    for (int k = 0; k < PY + 2; ++k) {
+        const Row6P x = load_row6p(xs + k * LDW);
+        const Row6 y = load_row6(ys + k * LDW);
         f2 xx[RW], xy[RW];
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
@@ -302,24 +325,40 @@ MVF_DEV void window_x(const f2 *__restrict__ xs, const float *__restrict__ ys, S
             xy[i] = x.v[i] * f2s(y.v[i]);
         }
 #pragma unroll
-        for (int j = 0; j < PX; ++j) {
+        for (int i = 0; i < PY; ++i) {
+            const int r = k - i;                 // which row of output row i's window this plane row is
+            if (r < 0 || r > 2) continue;
+            if (t) tstat_row(y, r == 0, t[i]);
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                if (r == 0 && d == 0) {
-                    o.sx[j] = x.v[j];
-                    o.sxx[j] = xx[j];
-                    o.sxy[j] = xy[j];
-                } else {
-                    o.sx[j] = o.sx[j] + x.v[j + d];
-                    o.sxx[j] = o.sxx[j] + xx[j + d];
-                    o.sxy[j] = o.sxy[j] + xy[j + d];
+            for (int j = 0; j < PX; ++j) {
+#pragma unroll
+                for (int d = 0; d < 3; ++d) {
+                    if (r == 0 && d == 0) {
+                        o[i].sx[j] = x.v[j];
+                        o[i].sxx[j] = xx[j];
+                        o[i].sxy[j] = xy[j];
+                    } else {
+                        o[i].sx[j] = o[i].sx[j] + x.v[j + d];
+                        o[i].sxx[j] = o[i].sxx[j] + xx[j + d];
+                        o[i].sxy[j] = o[i].sxy[j] + xy[j + d];
+                    }
+                }
+                if (r == 1) {
+                    o[i].xc[j] = x.v[j + 1];
+                    o[i].yc[j] = y.v[j + 1];
                 }
             }
-            if (r == 1) {
-                o.xc[j] = x.v[j + 1];
-                o.yc[j] = y.v[j + 1];
-            }
         }
+    }
+}
+MVF_DEV void target_rows(const float *__restrict__ ys, TStat2 (&t)[PY])
+{
+#pragma unroll
+    for (int k = 0; k < PY + 2; ++k) {
+        const Row6 y = load_row6(ys + k * LDW);
+#pragma unroll
+        for (int i = 0; i < PY; ++i)
+            if (k - i >= 0 && k - i <= 2) tstat_row(y, k == i, t[i]);
     }
 }
 #endif
@@ -339,72 +378,66 @@ MVF_DEV void fetch_tstats(const f2 *__restrict__ statP, f2 my[PX])
         my[j + 1] = mk2(v.z, v.w);
     }
 }
-// window means of the target alone (no auto-masking: there is no identity pass to ride on)
-MVF_DEV void target_stats(const float *__restrict__ ys, f2 my[PX])
+// window means of the target alone (no auto-masking, or the identity maps are handed over): stashed per row of the block
+MVF_DEV void target_stats(const float *__restrict__ ys, f2 *__restrict__ statP)
 {
-    TStat2 t;
-#ifdef MVF_FAST_SSIM
-    float cy[RW], cyy[RW];
+    TStat2 t[PY];
+    target_rows(ys, t);
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const Row6 y = load_row6(ys + r * LDW);
-#pragma unroll
-        for (int i = 0; i < RW; ++i) {
-            cy[i] = r == 0 ? y.v[i] : cy[i] + y.v[i];
-            cyy[i] = r == 0 ? y.v[i] * y.v[i] : fmaf(y.v[i], y.v[i], cyy[i]);
-        }
+    for (int i = 0; i < PY; ++i) {
+        f2 my[PX];
+        my[0] = div9(t[i].sy);        // (mu_y px0, mu_y px1)
+        my[1] = div9(t[i].syy);       // (E[yy] px0, E[yy] px1)
+        stash_tstats(statP + i * LDW, my);
     }
-    const float m = cy[1] + cy[2], mm = cyy[1] + cyy[2];
-    t.sy = mk2(cy[0] + m, m + cy[3]);
-    t.syy = mk2(cyy[0] + mm, mm + cyy[3]);
-#else
-#pragma unroll
-    for (int r = 0; r < 3; ++r) tstat_row(load_row6(ys + r * LDW), r == 0, t);
-#endif
-    my[0] = div9(t.sy);        // (mu_y px0, mu_y px1)
-    my[1] = div9(t.syy);       // (E[yy] px0, E[yy] px1)
 }
 // identity candidates (reference: train.py:973-985 on the raw sources), stashing the target means
 MVF_DEV void reproj_identity(const f2 *__restrict__ pair, const float *__restrict__ tgt, int off,
-                             bool no_ssim, f2 out[PX], f2 *__restrict__ statP, int roff)
+                             bool no_ssim, f2 (&out)[PY][PX], f2 *__restrict__ statP, int roff)
 {
-    f2 ab[PX], ss[PX];
+    f2 ab[PY][PX], ss[PY][PX];
 #pragma unroll
-    for (int j = 0; j < PX; ++j) ab[j] = ss[j] = f2s(0.0f);
+    for (int i = 0; i < PY; ++i)
+#pragma unroll
+        for (int j = 0; j < PX; ++j) ab[i][j] = ss[i][j] = f2s(0.0f);
 #pragma unroll 1
     for (int c = 0; c < 3; ++c) {
         if (no_ssim) {
-            Row6P x = load_row6p(pair + c * PPLANE + off + LDW);
-            Row6 y = load_row6(tgt + c * PLANE + off + LDW);
 #pragma unroll
-            for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(y.v[j + 1]) - x.v[j + 1]);
-        } else {
-            Stats4X s;
-            TStat2 t;
-            window_x(pair + c * PPLANE + off, tgt + c * PLANE + off, s, &t);
-            f2 my[PX];
-            my[0] = div9(t.sy);        // (mu_y px0, mu_y px1)
-            my[1] = div9(t.syy);       // (E[yy] px0, E[yy] px1)
+            for (int i = 0; i < PY; ++i) {
+                Row6P x = load_row6p(pair + c * PPLANE + off + (i + 1) * LDW);
+                Row6 y = load_row6(tgt + c * PLANE + off + (i + 1) * LDW);
 #pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const f2 m = tstat_of(my, j);
-                f2 raw = ssim_raw_pk(div9(s.sx[j]), f2s(m.x), div9(s.sxx[j]), f2s(m.y), div9(s.sxy[j]));
-                ss[j] = ss[j] + clamp01_med3_pk(raw);
-                ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
+                for (int j = 0; j < PX; ++j) ab[i][j] = ab[i][j] + pk_abs(f2s(y.v[j + 1]) - x.v[j + 1]);
             }
-            stash_tstats(statP + c * RPPLANE + roff, my);
+        } else {
+            Stats4X s[PY];
+            TStat2 t[PY];
+            window_blk(pair + c * PPLANE + off, tgt + c * PLANE + off, s, t);
+#pragma unroll
+            for (int i = 0; i < PY; ++i) {
+                f2 my[PX];
+                my[0] = div9(t[i].sy);        // (mu_y px0, mu_y px1)
+                my[1] = div9(t[i].syy);       // (E[yy] px0, E[yy] px1)
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const f2 m = tstat_of(my, j);
+                    f2 raw = ssim_raw_pk(div9(s[i].sx[j]), f2s(m.x), div9(s[i].sxx[j]), f2s(m.y), div9(s[i].sxy[j]));
+                    ss[i][j] = ss[i][j] + clamp01_med3_pk(raw);
+                    ab[i][j] = ab[i][j] + pk_abs(f2s(s[i].yc[j]) - s[i].xc[j]);
+                }
+                stash_tstats(statP + c * RPPLANE + roff + i * LDW, my);
+            }
         }
     }
 #pragma unroll
-    for (int j = 0; j < PX; ++j) {
-        f2 l1 = div3(ab[j]);
-        out[j] = no_ssim ? l1 : 0.85f * div3(ss[j]) + 0.15f * l1;
-    }
+    for (int i = 0; i < PY; ++i)
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            f2 l1 = div3(ab[i][j]);
+            out[i][j] = no_ssim ? l1 : 0.85f * div3(ss[i][j]) + 0.15f * l1;
+        }
 }
-
-// warp of the source pair into the pair planes: plane positions tid + k*NT, k < NSTAGE.  Full
-// iterations take U positions at a time (their divide chains interleave, all taps in flight);
-// the last position runs alone, and waves whose positions all lie beyond the plane skip it.
 
 // What phase 7 needs of the forward's projection chain at an output pixel, kept in SIX registers per
 // position: per source the byte offset of the row-y0 tap pair (< 2^28) with four flags above it (pair
@@ -489,7 +522,7 @@ MVF_DEV void warp_issue(const WarpCtx &k, int slot0, WarpBatch<U> &w)
         const bool live = fb_slot_pos(slot0 + u, r, c);
         w.s[u] = warp_slot_rc(r, c, live, k.dispP, k.iK, k.P2, k.H, k.W, k.py0, k.px0, k.min_disp, k.range, k.eps,
                               k.inner);
-        if (slot0 + u < 2) k.stash[slot0 + u] = pack_taps(w.s[u]);
+        if (slot0 + u < (TW * (TH - 2) + NT - 1) / NT) k.stash[slot0 + u] = pack_taps(w.s[u]);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -611,12 +644,11 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // the image's constants: one 128-byte line of the table k_units_prepare wrote, in flight with the staging loads
     if (threadIdx.x < TABF)
         reinterpret_cast<float *>(&sh)[threadIdx.x] = a.tab[(size_t)ub * TABF + threadIdx.x];
-    const int seg = threadIdx.x & (TW / PX - 1), row = threadIdx.x / (TW / PX);
-    const int off = row * LDW + seg * PX;     // plane element of the window's top-left
+    // a lane owns a PY x PX block of region pixels: rows row0 .. row0 + PY - 1, columns seg * PX ..
+    const int seg = threadIdx.x & (TW / PX - 1), row0 = (threadIdx.x / (TW / PX)) * PY;
+    const int off = row0 * LDW + seg * PX;    // plane element of the window's top-left (of the block's first row)
     const int roff = off;                     // region-plane element of this lane's first pixel
-    const int y = cy0 + row, x0 = cx0 + seg * PX;
-    const bool rowin = (y >= 0) && (y < H);
-    const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
+    const int y0 = cy0 + row0, x0 = cx0 + seg * PX;
 
     // ---- 1: target, disparity (and the identity pair) -> LDS
     // tiles whose staged plane lies inside the image need no reflect / clamp mapping of the
@@ -653,19 +685,23 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         k.idx_b = (!MVF_ANALYSIS && u.idx_xy) ? u.idx_xy + ((size_t)kb * a.B + b) * N * 2 : nullptr;
         k.inner = inner;
     }
-    TapStash stash[2] = {};
+    constexpr int NSTASH = (TW * (TH - 2) + NT - 1) / NT;     // adjoint positions per lane (phase 7 walks TW x OH)
+    TapStash stash[NSTASH] = {};
     wk_ctx.stash = stash;
 
     // ---- 2: identity candidates of every region pixel
     MVF_PHASE("2_identity");
-    f2 vid[PX];
+    f2 vid[PY][PX];
 #pragma unroll
-    for (int j = 0; j < PX; ++j) vid[j] = f2s(0.0f);
+    for (int i = 0; i < PY; ++i)
+#pragma unroll
+        for (int j = 0; j < PX; ++j) vid[i][j] = f2s(0.0f);
     if (automask && !ident_given) {
 #ifndef MVF_ABL_NOID     // timing ablation: identity candidates not evaluated
         reproj_identity(pairP, tgtP, off, no_ssim, vid, coefP, roff);
 #else
-        for (int j = 0; j < PX; ++j) vid[j] = pairP[off + LDW + 1 + j];
+        for (int i = 0; i < PY; ++i)
+            for (int j = 0; j < PX; ++j) vid[i][j] = pairP[off + (i + 1) * LDW + 1 + j];
 #endif
         __syncthreads();                       // identity pair consumed
     } else {
@@ -675,19 +711,17 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             // in flight while the target statistics below are evaluated
             const float *idb = uniform_ptr(u.ident_in + (size_t)b * N * 2);
 #pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                const int yc = min(max(y, 0), H - 1), xc = min(max(x0 + j, 0), W - 1);
-                const float2 v = ldg_f2_at(idb, plane_off4(yc, xc, W) * 2u);
-                vid[j] = mk2(v.x, v.y);
-            }
+            for (int i = 0; i < PY; ++i)
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    const int yc = min(max(y0 + i, 0), H - 1), xc = min(max(x0 + j, 0), W - 1);
+                    const float2 v = ldg_f2_at(idb, plane_off4(yc, xc, W) * 2u);
+                    vid[i][j] = mk2(v.x, v.y);
+                }
         }
         if (!no_ssim) {
 #pragma unroll 1
-            for (int c = 0; c < 3; ++c) {
-                f2 my[PX];
-                target_stats(tgtP + c * PLANE + off, my);
-                stash_tstats(coefP + c * RPPLANE + roff, my);
-            }
+            for (int c = 0; c < 3; ++c) target_stats(tgtP + c * PLANE + off, coefP + c * RPPLANE + roff);
         }
     }
 
@@ -704,16 +738,18 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // (channel loops unrolled: round 2 rolled them and rotated the partials through three slots,
     // 24 register moves per channel here and again in phase 6)
     MVF_PHASE("4_ssim_warped");
-    f2 pm[3][PX], px2[3][PX], pg[3][PX];      // d/d mu_x, 2 d/d E[xx], d/d E[xy]
-    f2 vw[PX];
+    f2 pm[3][PY][PX], px2[3][PY][PX], pg[3][PY][PX];      // d/d mu_x, 2 d/d E[xx], d/d E[xy]
+    f2 vw[PY][PX];
     {
-        f2 ab[PX], ss[PX];
+        f2 ab[PY][PX], ss[PY][PX];
 #pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            ab[j] = ss[j] = f2s(0.0f);
+        for (int i = 0; i < PY; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q) pm[q][j] = px2[q][j] = pg[q][j] = f2s(0.0f);
-        }
+            for (int j = 0; j < PX; ++j) {
+                ab[i][j] = ss[i][j] = f2s(0.0f);
+#pragma unroll
+                for (int q = 0; q < 3; ++q) pm[q][i][j] = px2[q][i][j] = pg[q][i][j] = f2s(0.0f);
+            }
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
 #ifdef MVF_ABL_NOSSIM4
@@ -721,47 +757,57 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #else
             if (no_ssim) {
 #endif
-                Row6P x = load_row6p(pairP + c * PPLANE + off + LDW);
-                Row6 yv = load_row6(tgtP + c * PLANE + off + LDW);
 #pragma unroll
-                for (int j = 0; j < PX; ++j) ab[j] = ab[j] + pk_abs(f2s(yv.v[j + 1]) - x.v[j + 1]);
+                for (int i = 0; i < PY; ++i) {
+                    Row6P x = load_row6p(pairP + c * PPLANE + off + (i + 1) * LDW);
+                    Row6 yv = load_row6(tgtP + c * PLANE + off + (i + 1) * LDW);
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) ab[i][j] = ab[i][j] + pk_abs(f2s(yv.v[j + 1]) - x.v[j + 1]);
+                }
             } else {
-                Stats4X s;
-                window_x(pairP + c * PPLANE + off, tgtP + c * PLANE + off, s);
-                f2 tm[PX];                 // (mu_y, E[y*y]) stashed by the identity / target pass
-                fetch_tstats(coefP + c * RPPLANE + roff, tm);
+                Stats4X st[PY];
+                window_blk(pairP + c * PPLANE + off, tgtP + c * PLANE + off, st);
 #pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    const f2 my = tstat_of(tm, j);
-                    f2 val;
-                    ssim_val_partials_pk(div9(s.sx[j]), f2s(my.x), div9(s.sxx[j]), f2s(my.y),
-                                         div9(s.sxy[j]), val, pm[c][j], px2[c][j], pg[c][j]);
-                    ss[j] = ss[j] + val;
-                    ab[j] = ab[j] + pk_abs(f2s(s.yc[j]) - s.xc[j]);
+                for (int i = 0; i < PY; ++i) {
+                    f2 tm[PX];                 // (mu_y, E[y*y]) stashed by the identity / target pass
+                    fetch_tstats(coefP + c * RPPLANE + roff + i * LDW, tm);
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        const f2 my = tstat_of(tm, j);
+                        f2 val;
+                        ssim_val_partials_pk(div9(st[i].sx[j]), f2s(my.x), div9(st[i].sxx[j]), f2s(my.y),
+                                             div9(st[i].sxy[j]), val, pm[c][i][j], px2[c][i][j], pg[c][i][j]);
+                        ss[i][j] = ss[i][j] + val;
+                        ab[i][j] = ab[i][j] + pk_abs(f2s(st[i].yc[j]) - st[i].xc[j]);
+                    }
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            f2 l1 = div3(ab[j]);
-            vw[j] = no_ssim ? l1 : 0.85f * div3(ss[j]) + 0.15f * l1;
-        }
+        for (int i = 0; i < PY; ++i)
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                f2 l1 = div3(ab[i][j]);
+                vw[i][j] = no_ssim ? l1 : 0.85f * div3(ss[i][j]) + 0.15f * l1;
+            }
     }
 
     // mask and tie-break noise of this lane's region pixels.  Fetched / drawn here rather than in
     // the prologue: six registers less across the warp and SSIM phases (128-VGPR budget of 4
     // waves per SIMD); with 4 workgroups per CU the one exposed load latency is covered
     MVF_PHASE("5a_mask_noise");
-    float mraw[PX];            // mask value (1 without a mask), 0 outside the image
-    f2 nz[PX];
+    float mraw[PY][PX];        // mask value (1 without a mask), 0 outside the image
+    f2 nz[PY][PX];
     const float *mask_b = (MVF_ANALYSIS ? (MVF_ANALYSIS == 3) : (u.mask != nullptr)) ? uniform_ptr(u.mask + (size_t)b * u.mask_stride) : nullptr;
 #pragma unroll
+    for (int i = 0; i < PY; ++i)
+#pragma unroll
     for (int j = 0; j < PX; ++j) {
-        const int x = x0 + j;
-        const bool in = rowin && (x >= 0) && (x < W);
+        const int x = x0 + j, y = y0 + i;
+        const bool in = (y >= 0) && (y < H) && (x >= 0) && (x < W);
         const unsigned pix4 = plane_off4(min(max(y, 0), H - 1), min(max(x, 0), W - 1), W);
-        mraw[j] = in ? (mask_b ? ldg_at(mask_b, pix4) : 1.0f) : 0.0f;
-        nz[j] = f2s(0.0f);
+        mraw[i][j] = in ? (mask_b ? ldg_at(mask_b, pix4) : 1.0f) : 0.0f;
+        nz[i][j] = f2s(0.0f);
 #ifdef MVF_ABL_NONOISE   // timing ablation: no tie-break noise
         if (false) {
 #else
@@ -769,14 +815,14 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 #endif
             if (!MVF_ANALYSIS && u.noise) {
                 const float *nb = uniform_ptr(u.noise + (size_t)b * (avg ? 1 : S) * N);
-                if (avg) nz[j] = f2s(ldg_at(nb, pix4));
-                else nz[j] = mk2(ldg_at(nb, pix4), hasb ? ldg_at(nb + N, pix4) : 0.0f);
+                if (avg) nz[i][j] = f2s(ldg_at(nb, pix4));
+                else nz[i][j] = mk2(ldg_at(nb, pix4), hasb ? ldg_at(nb + N, pix4) : 0.0f);
             } else {
-                nz[j] = normal_pair(u.seed0, u.seed1, (uint32_t)b * (uint32_t)N + (pix4 >> 2));
+                nz[i][j] = normal_pair(u.seed0, u.seed1, (uint32_t)b * (uint32_t)N + (pix4 >> 2));
                 if (!MVF_ANALYSIS && u.noise_out) {
                     float *nb = uniform_ptr(u.noise_out + (size_t)b * (avg ? 1 : S) * N);
-                    stg_at(nb, pix4, nz[j].x);
-                    if (!avg && hasb) stg_at(nb + N, pix4, nz[j].y);
+                    stg_at(nb, pix4, nz[i][j].x);
+                    if (!avg && hasb) stg_at(nb + N, pix4, nz[i][j].y);
                 }
             }
         }
@@ -784,54 +830,60 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
 
     // ---- 5: min / argmin / mask / outputs (reference: train.py:1010-1043)
     MVF_PHASE("5b_argmin_outputs");
-    f2 wk[PX];                 // adjoint weight of the two warped candidates
+    f2 wk[PY][PX];             // adjoint weight of the two warped candidates
     float fb_photo = 0.0f;
 #ifdef MVF_ABL_NO5       // timing ablation: no min / argmin / mask / outputs (every candidate value stays live)
 #pragma unroll
+    for (int i = 0; i < PY; ++i)
+#pragma unroll
     for (int j = 0; j < PX; ++j) {
-        asm volatile("" :: "v"(vw[j]), "v"(vid[j]), "v"(nz[j]));
-        wk[j] = f2s(a.gpix * mraw[j]);
+        asm volatile("" :: "v"(vw[i][j]), "v"(vid[i][j]), "v"(nz[i][j]));
+        wk[i][j] = f2s(a.gpix * mraw[i][j]);
     }
     if (false)
 #endif
 #pragma unroll
+    for (int i = 0; i < PY; ++i)
+#pragma unroll
     for (int j = 0; j < PX; ++j) {
-        const int x = x0 + j, col = seg * PX + j;
+        const int x = x0 + j, col = seg * PX + j, y = y0 + i, row = row0 + i;
+        const bool rowin = (y >= 0) && (y < H);
+        const bool row_out = (row >= 1) && (row <= OH) && rowin;   // interior (= output) rows
         const bool in = rowin && (x >= 0) && (x < W);
         const unsigned pix4 = plane_off4(min(max(y, 0), H - 1), min(max(x, 0), W - 1), W);
         float best = 0.0f;
         int bi = 0, nc = 0;
         if (automask) {
             if (avg) {
-                float m = vid[j].x;
-                if (hasb) m = m + vid[j].y;
+                float m = vid[i][j].x;
+                if (hasb) m = m + vid[i][j].y;
                 m = m / (float)S;
-                best = m + nz[j].x * 0.00001f;
+                best = m + nz[i][j].x * 0.00001f;
                 nc = 1;
             } else {
 #pragma unroll
                 for (int k = 0; k < S; ++k) {
-                    float v = (k == 0 ? vid[j].x : vid[j].y) + (k == 0 ? nz[j].x : nz[j].y) * 0.00001f;
+                    float v = (k == 0 ? vid[i][j].x : vid[i][j].y) + (k == 0 ? nz[i][j].x : nz[i][j].y) * 0.00001f;
                     if (nc == 0 || v < best) { best = v; bi = nc; }
                     ++nc;
                 }
             }
         }
         if (avg) {
-            float m = vw[j].x;
-            if (hasb) m = m + vw[j].y;
+            float m = vw[i][j].x;
+            if (hasb) m = m + vw[i][j].y;
             m = m / (float)S;
             if (nc == 0 || m < best) { best = m; bi = nc; }
             ++nc;
         } else {
 #pragma unroll
             for (int k = 0; k < S; ++k) {
-                float v = (k == 0) ? vw[j].x : vw[j].y;
+                float v = (k == 0) ? vw[i][j].x : vw[i][j].y;
                 if (nc == 0 || v < best) { best = v; bi = nc; }
                 ++nc;
             }
         }
-        if (mask_b) best = best * mraw[j];
+        if (mask_b) best = best * mraw[i][j];
         const int sel = (nc > 1) ? bi : 255;
         const bool outp = row_out && (col >= 1) && (col <= OW) && in;
         if (outp) {
@@ -839,7 +891,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
             if (!MVF_ANALYSIS && u.auto_mask_out) stg_at(uniform_ptr(u.auto_mask_out + (size_t)b * N), pix4, (bi > n_id - 1) ? 1.0f : 0.0f);
             if (!MVF_ANALYSIS && u.to_opt_out) stg_at(uniform_ptr(u.to_opt_out + (size_t)b * N), pix4, best);
             if ((MVF_ANALYSIS ? MVF_ANALYSIS == 1 : (u.ident_out != nullptr)) && automask)
-                stg_f2_at(uniform_ptr(u.ident_out + (size_t)b * N * 2), pix4 * 2u, make_float2(vid[j].x, vid[j].y));
+                stg_f2_at(uniform_ptr(u.ident_out + (size_t)b * N * 2), pix4 * 2u, make_float2(vid[i][j].x, vid[i][j].y));
             fb_photo += best;
         }
         // selection weight of the two sources: the argmin picked it (or the averaged channel)
@@ -847,8 +899,8 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
         if (sel == 255) wa = wb = avg ? 1.0f / (float)S : 1.0f;        // single candidate
         else if (avg) wa = wb = (sel == n_id) ? 1.0f / (float)S : 0.0f;
         else { wa = (sel == n_id) ? 1.0f : 0.0f; wb = (sel == n_id + 1) ? 1.0f : 0.0f; }
-        const float wbase = a.gpix * mraw[j];                          // 0 outside the image
-        wk[j] = mk2(wbase * wa, hasb ? wbase * wb : 0.0f);
+        const float wbase = a.gpix * mraw[i][j];                          // 0 outside the image
+        wk[i][j] = mk2(wbase * wa, hasb ? wbase * wb : 0.0f);
     }
 
     // ---- 6: SSIM adjoint, one channel at a time through the coefficient planes.
@@ -860,7 +912,6 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // hold row sums, and the vertical step reads two rows instead of nine row segments.
     // Reflect-pad multiplicities only exist next to the image border (rows 1, H-2, cols 1, W-2).
     MVF_PHASE("6_ssim_adjoint");
-    const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
     float mlx[PX], mrx[PX];
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
@@ -881,91 +932,117 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     auto from_right = [&](f2 v) { return mk2(dpp1(v.x, true), dpp1(v.y, true)); };     // lane seg+1 (0 at seg 15)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        f2 hs[3][PX];              // row sums of A, B, G at this lane's columns
+        f2 hs[3][PY][PX];          // row sums of A, B, G at this lane's columns, per row of its block
 #ifdef MVF_ABL_NO6H      // timing ablation: no SSIM adjoint at all (coefficients, DPP row sums, LDS round trip, gather)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-            for (int j = 0; j < PX; ++j) {
-                asm volatile("" :: "v"(pm[c][j]), "v"(px2[c][j]), "v"(pg[c][j]));
-                hs[pl][j] = f2s(0.0f);
-            }
+            for (int i = 0; i < PY; ++i)
+#pragma unroll
+                for (int j = 0; j < PX; ++j) {
+                    asm volatile("" :: "v"(pm[c][i][j]), "v"(px2[c][i][j]), "v"(pg[c][i][j]));
+                    hs[pl][i][j] = f2s(0.0f);
+                }
         if (false) {
 #else
         if (!no_ssim) {
 #endif
             if (c > 0) __syncthreads();        // vertical reads of the previous channel done
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                f2 cf[PX + 2];
+            for (int pl = 0; pl < 3; ++pl)
 #pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    const f2 g = wk[j] * ((0.85f / 3.0f) / 9.0f);
-                    cf[j + 1] = g * (pl == 0 ? pm[c][j] : (pl == 1 ? px2[c][j] : pg[c][j]));
+                for (int i = 0; i < PY; ++i) {
+                    f2 cf[PX + 2];
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        const f2 g = wk[i][j] * ((0.85f / 3.0f) / 9.0f);
+                        cf[j + 1] = g * (pl == 0 ? pm[c][i][j] : (pl == 1 ? px2[c][i][j] : pg[c][i][j]));
+                    }
+                    cf[0] = from_left(cf[PX]);
+                    cf[PX + 1] = from_right(cf[1]);
+                    if (col_border) {
+#pragma unroll
+                        for (int j = 0; j < PX; ++j)
+                            hs[pl][i][j] = pk_fma(f2s(mrx[j]), cf[j + 2], pk_fma(f2s(mlx[j]), cf[j], cf[j + 1]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) hs[pl][i][j] = (cf[j] + cf[j + 1]) + cf[j + 2];
+                    }
+                    // (with PY > 1 only the block's first and last row are read by other lanes, but every row is some
+                    // block's first or last for PY <= 2)
+                    float4 *cp = reinterpret_cast<float4 *>(coefP + pl * RPPLANE + roff + i * LDW);
+#pragma unroll
+                    for (int j = 0; j < PX; j += 2)
+                        cp[j / 2] = make_float4(hs[pl][i][j].x, hs[pl][i][j].y, hs[pl][i][j + 1].x, hs[pl][i][j + 1].y);
                 }
-                cf[0] = from_left(cf[PX]);
-                cf[PX + 1] = from_right(cf[1]);
-                if (col_border) {
-#pragma unroll
-                    for (int j = 0; j < PX; ++j)
-                        hs[pl][j] = pk_fma(f2s(mrx[j]), cf[j + 2], pk_fma(f2s(mlx[j]), cf[j], cf[j + 1]));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < PX; ++j) hs[pl][j] = (cf[j] + cf[j + 1]) + cf[j + 2];
-                }
-                float4 *cp = reinterpret_cast<float4 *>(coefP + pl * RPPLANE + roff);
-#pragma unroll
-                for (int j = 0; j < PX; j += 2)
-                    cp[j / 2] = make_float4(hs[pl][j].x, hs[pl][j].y, hs[pl][j + 1].x, hs[pl][j + 1].y);
-            }
             __syncthreads();
         }
-        // own centre values (the pair plane of this channel is only read by its owner from now on)
-        f2 xq[PX], gw[PX];
-        float yq[PX];
-        {
-            const f2 *xc = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
-            const float *yc = tgtP + c * PLANE + (row + 1) * LDW + seg * PX + 1;
 #pragma unroll
-            for (int j = 0; j < PX; ++j) { xq[j] = xc[j]; yq[j] = yc[j]; }
-        }
+        for (int i = 0; i < PY; ++i) {
+            const int row = row0 + i, y = y0 + i;
+            const float myu = (y == 1) ? 2.0f : 1.0f, myd = (y == H - 2) ? 2.0f : 1.0f;
+            // own centre values (the pair plane of this channel is only read by its owner from now on)
+            f2 xq[PX], gw[PX];
+            float yq[PX];
+            {
+                const f2 *xc = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
+                const float *yc = tgtP + c * PLANE + (row + 1) * LDW + seg * PX + 1;
 #pragma unroll
-        for (int j = 0; j < PX; ++j) {
-            // L1 term: d|t-p|/dp = -sign(t-p), channel mean
-            f2 df = f2s(yq[j]) - xq[j];
-            f2 sg = mk2(sign_of(df.x), sign_of(df.y));      // d|t - p| / dp = -sign(t - p): the minus sits in the constant
-            gw[j] = wk[j] * (-(no_ssim ? 1.0f : 0.15f) * (1.0f / 3.0f)) * sg;
-        }
+                for (int j = 0; j < PX; ++j) { xq[j] = xc[j]; yq[j] = yc[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < PX; ++j) {
+                // L1 term: d|t-p|/dp = -sign(t-p), channel mean
+                f2 df = f2s(yq[j]) - xq[j];
+                f2 sg = mk2(sign_of(df.x), sign_of(df.y));      // d|t - p| / dp = -sign(t - p): the minus sits in the constant
+                gw[j] = wk[i][j] * (-(no_ssim ? 1.0f : 0.15f) * (1.0f / 3.0f)) * sg;
+            }
 #if defined(MVF_ABL_NOGATHER) || defined(MVF_ABL_NO6H)
-        if (false) {
+            if (false) {
 #else
-        if (!no_ssim && row >= 1 && row <= OH) {
+            if (!no_ssim && row >= 1 && row <= OH) {
 #endif
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                const float4 *up = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff - LDW);
-                const float4 *dn = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff + LDW);
-                f2 uu[PX], dd[PX];
+                for (int pl = 0; pl < 3; ++pl) {
+                    // the rows above and below: the block's own (registers) or another lane's (LDS)
+                    f2 uu[PX], dd[PX];
+                    if (i == 0) {
+                        const float4 *up = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff - LDW);
 #pragma unroll
-                for (int j = 0; j < PX; j += 2) {
-                    const float4 uv = up[j / 2], d = dn[j / 2];
-                    uu[j] = mk2(uv.x, uv.y); uu[j + 1] = mk2(uv.z, uv.w);
-                    dd[j] = mk2(d.x, d.y); dd[j + 1] = mk2(d.z, d.w);
-                }
+                        for (int j = 0; j < PX; j += 2) {
+                            const float4 uv = up[j / 2];
+                            uu[j] = mk2(uv.x, uv.y); uu[j + 1] = mk2(uv.z, uv.w);
+                        }
+                    } else {
 #pragma unroll
-                for (int j = 0; j < PX; ++j) {
-                    const f2 t = pk_fma(f2s(myd), dd[j], pk_fma(f2s(myu), uu[j], hs[pl][j]));     // adjoint: tolerance arithmetic
-                    if (pl == 0) gw[j] += t;
-                    else if (pl == 1) gw[j] = pk_fma(xq[j], t, gw[j]);
-                    else gw[j] = pk_fma(f2s(yq[j]), t, gw[j]);
+                        for (int j = 0; j < PX; ++j) uu[j] = hs[pl][i > 0 ? i - 1 : 0][j];
+                    }
+                    if (i == PY - 1) {
+                        const float4 *dn = reinterpret_cast<const float4 *>(coefP + pl * RPPLANE + roff + PY * LDW);
+#pragma unroll
+                        for (int j = 0; j < PX; j += 2) {
+                            const float4 d = dn[j / 2];
+                            dd[j] = mk2(d.x, d.y); dd[j + 1] = mk2(d.z, d.w);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < PX; ++j) dd[j] = hs[pl][i < PY - 1 ? i + 1 : i][j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < PX; ++j) {
+                        const f2 t = pk_fma(f2s(myd), dd[j], pk_fma(f2s(myu), uu[j], hs[pl][i][j]));     // adjoint: tolerance arithmetic
+                        if (pl == 0) gw[j] += t;
+                        else if (pl == 1) gw[j] = pk_fma(xq[j], t, gw[j]);
+                        else gw[j] = pk_fma(f2s(yq[j]), t, gw[j]);
+                    }
                 }
             }
-        }
-        // park grad_warped of this channel in its own pair plane (own entries only)
-        {
-            f2 *gp = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
+            // park grad_warped of this channel in its own pair plane (own entries only)
+            {
+                f2 *gp = pairP + c * PPLANE + (row + 1) * LDW + seg * PX + 1;
 #pragma unroll
-            for (int j = 0; j < PX; ++j) gp[j] = gw[j];
+                for (int j = 0; j < PX; ++j) gp[j] = gw[j];
+            }
         }
     }
     __syncthreads();      // every grad_warped is parked
@@ -991,7 +1068,7 @@ __global__ void __launch_bounds__(NT, MVF_FB_WAVES) k_unit_fb(FbArgs a)
     // (the OH interior rows are enumerated, TW lanes each: 448 positions = 7 wave passes, same as the 420 of an OW-wide
     // walk; see fb_slot_pos for why the rows are TW wide)
     constexpr int NPOS7 = TW * OH;
-#pragma unroll 2
+#pragma unroll
     for (int k = 0; k < (NPOS7 + NT - 1) / NT; ++k) {
         const int p = (int)threadIdx.x + k * NT;
         if ((NPOS7 % NT) && ((int)(threadIdx.x & ~(kWave - 1)) + k * NT >= NPOS7)) break;   // whole wave beyond: wave-uniform

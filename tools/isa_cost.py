@@ -89,14 +89,31 @@ def main():
     per = collections.OrderedDict()
     top = collections.defaultdict(collections.Counter)
     ended = False
-    for l in body:
+    # Blocks the compiler laid out behind the first s_endpgm: the IEEE fallbacks of the guarded fast divides (never run:
+    # they hold v_div_scale / v_div_fixup) -- and, since round 6, HOT blocks it moved there by branch weight (the tap
+    # adjoint of the second position round of phase 7): those are priced with the phase they belong to.
+    end_at = next(i for i, l in enumerate(body) if l.strip().startswith("s_endpgm"))
+    block_phase, cur, has_div = {}, None, False
+    for i, l in enumerate(body[end_at + 1:], end_at + 1):
+        t = l.strip()
+        if re.match(r"^\.LBB\S*:", t):
+            if cur is not None:
+                block_phase[cur] = "cold_out_of_line" if has_div else "7_8_adjoint_smooth"
+            cur, has_div = i, False
+        if t.startswith(("v_div_scale", "v_div_fixup", "v_div_fmas")):
+            has_div = True
+    if cur is not None:
+        block_phase[cur] = "cold_out_of_line" if has_div else "7_8_adjoint_smooth"
+    for i, l in enumerate(body):
         t = l.strip()
         m = re.match(r"; MVF_PHASE (\S+)", t)
         if m:
             phase = m.group(1)
             continue
-        if ended and phase != "cold_out_of_line":
-            phase = "cold_out_of_line"       # blocks behind the first s_endpgm: the IEEE fallbacks of the guarded fast divides
+        if ended and i in block_phase:
+            phase = block_phase[i]
+        elif ended and phase not in ("cold_out_of_line", "7_8_adjoint_smooth"):
+            phase = "cold_out_of_line"
         if t.startswith("s_endpgm"):
             ended = True
         if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
