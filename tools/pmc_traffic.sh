@@ -2,7 +2,7 @@
 # per MI355X_MICROARCH.md.  Writes gpurun_out/pmc_traffic.csv (mean KB per launch).
 R=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-HP="python $R/bench.py --workload hotpath --steps 4 --warmup 2 --no-cpu-baseline"
+HP="python $R/bench.py --workload hotpath --steps 4 --warmup 2 --no-cpu-baseline --no-pmc-leg"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_f -- $HP > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_w -- $HP > /dev/null 2>&1
 cd $R
