@@ -40,6 +40,22 @@ def test_library_exports_every_declared_symbol(built):
     assert handle.mvf_abi_version() == built.ABI_VERSION
 
 
+def test_fast_build_is_a_separate_library_with_the_same_abi(built):
+    """Round 6: the opt-in fast mode (`make fast`, -DMVF_FAST_SSIM) is a SEPARATE library with the same entry points and
+    ABI version; the product loads the exact-mode library unless a process names another one with MVF_HOTPATH_LIB, and the
+    parity suite never does."""
+    fast = os.path.join(os.path.dirname(built.LIB_PATH), "libmvf_hotpath_fast.so")
+    assert os.path.exists(fast), fast
+    assert os.path.basename(built.LIB_PATH) == "libmvf_hotpath.so" or os.environ.get("MVF_HOTPATH_LIB")
+    handle = ctypes.CDLL(fast)
+    for name in header_symbols():
+        assert hasattr(handle, name), f"{name} missing from the fast build"
+    assert handle.mvf_abi_version() == built.ABI_VERSION
+    for f in os.listdir(os.path.join(ROOT, "tests")):
+        if f.endswith(".py") and f != "test_abi.py":
+            assert "libmvf_hotpath_fast" not in open(os.path.join(ROOT, "tests", f)).read(), f
+
+
 def test_binding_covers_the_header(built):
     assert sorted(built.EXPORTS) == header_symbols()
     lib = built.lib()
