@@ -543,23 +543,65 @@ __global__ void __launch_bounds__(NT) k_anc_fill(AncLevels L)
     const int slot = v.off[sb * (n + 1) + a.anchor] + atomicAdd(v.cur + sb * n + a.anchor, 1);
     v.ent[sb * n + slot] = make_int4(i, __float_as_int(a.wx), __float_as_int(a.wy), __float_as_int(a.sc));
 }
-// every anchor sorts its list by output pixel (lists average one entry: most lanes have nothing to do)
-__global__ void __launch_bounds__(NT) k_anc_sort(AncLevels L)
+// every anchor sorts its list by output pixel (lists average one entry: most lanes have nothing to do).  Lists of 3 .. 32
+// entries: insertion sort by the anchor's lane.  Longer lists -- a flow field that leaves the image piles a row's pixels on
+// that row's border anchor (the taps clamp) -- are sorted by the whole WAVE, one list after the other (one lane
+// moved O(L^2) entries through global memory): rank sort, every lane holds up to ANC_KMAX of the list's entries, counts for
+// each the entries with a smaller pixel index (the list is streamed through the wave 64 keys at a time) and writes it to
+// its rank; L^2 / 64 compares per lane, no dependent memory traffic.  Lists beyond 64 * ANC_KMAX entries (only a flow
+// that throws most of an image onto ONE anchor) keep the serial sort.
+constexpr int ANC_SERIAL = 32, ANC_KMAX = 16;
+MVF_DEV void anc_sort_serial(int4 *__restrict__ ent, int lo, int hi)
 {
-    const int lv = level_of_block(L, blockIdx.x);
-    const AncLevel &v = L.l[lv];
-    const int n = v.h * v.w, q = (blockIdx.x - v.blk0) * NT + threadIdx.x;
-    if (q >= n) return;
-    const size_t sb = (size_t)blockIdx.z * L.B + blockIdx.y;
-    const int *off = v.off + sb * (n + 1);
-    int4 *ent = v.ent + sb * n;
-    const int lo = off[q], hi = off[q + 1];
-    if (hi - lo < 3) return;            // a pair is put in order by its reader (k_fusion_level_bwd_anchor)
     for (int a = lo + 1; a < hi; ++a) {
         const int4 e = ent[a];
         int c = a - 1;
         while (c >= lo && ent[c].x > e.x) { ent[c + 1] = ent[c]; --c; }
         ent[c + 1] = e;
+    }
+}
+MVF_DEV void anc_sort_wave(int4 *__restrict__ ent, int lo, int hi)      // all 64 lanes, wave-uniform arguments
+{
+    const int lane = threadIdx.x & (kWave - 1), len = hi - lo;
+    int4 mine[ANC_KMAX];
+    int rank[ANC_KMAX];
+#pragma unroll
+    for (int k = 0; k < ANC_KMAX; ++k) {
+        const int a = lane + k * kWave;
+        mine[k] = ent[lo + min(a, len - 1)];
+        rank[k] = 0;
+    }
+    for (int c0 = 0; c0 < len; c0 += kWave) {
+        const int key = (c0 + lane < len) ? ent[lo + c0 + lane].x : 0x7fffffff;
+#pragma unroll 8
+        for (int j = 0; j < kWave; ++j) {
+            const int other = __shfl(key, j);
+#pragma unroll
+            for (int k = 0; k < ANC_KMAX; ++k) rank[k] += (other < mine[k].x) ? 1 : 0;      // pixel indices are distinct
+        }
+    }
+    // every load of the list above has returned (the ranks depend on them) before the first store below is issued
+#pragma unroll
+    for (int k = 0; k < ANC_KMAX; ++k)
+        if (lane + k * kWave < len) ent[lo + rank[k]] = mine[k];
+}
+__global__ void __launch_bounds__(NT) k_anc_sort(AncLevels L)
+{
+    const int lv = level_of_block(L, blockIdx.x);
+    const AncLevel &v = L.l[lv];
+    const int n = v.h * v.w, q = (blockIdx.x - v.blk0) * NT + threadIdx.x;
+    const size_t sb = (size_t)blockIdx.z * L.B + blockIdx.y;
+    const int *off = v.off + sb * (n + 1);
+    int4 *ent = v.ent + sb * n;
+    int lo = 0, hi = 0;
+    if (q < n) { lo = off[q]; hi = off[q + 1]; }
+    const int len = hi - lo;            // a pair is put in order by its reader (k_fusion_level_bwd_anchor)
+    if ((len >= 3 && len <= ANC_SERIAL) || len > kWave * ANC_KMAX) anc_sort_serial(ent, lo, hi);
+    unsigned long long todo = __ballot(len > ANC_SERIAL && len <= kWave * ANC_KMAX);
+    while (todo) {
+        const int src = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        anc_sort_wave(ent, __shfl(lo, src), __shfl(hi, src));
     }
 }
 

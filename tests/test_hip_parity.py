@@ -969,6 +969,48 @@ def test_fusion_levels_full_pyramids_vs_oracle(dev, pyr, fusion_bwd):
         assert rel_err(N(tf[2][i].grad), gp[i]) <= 1e-5
 
 
+@pytest.mark.parametrize("kind", ["leaves_right", "leaves_corner", "mixed"])
+def test_fusion_adjoint_with_flows_that_leave_the_image(dev, kind):
+    """a flow field that leaves the image clamps its taps to the border, so a whole row's (or, towards a
+    corner, a whole image's) pixels pile on ONE border anchor: lists of hundreds of entries (wave-cooperative rank sort,
+    `anc_sort_wave`) up to a whole level (serial fallback beyond 1,024) instead of the usual one or two.  The anchor
+    lists' adjoint against the oracle, and bit-reproducible across two backward passes."""
+    from mono_vifi_amd import ops, synthetic
+    rng = np.random.default_rng(17)
+    B, H, W = 2, 64, 160
+    chans, strides = [16, 24], [2, 4]
+    feats = [[rng.standard_normal((B, c, H // s, W // s)).astype(np.float32) for c, s in zip(chans, strides)] for _ in range(3)]
+    base = synthetic._box3((3 * rng.standard_normal((B, 2, H, W))).astype(np.float32))
+    flows = []
+    for sgn in (1.0, -1.0):
+        f = base.copy()
+        if kind == "leaves_right":
+            f[:, 0] += sgn * 2.0 * W                       # every tap beyond the right / left border: lists of w entries
+        elif kind == "leaves_corner":
+            f[:, 0] += sgn * 2.0 * W
+            f[:, 1] += sgn * 2.0 * H                       # ... and beyond the bottom / top: one list of h * w entries
+        else:
+            f[:, 0, :, W // 2:] += sgn * 2.0 * W           # half of every row leaves
+        flows.append(np.ascontiguousarray(f))
+    mask = rng.random((B, 1, H, W)).astype(np.float32)
+    want = O.fusion_forward(feats, flows, mask, False)
+    wts = [rng.standard_normal(w.shape).astype(np.float32) for w in want]
+    gn, g0, gp = O.fusion_backward(feats, flows, mask, wts)
+    sizes = [tuple(f.shape[-2:]) for f in feats[1]]
+    grads = []
+    for _ in range(2):
+        tf = [[T(f, dev, True) for f in lvl] for lvl in feats]
+        preps = ops.fusion_prep(T(flows[0], dev), T(flows[1], dev), T(mask, dev), sizes, False)
+        outs = [ops.fusion_level(tf[1][i], tf[0][i], tf[2][i], preps[i], lists=(preps.lists, i)) for i in range(len(chans))]
+        sum((o * T(wts[i], dev)).sum() for i, o in enumerate(outs)).backward()
+        grads.append([(tf[0][i].grad.clone(), tf[2][i].grad.clone()) for i in range(len(chans))])
+    for i in range(len(chans)):
+        assert torch.equal(grads[0][i][0], grads[1][i][0]) and torch.equal(grads[0][i][1], grads[1][i][1])
+        # (thousands of terms pile on one cell: the fp32 sums of oracle and kernel run in the same sorted order)
+        assert rel_err(N(grads[0][i][0]), gn[i]) <= 2e-5
+        assert rel_err(N(grads[0][i][1]), gp[i]) <= 2e-5
+
+
 def test_fusion_module_fused_equals_op_by_op(dev):
     """FusionModule on the device: the fused levels against the module's own op-by-op form
     (warp kernel + torch interpolate / sin / cos / cat), outputs and parameter / feature grads."""
