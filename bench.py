@@ -661,7 +661,7 @@ def main():
         out = {"metric": metric, "value": round(images / elapsed, 2), "unit": "images/sec", "n_gpus": n_gpus,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": (f"{workload}: " + (step.describe() or ""))[:200],
+               "config": {"workload": (f"{workload}: " + (getattr(step, "describe_short", step.describe)() or ""))[:200],
                           "global_batch": args.batch * world, "parallelism": f"dp{world}"},
                "roofline": roofline}
         if n_gpus != world:

@@ -54,5 +54,13 @@ class TrainStep:
                 f"(data loading excluded), nets {'bf16 autocast' if o.amp_bf16 else 'fp32'}"
                 f"{(', forward + backward + gradient exchange replayed as one HIP graph, clipping + AdamW eager' if o.hip_graph_scope != 'step' else ', device work of the whole step replayed as one HIP graph') if o.hip_graph else ''}")
 
+    def describe_short(self):
+        """The same in at most 200 characters (the bench line's config.workload)."""
+        o = self.opts
+        units = ("6+3 units per launch" if o.merge_unit_groups else "3 units per launch") if o.batch_units else "1 unit per launch"
+        return (f"optimisation step (train.py:640-696), {o.backbone} {o.width}x{o.height} 3-frame, batch {o.batch_size}/GPU, "
+                f"use_affine, {o.fuse_model_type}, 9 fused units ({units}), AdamW, "
+                f"{'bf16 autocast' if o.amp_bf16 else 'fp32'}{', HIP graph' if o.hip_graph else ''}, device-resident batch")
+
     def __call__(self):
         return self.trainer.optimisation_step(dict(self.batch))
