@@ -46,6 +46,34 @@ def dump(shape, path):
     loss.backward()
     np.savez(path, loss=float(loss.detach()), argmin=argmin.cpu().numpy(), idx=idx.cpu().numpy(),
              gd=disp.grad.cpu().numpy(), gT=Tt.grad.cpu().numpy())
+    # the SEPARATE forward and backward unit kernels (mvf_unit_fwd / mvf_unit_bwd, the non-training route: SURVEY 8d asks
+    # for forward and backward on their own): library events around 20 launches each, 44 / 45 algorithmic B/px
+    from mono_vifi_amd import _native as nat
+    ops.UNIT_FWDBWD = False
+    cfgt = (2, 0, 1e-3, 0.1, 100.0, 1e-7, False, False)
+    args = (t(inp["tgt"]), Tt, t(inp["K"]), t(inp["inv_K"]), None, t(inp["noise"]), cfgt, t(inp["src"][0]), t(inp["src"][1]))
+
+    def once():
+        disp.grad = None
+        Tt.grad = None
+        ops.Unit.apply(disp, *args)[0].backward()
+    for _ in range(3):
+        once()
+    torch.cuda.synchronize()
+    nat.check(nat.lib().mvf_profile_reset(), "reset")
+    nat.check(nat.lib().mvf_profile_enable(1), "enable")
+    for _ in range(20):
+        once()
+    torch.cuda.synchronize()
+    nat.lib().mvf_profile_enable(0)
+    px = B * H * W
+    sep = {}
+    for name, kid, bpp in (("fwd", nat.PROF_UNIT_FWD, 44), ("bwd", nat.PROF_UNIT_BWD, 45)):
+        ms, n = nat.profile_read(kid)
+        if n:
+            us = ms / n * 1e3
+            sep[name] = {"us_per_unit": round(us, 2), "frac": round(bpp * px / (us * 1e-6) / 8e12, 4), "launches": n}
+    print("SEPARATE " + json.dumps(sep))
 
 
 def compare(a, b):
@@ -81,8 +109,11 @@ def main():
                 continue
             rf = json.loads(line[-1])["roofline"]
             row[mode] = {k: rf.get(k) for k in ("us_per_unit", "frac", "achieved", "valu_instr_per_px", "valu_busy", "avg_us")}
-            subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", name, os.path.join(tmp, f"{name}_{mode}.npz")],
-                           env=env, check=True, timeout=600)
+            r2 = subprocess.run([sys.executable, os.path.abspath(__file__), "--dump", name, os.path.join(tmp, f"{name}_{mode}.npz")],
+                                env=env, check=True, timeout=600, capture_output=True, text=True)
+            for ln in r2.stdout.splitlines():
+                if ln.startswith("SEPARATE "):
+                    row[mode]["separate_kernels"] = json.loads(ln[9:])
         if "us_per_unit" in row.get("exact", {}) and "us_per_unit" in row.get("fast", {}):
             row["fast_over_exact_time"] = round(row["fast"]["us_per_unit"] / row["exact"]["us_per_unit"], 4)
             row["deviation"] = compare(np.load(os.path.join(tmp, f"{name}_exact.npz")), np.load(os.path.join(tmp, f"{name}_fast.npz")))
