@@ -743,7 +743,8 @@ def test_affine_batched_forms_equal_single_calls(dev):
 
 
 # ------------------------------------------------------------------ f2: affine glue
-AFFINE_SHAPES = [(2, 3, 32, 64), (3, 1, 37, 101), (2, 2, 5, 7), (12, 3, 192, 640), (8, 1, 320, 1024)]
+AFFINE_SHAPES = [(2, 3, 32, 64), (3, 1, 37, 101), (2, 2, 5, 7), (12, 3, 192, 640), (8, 1, 320, 1024),
+                 (2, 6, 20, 70)]       # (six channels: two LDS chunks of the round-6 transform kernel)
 
 
 @pytest.mark.parametrize("shape", AFFINE_SHAPES)
