@@ -61,8 +61,8 @@ UNIT_KERNEL = "k_unit_fb<2>"
 REFERENCE_CPU_SAMPLES_PER_S = {(4, 192, 640): 15.9, (12, 192, 640): 10.1, (8, 320, 1024): 3.9, (12, 192, 512): 23.8}
 REFERENCE_CPU_CORES = 8
 # same-core calibration in the build container (tools/cpu_reference_calibration.py, profiles/r06_cpu_baseline_calibration.json): the
-# C / OpenMP port runs a unit fwd + bwd this many times faster than the reference's own code on the same 8 cores (3.7-4.7 over runs)
-PORT_OVER_REFERENCE = 3.93
+# C / OpenMP port runs a unit fwd + bwd this many times faster than the reference's own code on the same 8 cores (2.8-3.0 over runs)
+PORT_OVER_REFERENCE = 2.9
 HOST_CPU = {}                  # CPU time of the last timed region (this rank)
 
 
@@ -71,8 +71,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=os.environ.get("MVF_BENCH_WORKLOAD", "train"),
-                    choices=["auto", "hotpath", "train", "mock"])
+    ap.add_argument("--workload", default=os.environ.get("MVF_BENCH_WORKLOAD", "train"), choices=["auto", "hotpath", "train", "mock"])
     ap.add_argument("--batch", type=int, default=12)
     ap.add_argument("--height", type=int, default=192)
     ap.add_argument("--width", type=int, default=640)
@@ -163,7 +162,6 @@ def dist_setup(args):
 
 def reducer_of(step):
     return getattr(getattr(step, "trainer", step), "reducer", None)
-
 
 def comm_report(args, rank, dev, backend, step, counts_per_step):
     """What the process group itself says about the job (all ranks call this); compact: it rides in the line."""
@@ -323,8 +321,7 @@ class HotPathStep:
 
 
 def cpu_quota():
-    """(CPUs the container may use, hardware threads it sees): the cgroup quota if there is one, else the affinity mask.
-    The gpurun boxes show 256 hardware threads and grant 16 CPUs (cpu.max = 1600000 100000)."""
+    """(CPUs the container may use, hardware threads it sees): cgroup quota, else affinity mask (gpurun boxes: 16 of 256)."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         with open("/sys/fs/cgroup/cpu.max") as f:
@@ -353,6 +350,10 @@ def cpu_baseline(args):
     T = np.stack([O.pose(inp["axisangle"][k], inp["translation"][k], invert=(k == 1)) for k in range(2)], 0)
     cores, hw = cpu_quota()
     threads = O.set_threads(cores)
+    # the port's ~100 MB of output arrays per call come from the heap and are reused (M_MMAP_THRESHOLD / M_TRIM_THRESHOLD
+    # raised): by default every call page-faults them afresh or not depending on what the process freed before (24 vs 36)
+    libc = __import__("ctypes").CDLL(None)
+    libc.mallopt(-3, 1 << 30), libc.mallopt(-1, (1 << 31) - 1)
 
     def one():
         O.unit(inp["disp"], inp["tgt"], inp["src"], T, inp["K"], inp["inv_K"], inp["noise"], inp["mask_rec"], 0,

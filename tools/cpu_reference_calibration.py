@@ -58,6 +58,8 @@ def port_unit():
 
 
 O.set_threads(threads)
+libc = __import__("ctypes").CDLL(None)              # large buffers from the heap, reused (as bench.cpu_baseline does)
+libc.mallopt(-3, 1 << 30), libc.mallopt(-1, (1 << 31) - 1)
 fns = (("reference", reference_unit), ("torch_unfused", unfused_unit), ("c_port_openmp", port_unit))
 times = {n: [] for n, _ in fns}
 loss = {}

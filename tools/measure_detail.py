@@ -12,6 +12,8 @@ measurements below used to ride in that line and grew it to 20 KB (VERDICT r05);
 * ``host``           -- the step pinned to the CPUs one of eight ranks would have (child processes, eager and graph)
 * ``conv_mfma``      -- MFMA / VALU utilisation of the step's kernels by family (child under rocprofv3 --pmc)
 * ``cpu_unfused``    -- second CPU baseline: the unit as ~130 ATen operators under autograd (oracle/torch_unfused.py)
+* ``fast_mode``      -- ``frac_fast`` / ``us_per_unit_fast``: the hot-path loop through the opt-in fast library (child process
+                        with MVF_HOTPATH_LIB), beside the same loop through the shipped one
 
 `run()` gets bench.py's module object (its step classes, timing and roofline helpers) instead of importing it a second
 time.  Every leg is optional and must never take the line down: errors are recorded in the leg's entry."""
@@ -34,7 +36,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
-LEGS = ("own_kernels", "unit_launches", "hotpath_graph", "other_configs", "hip_graph_step", "host", "conv_mfma", "cpu_unfused")
+LEGS = ("own_kernels", "unit_launches", "hotpath_graph", "other_configs", "hip_graph_step", "host", "conv_mfma", "cpu_unfused",
+        "fast_mode")
 
 OTHER_CONFIGS = {
     # BASELINE.json configs[2..4] at their per-GPU shapes (reference: configs/dhrnet/DHRNet_KITTI_MR.txt,
@@ -295,6 +298,8 @@ def cpu_unfused(B, args):
         U.unit(tens[0], tens[1], srcs, tens[2], tens[3], tens[4], tens[5], tens[6], 0)
     old = torch.get_num_threads()
     samples = []
+    libc = __import__("ctypes").CDLL(None)          # buffers reused, as in bench.cpu_baseline
+    libc.mallopt(-3, 1 << 30), libc.mallopt(-1, (1 << 31) - 1)
     try:
         torch.set_num_threads(cores)
         one()
@@ -312,6 +317,25 @@ def cpu_unfused(B, args):
     return {"value": round(statistics.median(samples), 3), "unit": "images/sec", "cores": cores, "threads": cores, "kind": "port",
             "runs": 3, "min": round(min(samples), 3), "max": round(max(samples), 3), "hardware_threads": hw,
             "sample": "1 unit fwd+bwd per call as ~130 ATen ops under autograd; value = hot-path part of a step (9 units)"}
+
+
+def fast_mode(args, timeout_s=240):
+    """What the reference's evaluation order costs: the stand-alone hot-path loop through the exact
+    library and through `make fast`'s (separable shared window sums, contracted formula), each in a child process.  The
+    deviation report at the four shapes is tools/fast_mode_report.py -> profiles/r06_fast_mode_report.json."""
+    lib = os.path.join(ROOT, "mono-vifi_amd", "lib")
+    fast = os.path.join(lib, "libmvf_hotpath_fast.so")
+    if not os.path.exists(fast):
+        return {"error": "libmvf_hotpath_fast.so not built (make -C mono-vifi_amd/csrc fast)"}
+    out = {}
+    for mode, path in (("exact", os.path.join(lib, "libmvf_hotpath.so")), ("fast", fast)):
+        d = _child_line([sys.executable, BENCH, "--workload", "hotpath", "--steps", "50", "--warmup", "5", "--no-cpu-baseline",
+                         "--no-pmc-leg", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width)],
+                        timeout_s, env_extra={"MVF_HOTPATH_LIB": path})
+        out[f"frac_{mode}"] = d["roofline"]["frac"]
+        out[f"us_per_unit_{mode}"] = d["roofline"]["us_per_unit"]
+    out["fast_over_exact_time"] = round(out["us_per_unit_fast"] / out["us_per_unit_exact"], 4)
+    return out
 
 
 def run(B, args, step, nat, rank, world, dev, hp_step):
@@ -361,4 +385,5 @@ def run(B, args, step, nat, rank, world, dev, hp_step):
         leg("host", host, B, args)
         leg("conv_mfma", conv_mfma, args)
     leg("cpu_unfused", cpu_unfused, B, args)
+    leg("fast_mode", fast_mode, args)
     return out
