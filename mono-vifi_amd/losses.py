@@ -138,7 +138,7 @@ class HotPathLosses:
             # a disparity that is a view of its head's output (ops.disp_head): the unit reads it in place and leaves
             # its raw gradient to the head's adjoint kernel (ops.HeadSink) -- no scaled copy, no re-interleaving stack
             sink = un["disp_tgt"].get(("disp_head_sink", 0)) if defer else None
-            where = sink.covers(disp) if (sink is not None and disp.requires_grad) else None
+            where = sink.claim(disp) if (sink is not None and disp.requires_grad) else None
             if where is not None:
                 sinks.append((sink, where[0], where[1]))
                 if not any(t is sink.token for t in tokens):

@@ -1288,6 +1288,18 @@ class HeadSink:
         # a cycle through the node would keep the head's tensors alive until the garbage collector runs)
         self.token, self.entries = token, entries
         self.storage, self.offset, self.shape = disp.untyped_storage().data_ptr(), disp.storage_offset(), tuple(disp.shape)
+        # units that have claimed this head in the current forward: the head's adjoint kernel takes at most MAX_UNITS of them;
+        # a further one gets `None` from claim() and returns its (scaled) gradient through autograd as any other consumer
+        # does (the backward used to raise)
+        self.claimed = 0
+
+    def claim(self, view):
+        """covers(view) if this head can still take a deferred unit, else None (the caller falls back)."""
+        where = self.covers(view)
+        if where is None or self.claimed >= nat.MAX_UNITS:
+            return None
+        self.claimed += 1
+        return where
 
     def covers(self, view):
         """(first image, image step) of `view` [B,1,H,W] inside the head's batch, or None if it is not such a view."""

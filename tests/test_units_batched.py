@@ -412,6 +412,58 @@ def test_deferred_unit_gradients_through_the_disparity_head(dev, shape, G, with_
         assert float(np.abs(b[1].reshape(B, G, -1)[:, n:]).max()) == 0.0
 
 
+def test_more_deferred_units_than_the_head_kernel_takes_fall_back(dev):
+    """a disparity head's adjoint kernel takes the raw gradients of at most MAX_UNITS units; the backward
+    used to raise when more had been deposited.  Ten units in two launches read ONE head's output in place: eight are
+    deferred, the other two return their scaled gradient through autograd, and the logit gradient equals the
+    all-through-autograd route within rounding (the two routes add the same terms in another order)."""
+    from types import SimpleNamespace
+    from mono_vifi_amd import ops
+    from mono_vifi_amd import _native as nat
+    from mono_vifi_amd.losses import HotPathLosses
+    B, H, W, G = 1, 40, 72, 10
+    assert G > nat.MAX_UNITS
+    inps = [_inputs(7300 + 31 * u, B, H, W, 0, with_mask=False) for u in range(G)]
+    logit0 = torch.empty((B * G, 1, H, W), device=dev)
+    for g in range(G):
+        dnp = np.clip(inps[g]["disp"], 1e-4, 1 - 1e-4)
+        logit0.view(B, G, 1, H, W)[:, g] = T(np.log(dnp / (1 - dnp)).astype(np.float32), dev)
+
+    class L(HotPathLosses):
+        pass
+
+    def run(defer):
+        l = L()
+        l.opt = SimpleNamespace(min_depth=0.1, max_depth=100.0, no_ssim=False, avg_reprojection=False,
+                                disable_automasking=False, disparity_smoothness=1e-3, inkernel_noise=False,
+                                batch_units=True, defer_unit_grads=defer)
+        logit = logit0.clone().requires_grad_(True)
+        disp, _, part, sink = ops.disp_head(logit, 0.1, 100.0, want_depth=False, want_sink=True)
+        views = torch.unbind(disp.view(B, G, 1, H, W), 1)
+        parts = torch.unbind(part.view(B, G, 32), 1)
+        total = None
+        for lo, hi in ((0, 5), (5, 10)):
+            units = []
+            for u in range(lo, hi):
+                inp = inps[u]
+                units.append(dict(disp_tgt={("disp", 0): views[u], ("disp_mean_partials", 0): parts[u].contiguous(),
+                                            ("disp_head_sink", 0): sink},
+                                  img_tgt=T(inp["tgt"], dev), poses=T(inp["T"], dev, True),
+                                  imgs_src=[T(inp["src"][0], dev), T(inp["src"][1], dev)], K=T(inp["K"], dev),
+                                  inv_K=T(inp["inv_K"], dev), mask_rec=None))
+            torch.manual_seed(11 + lo)
+            total, _, _ = l.compute_units(units, want_sum=True, sum_in=total)
+        total.backward()
+        return float(total.detach()), N(logit.grad), sink.claimed
+
+    a, b = run(False), run(True)
+    assert a[2] == 0 and b[2] == nat.MAX_UNITS
+    assert a[0] == b[0]
+    assert float(np.abs(a[1] - b[1]).max()) <= 1e-6 * float(np.abs(a[1]).max())
+    assert float(np.abs(b[1].reshape(B, G, -1)).min(axis=(0, 2)).max()) >= 0.0 and all(
+        float(np.abs(b[1].reshape(B, G, -1)[:, g]).max()) > 0.0 for g in range(G))       # every group got its gradient
+
+
 @pytest.mark.parametrize("shape", [(2, 33, 70), (3, 37, 53), (1, 64, 200), (4, 192, 640), (2, 320, 1024)])
 def test_preparing_launch_means_equal_the_heads_partials(dev, shape):
     """The mean disparity a launch computes itself (k_units_prepare: 32 chunk sums per image, sixteen loads in
